@@ -1,0 +1,111 @@
+"""CPU: cross-check the oracle's restatement of the (absent, unpinned) TensorFlow forward semantics
+against an independent torch-CPU fp32 formulation: SAME padding asymmetry, HWIO weights, NHWC flatten
+order, batch-norm with biased batch variance, first-max argmax.  Tolerance 1e-4 (summation order)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def _torch_forward(L, th, obs_u8, kind, ref_u8=None):
+    th = torch.from_numpy(th)
+    A = L.nact
+
+    def t(off, shape):
+        n = int(np.prod(shape))
+        return th[off:off + n].reshape(shape)
+
+    w1 = t(L.c1w, (8, 8, 4, 16)).permute(3, 2, 0, 1); b1 = t(L.c1b, (16,))
+    w2 = t(L.c2w, (4, 4, 16, 32)).permute(3, 2, 0, 1); b2 = t(L.c2b, (32,))
+    wf = t(L.fcw, (3872, 256)); bf = t(L.fcb, (256,))
+    wo = t(L.ow, (256, A)); bo = t(L.ob, (A,))
+
+    def trunk(x_u8, stats=None, collect=None):
+        x = torch.from_numpy(x_u8.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2)
+        y1 = F.conv2d(F.pad(x, (2, 2, 2, 2)), w1, b1, stride=4)          # SAME: 2/2
+        a1 = bn(y1, 1, stats, collect)
+        y2 = F.conv2d(F.pad(a1, (1, 2, 1, 2)), w2, b2, stride=2)         # SAME: 1 before, 2 after
+        a2 = bn(y2, 2, stats, collect)
+        flat = a2.permute(0, 2, 3, 1).reshape(x.shape[0], 3872)          # NHWC flatten
+        y3 = flat @ wf + bf
+        a3 = bn(y3, 3, stats, collect)
+        return y1, y2, y3, a3 @ wo + bo
+
+    def bn(y, i, stats, collect):
+        if kind == 1:
+            return torch.relu(y)
+        beta = t(getattr(L, "bn%db" % i), (y.shape[1],)); gamma = t(getattr(L, "bn%dg" % i), (y.shape[1],))
+        dims = [0, 2, 3] if y.dim() == 4 else [0]
+        if collect is not None:
+            mean = y.mean(dims); var = y.var(dims, unbiased=False)
+            collect[i] = (mean, var)
+        else:
+            mean, var = stats[i]
+        shp = [1, -1, 1, 1] if y.dim() == 4 else [1, -1]
+        out = (y - mean.reshape(shp)) * (gamma / torch.sqrt(var + 1e-3)).reshape(shp) + beta.reshape(shp)
+        return torch.relu(out)
+
+    stats = None
+    if kind == 0:
+        stats = {}
+        trunk(ref_u8, collect=stats)
+    return [v.numpy() for v in trunk(obs_u8, stats=stats)], stats
+
+
+@pytest.mark.parametrize("kind,nact", [(0, 18), (1, 18), (0, 14)])
+def test_forward_vs_torch(oracle, kind, nact):
+    O = oracle
+    L = O.layout(kind, nact)
+    rs = np.random.RandomState(7 + kind)
+    if kind == 0:
+        th = O.es_init_theta(L, 0)
+        th += (0.02 * rs.randn(L.P)).astype(np.float32)  # perturbed betas/gammas/biases too
+    else:
+        th = O.ga_normc(L, rs.randn(L.P).astype(np.float32))
+        th += (0.005 * rs.randn(L.P)).astype(np.float32)
+    ref = O.get_ref_batch(seed=0, batch_size=16, nact=nact)
+    obs = rs.randint(0, 256, (4, 84, 84, 4)).astype(np.uint8)
+    obs[1] = ref[3]
+    bn = O.es_ref_pass(L, th, ref) if kind == 0 else None
+    (y1, y2, y3, lg), stats = _torch_forward(L, th, obs, kind, ref)
+    for i in range(obs.shape[0]):
+        o1, o2, o3, ol = O.forward_debug(L, th, bn, obs[i])
+        assert np.allclose(o1.reshape(21, 21, 16), y1[i].transpose(1, 2, 0), atol=1e-4, rtol=1e-4)
+        assert np.allclose(o2.reshape(11, 11, 32), y2[i].transpose(1, 2, 0), atol=2e-4, rtol=1e-4)
+        assert np.allclose(o3, y3[i], atol=5e-4, rtol=1e-4)
+        assert np.allclose(ol, lg[i], atol=5e-4, rtol=1e-4)
+        a, _ = O.act(L, th, bn, obs[i])
+        srt = np.sort(lg[i])
+        if srt[-1] - srt[-2] > 1e-3:
+            assert a == int(np.argmax(lg[i]))
+    if kind == 0:
+        # scale/shift agree with torch's batch moments
+        for i, (o, C) in enumerate(((0, 16), (32, 32), (96, 256)), 1):
+            mean, var = stats[i]
+            gamma = th[getattr(L, "bn%dg" % i):][:C]; beta = th[getattr(L, "bn%db" % i):][:C]
+            sc = gamma / np.sqrt(var.numpy() + 1e-3)
+            assert np.allclose(bn[o:o + C], sc, rtol=1e-4, atol=1e-6)
+            assert np.allclose(bn[o + C:o + 2 * C], beta - mean.numpy() * sc, rtol=1e-3, atol=1e-4)
+
+
+def test_argmax_first_max(oracle):
+    O = oracle
+    L = O.layout(O.KIND_GA, 18)
+    th = np.zeros(L.P, np.float32)  # all logits equal -> first index (tf.argmax)
+    a, lg = O.act(L, th, None, np.zeros((84, 84, 4), np.uint8))
+    assert a == 0 and not lg.any()
+    th[L.ob + 5] = 1.0; th[L.ob + 9] = 1.0
+    a, _ = O.act(L, th, None, np.zeros((84, 84, 4), np.uint8))
+    assert a == 5
+
+
+def test_antithetic_symmetry(oracle, small_noise):
+    # gpu_implementation/es.py:182-183: the reference's only numeric tolerance
+    O = oracle
+    L = O.layout(O.KIND_ES)
+    th = O.es_init_theta(L, 0)
+    idx = 12345
+    p = O.perturb(th, small_noise, idx, 0.02, +1); n = O.perturb(th, small_noise, idx, 0.02, -1)
+    assert np.abs((p + n) / 2 - th).max() < 1e-5
+    v = np.float32(0.02) * small_noise[idx:idx + L.P]
+    assert np.array_equal(p, th + v) and np.array_equal(n, th - v)
