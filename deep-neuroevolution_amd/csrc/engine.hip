@@ -1,0 +1,946 @@
+// engine.hip -- host side of libdne_hip.so: the C ABI of include/dne_hip.h over the gfx950 kernels in
+// env_synth.h / forward.h / reduce.h.  One handle = one HIP device + one stream; all state (noise table,
+// parent vectors, optimizer moments, frame stacks, emulator RAM, activations) lives in HBM for the
+// lifetime of the handle, and a generation only moves (noise_idx, seed) in and (return, length) out.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dne_hip.h"
+#include "env_synth.h"
+#include "forward.h"
+#include "reduce.h"
+
+using namespace dne;
+
+static thread_local std::string g_create_error;
+
+#define HCHECK(h, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) return (h)->fail("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------- env kernels
+struct EnvArgs {
+    uint8_t *ram_prev, *ram_cur;     // [M][128]
+    uint8_t *stacks;                 // [M][84][84][4]
+    const ResizeTables *T;
+    float *ret, *sign, *step_reward; // [M]
+    int32_t *len, *done;
+    const int32_t *action;
+    uint8_t *bc;
+    int bc_mode;                     // 0 none, 1 RAM per step (ES, policies.py:410,418), 2 final RAM (GA, policies.py:510)
+    int bc_max_steps;
+};
+
+__device__ __forceinline__ void ram_copy(uint8_t *dst, const uint8_t *src) {
+    for (int j = 0; j < 32; j++) ((uint32_t *)dst)[j] = ((const uint32_t *)src)[j];
+}
+
+// atari_wrappers.py:95-107: repeat the action 4 raw frames, sum rewards, stop at game over
+__device__ inline int skip4(EnvLds &s, int action, int *over) {
+    int tot = 0;
+    *over = 0;
+    for (int i = 0; i < 4; i++) {
+        ram_copy(s.ram_prev, s.ram_cur);
+        tot += synth_frame(s.ram_cur, action);
+        if (s.ram_cur[RM_OVER]) { *over = 1; break; }
+    }
+    return tot;
+}
+
+__global__ __launch_bounds__(256) void k_env_reset(EnvArgs E, const uint32_t *__restrict__ seeds, int n) {
+    __shared__ __attribute__((aligned(16))) EnvLds s;
+    const int m = blockIdx.x, tid = threadIdx.x;
+    s.gray2[tid] = E.T->gray2[tid];
+    if (tid == 0) {
+        const uint32_t seed = seeds[m];
+        synth_reset(s.ram_cur, seed);                    // env.reset()
+        ram_copy(s.ram_prev, s.ram_cur);
+        const int noops = 1 + (int)(seed % 30u);         // atari_wrappers.py:18-31 (count fixed by the seed)
+        for (int i = 0; i < noops; i++) { ram_copy(s.ram_prev, s.ram_cur); synth_frame(s.ram_cur, 0); }
+        int over;
+        skip4(s, 1, &over);                              // atari_wrappers.py:40-48 FIRE then action 2
+        skip4(s, 2, &over);
+        E.ret[m] = 0.0f; E.sign[m] = 0.0f; E.step_reward[m] = 0.0f; E.len[m] = 0; E.done[m] = 0;
+    }
+    __syncthreads();
+    synth_observe(s, E.T, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), true);   // FrameStack reset: 4 copies
+    __syncthreads();
+    if (tid < 128) {
+        E.ram_prev[(size_t)m * 128 + tid] = s.ram_prev[tid];
+        E.ram_cur[(size_t)m * 128 + tid] = s.ram_cur[tid];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_env_step(EnvArgs E, const int *__restrict__ list, int gsize, int tslimit) {
+    __shared__ __attribute__((aligned(16))) EnvLds s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int g = list ? list[b / gsize] : b / gsize;
+    const int m = g * gsize + b % gsize;
+    if (E.done[m]) return;
+    s.gray2[tid] = E.T->gray2[tid];
+    if (tid < 128) {
+        s.ram_prev[tid] = E.ram_prev[(size_t)m * 128 + tid];
+        s.ram_cur[tid] = E.ram_cur[(size_t)m * 128 + tid];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int over;
+        s.misc[0] = skip4(s, E.action[m], &over);
+        s.misc[1] = over;
+    }
+    __syncthreads();
+    synth_observe(s, E.T, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), false);
+    __syncthreads();
+    const int t = E.len[m];
+    if (tid < 128) {
+        E.ram_prev[(size_t)m * 128 + tid] = s.ram_prev[tid];
+        E.ram_cur[(size_t)m * 128 + tid] = s.ram_cur[tid];
+        if (E.bc_mode == 1 && t < E.bc_max_steps) E.bc[((size_t)m * E.bc_max_steps + t) * 128 + tid] = s.ram_cur[tid];
+        if (E.bc_mode == 2) E.bc[(size_t)m * 128 + tid] = s.ram_cur[tid];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int r = s.misc[0];
+        E.ret[m] += (float)r;                                    // es.py:425 rews.sum()
+        E.sign[m] += (float)((r > 0) - (r < 0));                 // es.py:423 np.sign(rews).sum()
+        E.step_reward[m] = (float)r;
+        E.len[m] = t + 1;
+        if (s.misc[1] || t + 1 >= tslimit) E.done[m] = 1;       // policies.py:401,424-425
+    }
+}
+
+// order-preserving compaction of the active-group list
+__global__ __launch_bounds__(1024) void k_compact(const int32_t *__restrict__ done, int gsize, const int *__restrict__ list_in,
+                                                  int n_in, int *__restrict__ list_out, int *__restrict__ count_out) {
+    __shared__ int wave_tot[16];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    int running = 0;
+    for (int start = 0; start < n_in; start += 1024) {
+        const int i = start + tid;
+        int g = -1;
+        bool alive = false;
+        if (i < n_in) {
+            g = list_in ? list_in[i] : i;
+            for (int k = 0; k < gsize; k++) alive = alive || !done[g * gsize + k];
+        }
+        const unsigned long long bal = __ballot(alive);
+        if (lane == 0) wave_tot[wv] = __popcll(bal);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int k = 0; k < 16; k++) { before += k < wv ? wave_tot[k] : 0; total += wave_tot[k]; }
+        if (alive) list_out[running + before + __popcll(bal & ((1ull << lane) - 1ull))] = g;
+        running += total;
+        __syncthreads();
+    }
+    if (tid == 0) *count_out = running;
+}
+
+__global__ void k_iota(int *p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
+// ------------------------------------------------------------------------------- handle
+struct dne_handle {
+    dne_config cfg{};
+    Layout L{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    int M = 0, F = 0, ref_chunk = 0;
+    size_t base_stride = 0;
+    // device memory
+    float *noise = nullptr; size_t noise_count = 0;
+    float *bases = nullptr; int base_cap = 0;
+    float *opt_m = nullptr, *opt_v = nullptr, *g = nullptr; int opt_t = 0;
+    double *partial = nullptr;
+    uint8_t *ref = nullptr; bool ref_set = false;
+    int32_t *m_slot = nullptr; int64_t *m_off = nullptr; float *m_scale = nullptr;
+    float *bn = nullptr;
+    uint8_t *ram_prev = nullptr, *ram_cur = nullptr, *stacks = nullptr;
+    ResizeTables *tables = nullptr;
+    float *ret = nullptr, *sign = nullptr, *step_reward = nullptr, *logits = nullptr;
+    int32_t *len = nullptr, *done = nullptr, *action = nullptr;
+    uint32_t *seeds = nullptr;
+    float *y1 = nullptr, *y2 = nullptr, *y3 = nullptr; size_t rows_cap = 0;
+    int *list_a = nullptr, *list_b = nullptr, *count_dev = nullptr;
+    uint8_t *bc = nullptr; size_t bc_bytes = 0;
+    float *mat_out = nullptr; size_t mat_cap = 0;
+    float *scratch_f = nullptr; size_t scratch_cap = 0;   // small float scratch (ranks, weights)
+    int64_t *scratch_i = nullptr;
+    // profiling
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    dne_profile prof{};
+    // GA parent cache: prefix chain -> base slot
+    std::map<std::vector<int64_t>, int> ga_cache;
+    std::vector<int> free_slots;
+
+    int fail(const char *fmt, ...) {
+        char buf[1024];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        err = buf;
+        return -1;
+    }
+    FwdArgs fwd(bool use_done) const {
+        FwdArgs A;
+        A.noise = noise; A.bases = bases; A.base_stride = base_stride;
+        A.m_slot = m_slot; A.m_off = m_off; A.m_scale = m_scale; A.bn = bn;
+        A.done = use_done ? done : nullptr; A.L = L;
+        return A;
+    }
+    EnvArgs env(int bc_mode) const {
+        EnvArgs E;
+        E.ram_prev = ram_prev; E.ram_cur = ram_cur; E.stacks = stacks; E.T = tables;
+        E.ret = ret; E.sign = sign; E.step_reward = step_reward; E.len = len; E.done = done; E.action = action;
+        E.bc = bc; E.bc_mode = bc ? bc_mode : 0; E.bc_max_steps = cfg.bc_max_steps;
+        return E;
+    }
+    hipEvent_t event(size_t i) {
+        while (ev_pool.size() <= i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            ev_pool.push_back(e);
+        }
+        return ev_pool[i];
+    }
+};
+
+static void make_layout(int kind, int nact, Layout *L) {
+    int o = 0;
+    memset(L, 0, sizeof(*L));
+    L->kind = kind; L->nact = nact;
+    auto take = [&](int n) { int r = o; o += n; return r; };
+    if (kind == DNE_KIND_ES) {   // creation order of trainable variables, policies.py:319-330
+        L->c1w = take(4096); L->c1b = take(16); L->bn1b = take(16); L->bn1g = take(16);
+        L->c2w = take(8192); L->c2b = take(32); L->bn2b = take(32); L->bn2g = take(32);
+        L->fcw = take(3872 * 256); L->fcb = take(256); L->bn3b = take(256); L->bn3g = take(256);
+        L->ow = take(256 * nact); L->ob = take(nact);
+    } else {                     // policies.py:449-459 via tf_util.py:133-162
+        L->c1w = take(4096); L->c1b = take(16); L->c2w = take(8192); L->c2b = take(32);
+        L->fcw = take(3872 * 256); L->fcb = take(256); L->ow = take(256 * nact); L->ob = take(nact);
+        L->bn1b = L->bn1g = L->bn2b = L->bn2g = L->bn3b = L->bn3g = -1;
+    }
+    L->P = o;
+}
+
+// Pillow Resample.c precompute_coeffs (BILINEAR, support 1.0) -- the filter WarpFrame uses
+// (atari_wrappers.py:140-141); third-party algorithm restated from its published source.
+static void pil_coeffs(int in_size, int out_size, int ksize, int *bounds, double *kk) {
+    const double scale = (double)in_size / out_size;
+    const double fscale = scale < 1.0 ? 1.0 : scale;
+    const double support = fscale;
+    for (int xx = 0; xx < out_size; xx++) {
+        const double center = (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double ww = 0.0;
+        double *k = kk + xx * ksize;
+        for (int x = 0; x < ksize; x++) k[x] = 0.0;
+        for (int x = 0; x < xmax; x++) {
+            double t = (x + xmin - center + 0.5) * (1.0 / fscale);
+            t = t < 0 ? -t : t;
+            k[x] = t < 1.0 ? 1.0 - t : 0.0;
+            ww += k[x];
+        }
+        if (ww != 0.0)
+            for (int x = 0; x < xmax; x++) k[x] /= ww;
+        bounds[2 * xx] = xmin;
+        bounds[2 * xx + 1] = xmax;
+    }
+}
+
+static const uint8_t kPalette[16][3] = {
+    {0, 0, 0},       {170, 170, 170}, {45, 50, 184},   {24, 26, 167},  {214, 214, 214}, {0, 28, 136},
+    {236, 236, 236}, {84, 138, 210},  {198, 108, 58},  {181, 83, 40},  {192, 192, 192}, {252, 252, 84},
+    {92, 186, 92},   {74, 74, 74},    {252, 144, 144}, {0, 44, 160}};
+
+static void make_tables(ResizeTables *T) {
+    pil_coeffs(160, 84, 5, T->bh, T->kh);
+    pil_coeffs(210, 84, 7, T->bv, T->kv);
+    for (int a = 0; a < 16; a++)
+        for (int b = 0; b < 16; b++) {   // MaxAndSkip max (atari_wrappers.py:105) then WarpFrame gray (:139)
+            const uint8_t r = std::max(kPalette[a][0], kPalette[b][0]);
+            const uint8_t g = std::max(kPalette[a][1], kPalette[b][1]);
+            const uint8_t bl = std::max(kPalette[a][2], kPalette[b][2]);
+            volatile float t0 = (float)r * 0.299f, t1 = (float)g * 0.587f, t2 = (float)bl * 0.114f;
+            volatile float s = t0 + t1;
+            T->gray2[(a << 4) | b] = s + t2;
+        }
+}
+
+template <typename T>
+static hipError_t dalloc(T **p, size_t n) {
+    return hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T));
+}
+
+extern "C" int dne_num_params(int kind, int nact) {
+    Layout L;
+    make_layout(kind, nact, &L);
+    return L.P;
+}
+
+extern "C" const char *dne_last_error(dne_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+static int grow_bases(dne_handle *h, int cap) {
+    if (cap <= h->base_cap) return 0;
+    float *nb = nullptr;
+    HCHECK(h, dalloc(&nb, (size_t)cap * h->base_stride));
+    if (h->bases) {
+        HCHECK(h, hipMemcpyAsync(nb, h->bases, (size_t)h->base_cap * h->base_stride * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        HCHECK(h, hipStreamSynchronize(h->stream));
+        HCHECK(h, hipFree(h->bases));
+    }
+    for (int s = cap - 1; s >= std::max(h->base_cap, 1); s--) h->free_slots.push_back(s);
+    h->bases = nb;
+    h->base_cap = cap;
+    return 0;
+}
+
+extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        g_create_error = "dne_create: no HIP device visible (this engine has no CPU fallback)";
+        return -1;
+    }
+    if (cfg->max_members <= 0 || cfg->n_actions <= 1 || cfg->n_actions > 32 ||
+        (cfg->policy_kind != DNE_KIND_ES && cfg->policy_kind != DNE_KIND_GA)) {
+        g_create_error = "dne_create: bad config";
+        return -1;
+    }
+    dne_handle *h = new dne_handle();
+    h->cfg = *cfg;
+    auto bail = [&](int) { g_create_error = h->err; delete h; return -1; };
+#define CCHECK(expr) do { if ((expr) != 0) return bail(0); } while (0)
+#define CH(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { h->fail("%s -> %s", #expr, hipGetErrorString(_e)); return bail(0); } } while (0)
+    CH(hipSetDevice(cfg->device_id));
+    CH(hipStreamCreate(&h->stream));
+    make_layout(cfg->policy_kind, cfg->n_actions, &h->L);
+    h->M = cfg->max_members;
+    h->F = cfg->policy_kind == DNE_KIND_ES ? (cfg->ref_count > 0 ? cfg->ref_count : 128) : 0;
+    if (h->F % 8) { h->fail("ref_count must be a multiple of 8"); return bail(0); }
+    h->ref_chunk = cfg->ref_chunk > 0 ? cfg->ref_chunk : 512;
+    h->ref_chunk = std::min(h->ref_chunk, h->M);
+    h->base_stride = ((size_t)h->L.P + 63) / 64 * 64;
+    const size_t M = h->M;
+    CCHECK(grow_bases(h, 1));
+    CH(hipMemset(h->bases, 0, h->base_stride * sizeof(float)));
+    CH(dalloc(&h->opt_m, h->L.P)); CH(dalloc(&h->opt_v, h->L.P)); CH(dalloc(&h->g, h->L.P));
+    CH(hipMemset(h->opt_m, 0, h->L.P * sizeof(float))); CH(hipMemset(h->opt_v, 0, h->L.P * sizeof(float)));
+    CH(dalloc(&h->partial, 2 * ((size_t)h->L.P / 256 + 1)));
+    if (h->F) CH(dalloc(&h->ref, (size_t)h->F * OB_BYTES));
+    CH(dalloc(&h->m_slot, M)); CH(dalloc(&h->m_off, M)); CH(dalloc(&h->m_scale, M));
+    CH(hipMemset(h->m_slot, 0, M * sizeof(int32_t))); CH(hipMemset(h->m_off, 0, M * sizeof(int64_t)));
+    CH(hipMemset(h->m_scale, 0, M * sizeof(float)));
+    CH(dalloc(&h->bn, M * 608));
+    CH(dalloc(&h->ram_prev, M * 128)); CH(dalloc(&h->ram_cur, M * 128)); CH(dalloc(&h->stacks, M * OB_BYTES));
+    CH(hipMemset(h->stacks, 0, M * OB_BYTES));
+    CH(dalloc(&h->tables, 1));
+    {
+        ResizeTables T;
+        make_tables(&T);
+        CH(hipMemcpy(h->tables, &T, sizeof(T), hipMemcpyHostToDevice));
+    }
+    CH(dalloc(&h->ret, M)); CH(dalloc(&h->sign, M)); CH(dalloc(&h->step_reward, M));
+    CH(dalloc(&h->logits, M * cfg->n_actions));
+    CH(dalloc(&h->len, M)); CH(dalloc(&h->done, M)); CH(dalloc(&h->action, M)); CH(dalloc(&h->seeds, M));
+    CH(hipMemset(h->done, 0, M * sizeof(int32_t))); CH(hipMemset(h->len, 0, M * sizeof(int32_t)));
+    h->rows_cap = std::max<size_t>(M, (size_t)h->ref_chunk * std::max(h->F, 1));
+    CH(dalloc(&h->y1, h->rows_cap * 7056)); CH(dalloc(&h->y2, h->rows_cap * 3872)); CH(dalloc(&h->y3, h->rows_cap * 256));
+    CH(dalloc(&h->list_a, M)); CH(dalloc(&h->list_b, M)); CH(dalloc(&h->count_dev, 1));
+    if (cfg->record_bc) {
+        h->bc_bytes = cfg->policy_kind == DNE_KIND_ES ? M * (size_t)std::max(cfg->bc_max_steps, 1) * 128 : M * 128;
+        CH(dalloc(&h->bc, h->bc_bytes));
+    }
+    h->scratch_cap = std::max<size_t>(4 * M + 64, 65536);
+    CH(dalloc(&h->scratch_f, h->scratch_cap)); CH(dalloc(&h->scratch_i, h->scratch_cap));
+    CH(hipEventCreate(&h->ev_a)); CH(hipEventCreate(&h->ev_b));
+    CH(hipDeviceSynchronize());
+#undef CH
+#undef CCHECK
+    *out = h;
+    return 0;
+}
+
+extern "C" void dne_destroy(dne_handle *h) {
+    if (!h) return;
+    hipSetDevice(h->cfg.device_id);
+    hipDeviceSynchronize();
+    void *ptrs[] = {h->noise, h->bases, h->opt_m, h->opt_v, h->g, h->partial, h->ref, h->m_slot, h->m_off, h->m_scale,
+                    h->bn, h->ram_prev, h->ram_cur, h->stacks, h->tables, h->ret, h->sign, h->step_reward, h->logits,
+                    h->len, h->done, h->action, h->seeds, h->y1, h->y2, h->y3, h->list_a, h->list_b, h->count_dev,
+                    h->bc, h->mat_out, h->scratch_f, h->scratch_i};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->ev_a) hipEventDestroy(h->ev_a);
+    if (h->ev_b) hipEventDestroy(h->ev_b);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int dne_get_profile(dne_handle *h, dne_profile *out) {
+    *out = h->prof;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- noise / theta
+extern "C" int dne_noise_upload(dne_handle *h, const float *host, size_t count) {
+    HCHECK(h, hipSetDevice(h->cfg.device_id));
+    if (h->noise) { HCHECK(h, hipFree(h->noise)); h->noise = nullptr; }
+    HCHECK(h, dalloc(&h->noise, count + 64));
+    HCHECK(h, hipMemcpy(h->noise, host, count * sizeof(float), hipMemcpyHostToDevice));
+    HCHECK(h, hipMemset(h->noise + count, 0, 64 * sizeof(float)));
+    h->noise_count = count;
+    return 0;
+}
+
+static int check_noise_range(dne_handle *h, int64_t idx, int64_t dim) {
+    if (!h->noise) return h->fail("noise table not uploaded (dne_noise_upload)");
+    if (idx < 0 || (uint64_t)(idx + dim) > h->noise_count) return h->fail("noise index %lld + %lld outside the table of %zu", (long long)idx, (long long)dim, h->noise_count);
+    return 0;
+}
+
+extern "C" int dne_noise_get(dne_handle *h, int64_t idx, int dim, float *out) {
+    if (check_noise_range(h, idx, dim)) return -1;
+    HCHECK(h, hipMemcpy(out, h->noise + idx, (size_t)dim * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int dne_set_theta(dne_handle *h, int slot, const float *theta, size_t n) {
+    if (n != (size_t)h->L.P) return h->fail("dne_set_theta: expected %d parameters, got %zu", h->L.P, n);
+    if (slot < 0) return h->fail("bad slot");
+    if (grow_bases(h, slot + 1)) return -1;
+    HCHECK(h, hipMemcpy(h->bases + (size_t)slot * h->base_stride, theta, n * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int dne_get_theta(dne_handle *h, int slot, float *out, size_t n) {
+    if (n != (size_t)h->L.P) return h->fail("dne_get_theta: expected %d parameters, got %zu", h->L.P, n);
+    if (slot < 0 || slot >= h->base_cap) return h->fail("bad slot");
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    HCHECK(h, hipMemcpy(out, h->bases + (size_t)slot * h->base_stride, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int dne_set_ref_batch(dne_handle *h, const uint8_t *ref, int count) {
+    if (h->L.kind != DNE_KIND_ES) return h->fail("reference batch is an ESAtariPolicy concept");
+    if (count != h->F) return h->fail("dne_set_ref_batch: engine was created for %d reference frames, got %d", h->F, count);
+    HCHECK(h, hipMemcpy(h->ref, ref, (size_t)count * OB_BYTES, hipMemcpyHostToDevice));
+    h->ref_set = true;
+    return 0;
+}
+
+extern "C" int dne_materialize(dne_handle *h, const int64_t *idx, int n, float sigma, float *out_host) {
+    for (int i = 0; i < n; i++)
+        if (check_noise_range(h, idx[i], h->L.P)) return -1;
+    const size_t need = (size_t)n * 2 * h->L.P;
+    if (need > h->mat_cap) {
+        if (h->mat_out) HCHECK(h, hipFree(h->mat_out));
+        HCHECK(h, dalloc(&h->mat_out, need));
+        h->mat_cap = need;
+    }
+    if ((size_t)n > h->scratch_cap) return h->fail("too many pairs");
+    HCHECK(h, hipMemcpyAsync(h->scratch_i, idx, n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipEventRecord(h->ev_a, h->stream));
+    hipLaunchKernelGGL(k_materialize, dim3((h->L.P + 255) / 256, n), dim3(256), 0, h->stream, h->bases, h->noise,
+                       h->scratch_i, h->L.P, sigma, h->mat_out);
+    HCHECK(h, hipEventRecord(h->ev_b, h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HCHECK(h, hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    h->prof.materialize_ms = ms;
+    if (out_host) HCHECK(h, hipMemcpy(out_host, h->mat_out, need * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- env ABI
+static int check_n(dne_handle *h, int n) {
+    if (n <= 0 || n > h->M) return h->fail("n = %d outside [1, max_members = %d]", n, h->M);
+    return 0;
+}
+
+extern "C" int dne_env_reset(dne_handle *h, int n, const uint32_t *seeds) {
+    if (check_n(h, n)) return -1;
+    HCHECK(h, hipMemcpyAsync(h->seeds, seeds, n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_env_reset, dim3(n), dim3(256), 0, h->stream, h->env(0), h->seeds, n);
+    HCHECK(h, hipGetLastError());
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int dne_env_step(dne_handle *h, int n, const int32_t *actions, float *reward, int32_t *done) {
+    if (check_n(h, n)) return -1;
+    for (int i = 0; i < n; i++)
+        if (actions[i] < 0 || actions[i] >= h->cfg.n_actions) return h->fail("action %d out of range", actions[i]);
+    HCHECK(h, hipMemcpyAsync(h->action, actions, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipMemsetAsync(h->step_reward, 0, n * sizeof(float), h->stream));
+    hipLaunchKernelGGL(k_env_step, dim3(n), dim3(256), 0, h->stream, h->env(0), (const int *)nullptr, 1, 0x7fffffff);
+    HCHECK(h, hipGetLastError());
+    if (reward) HCHECK(h, hipMemcpyAsync(reward, h->step_reward, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (done) HCHECK(h, hipMemcpyAsync(done, h->done, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int dne_env_observation(dne_handle *h, int n, uint8_t *out) {
+    if (check_n(h, n)) return -1;
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    HCHECK(h, hipMemcpy(out, h->stacks, (size_t)n * OB_BYTES, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int dne_env_ram(dne_handle *h, int n, uint8_t *out) {
+    if (check_n(h, n)) return -1;
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    HCHECK(h, hipMemcpy(out, h->ram_cur, (size_t)n * 128, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int dne_env_set_observation(dne_handle *h, int n, const uint8_t *obs) {
+    if (check_n(h, n)) return -1;
+    HCHECK(h, hipMemcpy(h->stacks, obs, (size_t)n * OB_BYTES, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- forward
+extern "C" int dne_set_members(dne_handle *h, int n, const int32_t *slot, const int64_t *off, const float *scale) {
+    if (check_n(h, n)) return -1;
+    for (int i = 0; i < n; i++) {
+        if (slot[i] < 0 || slot[i] >= h->base_cap) return h->fail("member %d: base slot %d not allocated", i, slot[i]);
+        if (check_noise_range(h, off[i], h->L.P)) return -1;
+    }
+    HCHECK(h, hipMemcpyAsync(h->m_slot, slot, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipMemcpyAsync(h->m_off, off, n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipMemcpyAsync(h->m_scale, scale, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// policies.py:399: the reference batch through every member's perturbed network -> per-member BN scale/shift
+static int ref_pass(dne_handle *h, int n) {
+    if (h->L.kind != DNE_KIND_ES) return 0;
+    if (!h->ref_set) return h->fail("reference batch not set (dne_set_ref_batch)");
+    const int F = h->F;
+    const FwdArgs A = h->fwd(false);
+    for (int m0 = 0; m0 < n; m0 += h->ref_chunk) {
+        const int nc = std::min(h->ref_chunk, n - m0);
+        hipLaunchKernelGGL(k_conv1, dim3(nc * F), dim3(256), 0, h->stream, A, (const int *)nullptr, 1, F, m0,
+                           (const uint8_t *)h->stacks, (const uint8_t *)h->ref, h->y1);
+        hipLaunchKernelGGL((k_bn_stats<16, 441>), dim3(nc), dim3(256), F * 16 * sizeof(float), h->stream, A, m0, F,
+                           (const float *)h->y1, 0, h->L.bn1b, h->L.bn1g);
+        hipLaunchKernelGGL((k_conv2<true>), dim3(nc * F), dim3(128), 0, h->stream, A, (const int *)nullptr, 1, F, m0,
+                           (const float *)h->y1, h->y2);
+        hipLaunchKernelGGL((k_bn_stats<32, 121>), dim3(nc), dim3(256), F * 32 * sizeof(float), h->stream, A, m0, F,
+                           (const float *)h->y2, 32, h->L.bn2b, h->L.bn2g);
+        const int nfg = F / 8;
+        hipLaunchKernelGGL((k_fc<8, true, true>), dim3((nc + 7) / 8 * 8 * nfg), dim3(256), 0, h->stream, A,
+                           (const int *)nullptr, nc, F, m0, (const float *)h->y2, h->y3, (int32_t *)nullptr,
+                           (float *)nullptr);
+        hipLaunchKernelGGL((k_bn_stats<256, 1>), dim3(nc), dim3(256), 0, h->stream, A, m0, F, (const float *)h->y3,
+                           96, h->L.bn3b, h->L.bn3g);
+    }
+    HCHECK(h, hipGetLastError());
+    return 0;
+}
+
+extern "C" int dne_ref_pass(dne_handle *h, int n) {
+    if (check_n(h, n)) return -1;
+    if (h->L.kind != DNE_KIND_ES) return h->fail("dne_ref_pass: GAAtariPolicy has no reference batch");
+    if (ref_pass(h, n)) return -1;
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int dne_get_bn(dne_handle *h, int n, float *out) {
+    if (check_n(h, n)) return -1;
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    HCHECK(h, hipMemcpy(out, h->bn, (size_t)n * 608 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// one policy decision for the groups in `list` (count groups of gsize members)
+static void launch_forward(dne_handle *h, const int *list, int count, int gsize, bool use_done, float *logits) {
+    const FwdArgs A = h->fwd(use_done);
+    const bool es = h->L.kind == DNE_KIND_ES;
+    hipLaunchKernelGGL(k_conv1, dim3(count * gsize), dim3(256), 0, h->stream, A, list, gsize, 1, 0,
+                       (const uint8_t *)h->stacks, (const uint8_t *)nullptr, h->y1);
+    if (es) hipLaunchKernelGGL((k_conv2<true>), dim3(count * gsize), dim3(128), 0, h->stream, A, list, gsize, 1, 0, (const float *)h->y1, h->y2);
+    else hipLaunchKernelGGL((k_conv2<false>), dim3(count * gsize), dim3(128), 0, h->stream, A, list, gsize, 1, 0, (const float *)h->y1, h->y2);
+}
+
+static void launch_fc(dne_handle *h, const int *list, int count, int gsize, float *logits) {
+    const FwdArgs A = h->fwd(false);
+    const bool es = h->L.kind == DNE_KIND_ES;
+#define FC(NV, BN) hipLaunchKernelGGL((k_fc<NV, false, BN>), dim3(count), dim3(256), 0, h->stream, A, list, count, 1, 0, (const float *)h->y2, h->y3, h->action, logits)
+    if (gsize == 2) { if (es) FC(2, true); else FC(2, false); }
+    else { if (es) FC(1, true); else FC(1, false); }
+#undef FC
+}
+
+extern "C" int dne_act(dne_handle *h, int n, int32_t *actions, float *logits) {
+    if (check_n(h, n)) return -1;
+    launch_forward(h, nullptr, n, 1, false, nullptr);
+    launch_fc(h, nullptr, n, 1, h->logits);
+    HCHECK(h, hipGetLastError());
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    if (actions) HCHECK(h, hipMemcpy(actions, h->action, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (logits) HCHECK(h, hipMemcpy(logits, h->logits, (size_t)n * h->cfg.n_actions * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int dne_debug_activations(dne_handle *h, int member, float *y1, float *y2, float *y3) {
+    if (member < 0 || member >= h->M) return h->fail("bad member");
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    if (y1) HCHECK(h, hipMemcpy(y1, h->y1 + (size_t)member * 7056, 7056 * sizeof(float), hipMemcpyDeviceToHost));
+    if (y2) HCHECK(h, hipMemcpy(y2, h->y2 + (size_t)member * 3872, 3872 * sizeof(float), hipMemcpyDeviceToHost));
+    if (y3) HCHECK(h, hipMemcpy(y3, h->y3 + (size_t)member * 256, 256 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- batch evaluation
+// policies.py:378-429 / 473-513 for n members at once: reset, (ES) reference pass, then lock-step
+// act -> env.step over the shrinking list of active groups until every episode is done.
+static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_t *env_seed, float *returns,
+                     float *signreturns, int32_t *lengths, uint8_t *bc_out) {
+    if (n % gsize) return h->fail("member count %d not a multiple of the group size %d", n, gsize);
+    if (tslimit <= 0) return h->fail("timestep limit must be positive");
+    if (bc_out && !h->bc) return h->fail("behaviour characterisations requested but the engine was created with record_bc = 0");
+    const bool prof = h->cfg.profile_events != 0;
+    const int bc_mode = bc_out ? (h->L.kind == DNE_KIND_ES ? 1 : 2) : 0;
+    if (bc_mode == 1) HCHECK(h, hipMemsetAsync(h->bc, 0, (size_t)n * h->cfg.bc_max_steps * 128, h->stream));
+    HCHECK(h, hipEventRecord(h->ev_a, h->stream));
+    HCHECK(h, hipMemcpyAsync(h->seeds, env_seed, n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_env_reset, dim3(n), dim3(256), 0, h->stream, h->env(0), h->seeds, n);
+    size_t ne = 0;
+    if (prof) HCHECK(h, hipEventRecord(h->event(ne++), h->stream));
+    if (ref_pass(h, n)) return -1;
+    if (prof) HCHECK(h, hipEventRecord(h->event(ne++), h->stream));
+    int count = n / gsize;
+    hipLaunchKernelGGL(k_iota, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->list_a, count);
+    int *cur = h->list_a, *nxt = h->list_b;
+    const EnvArgs E = h->env(bc_mode);
+    int t = 0;
+    std::vector<int> step_counts;
+    long long group_steps = 0;
+    while (count > 0 && t < tslimit) {
+        const int burst = std::min(16, tslimit - t);
+        for (int s = 0; s < burst; s++) {
+            launch_forward(h, cur, count, gsize, true, nullptr);
+            if (prof) HCHECK(h, hipEventRecord(h->event(ne++), h->stream));
+            launch_fc(h, cur, count, gsize, nullptr);
+            if (prof) HCHECK(h, hipEventRecord(h->event(ne++), h->stream));
+            hipLaunchKernelGGL(k_env_step, dim3(count * gsize), dim3(256), 0, h->stream, E, (const int *)cur, gsize, tslimit);
+            if (prof) HCHECK(h, hipEventRecord(h->event(ne++), h->stream));
+            step_counts.push_back(count);
+            group_steps += count;
+        }
+        t += burst;
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, (const int32_t *)h->done, gsize, (const int *)cur,
+                           count, nxt, h->count_dev);
+        HCHECK(h, hipMemcpyAsync(&count, h->count_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HCHECK(h, hipStreamSynchronize(h->stream));
+        std::swap(cur, nxt);
+    }
+    HCHECK(h, hipGetLastError());
+    HCHECK(h, hipEventRecord(h->ev_b, h->stream));
+    HCHECK(h, hipMemcpyAsync(returns, h->ret, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (signreturns) HCHECK(h, hipMemcpyAsync(signreturns, h->sign, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipMemcpyAsync(lengths, h->len, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    if (bc_out) HCHECK(h, hipMemcpy(bc_out, h->bc, bc_mode == 1 ? (size_t)n * h->cfg.bc_max_steps * 128 : (size_t)n * 128, hipMemcpyDeviceToHost));
+    float ms = 0;
+    HCHECK(h, hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    dne_profile &P = h->prof;
+    P.eval_ms = ms;
+    P.fc_ms = P.conv_ms = P.env_ms = P.ref_ms = 0;
+    P.fc_launches = (int64_t)step_counts.size();
+    P.fc_group_steps = group_steps;
+    P.env_steps = 0;
+    for (int i = 0; i < n; i++) P.env_steps += lengths[i];
+    if (prof) {
+        HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[0], h->ev_pool[1]));
+        P.ref_ms = ms;
+        for (size_t s = 0; s < step_counts.size(); s++) {
+            const size_t e = 2 + 3 * s;
+            hipEvent_t before = e == 2 ? h->ev_pool[1] : h->ev_pool[e - 1];
+            HCHECK(h, hipEventElapsedTime(&ms, before, h->ev_pool[e])); P.conv_ms += ms;
+            HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e], h->ev_pool[e + 1])); P.fc_ms += ms;
+            HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e + 1], h->ev_pool[e + 2])); P.env_ms += ms;
+        }
+    }
+    return 0;
+}
+
+extern "C" int dne_es_eval(dne_handle *h, const int64_t *idx, int n, float sigma, int tslimit, const uint32_t *env_seed,
+                           float *returns_n2, float *signreturns_n2, int32_t *lengths_n2, uint8_t *bc) {
+    if (h->L.kind != DNE_KIND_ES) return h->fail("dne_es_eval needs an ESAtariPolicy engine");
+    if (n <= 0 || 2 * n > h->M) return h->fail("%d pairs exceed max_members = %d", n, h->M);
+    std::vector<int32_t> slot(2 * n, 0);
+    std::vector<int64_t> off(2 * n);
+    std::vector<float> sc(2 * n);
+    for (int i = 0; i < n; i++) {
+        off[2 * i] = off[2 * i + 1] = idx[i];
+        sc[2 * i] = sigma;        // es.py:415 params + v
+        sc[2 * i + 1] = -sigma;   // es.py:419 params - v
+    }
+    if (dne_set_members(h, 2 * n, slot.data(), off.data(), sc.data())) return -1;
+    return eval_core(h, 2 * n, 2, tslimit, env_seed, returns_n2, signreturns_n2, lengths_n2, bc);
+}
+
+extern "C" int dne_eval_members(dne_handle *h, int n, int tslimit, const uint32_t *env_seed, float *returns,
+                                float *signreturns, int32_t *lengths, uint8_t *bc) {
+    if (check_n(h, n)) return -1;
+    return eval_core(h, n, 1, tslimit, env_seed, returns, signreturns, lengths, bc);
+}
+
+// ------------------------------------------------------------------------------- GA genomes
+static void launch_normc(dne_handle *h, float *th) {
+    const Layout &L = h->L;
+    auto nc = [&](int off, int K, int C, float std) { hipLaunchKernelGGL(k_normc, dim3((C + 63) / 64), dim3(64), 0, h->stream, th + off, K, C, std); };
+    auto z = [&](int off, int n) { hipLaunchKernelGGL(k_zero, dim3((n + 63) / 64), dim3(64), 0, h->stream, th + off, n); };
+    nc(L.c1w, 256, 16, 1.0f); z(L.c1b, 16);
+    nc(L.c2w, 256, 32, 1.0f); z(L.c2b, 32);
+    nc(L.fcw, 3872, 256, 1.0f); z(L.fcb, 256);
+    nc(L.ow, 256, L.nact, 0.1f); z(L.ob, L.nact);   // ac_init_std = 0.1, policies.py:434
+}
+
+// build theta(chain) into `slot`; `src_slot` >= 0 means chain[:src_len] is already materialised there
+static int build_chain(dne_handle *h, int slot, const int64_t *seeds, int nseeds, float sigma, int src_slot, int src_len) {
+    const int P = h->L.P, nb = (P + 255) / 256;
+    float *dst = h->bases + (size_t)slot * h->base_stride;
+    for (int s = 0; s < nseeds; s++)
+        if (check_noise_range(h, seeds[s], P)) return -1;
+    int start = 1;
+    const float *src = dst;
+    if (src_slot >= 0) {
+        src = h->bases + (size_t)src_slot * h->base_stride;
+        start = src_len;
+        if (start == nseeds) {
+            HCHECK(h, hipMemcpyAsync(dst, src, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+            return 0;
+        }
+    } else {
+        hipLaunchKernelGGL(k_copy_noise, dim3(nb), dim3(256), 0, h->stream, (const float *)h->noise, seeds[0], P, dst);   // ga.py:256
+        launch_normc(h, dst);                                                                                                // ga.py:258-260
+    }
+    for (int s = start; s < nseeds; s++) {   // ga.py:262-263
+        hipLaunchKernelGGL(k_axpy_noise, dim3(nb), dim3(256), 0, h->stream, (const float *)h->noise, seeds[s], P, sigma, src, dst);
+        src = dst;
+    }
+    return 0;
+}
+
+extern "C" int dne_ga_rebuild(dne_handle *h, int slot, const int64_t *seeds, int nseeds, float sigma, float *out_host) {
+    if (h->L.kind != DNE_KIND_GA) return h->fail("dne_ga_rebuild needs a GAAtariPolicy engine");
+    if (slot < 0 || nseeds < 1) return h->fail("bad arguments");
+    if (grow_bases(h, slot + 1)) return -1;
+    h->free_slots.erase(std::remove(h->free_slots.begin(), h->free_slots.end(), slot), h->free_slots.end());
+    if (build_chain(h, slot, seeds, nseeds, sigma, -1, 0)) return -1;
+    HCHECK(h, hipGetLastError());
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    if (out_host) HCHECK(h, hipMemcpy(out_host, h->bases + (size_t)slot * h->base_stride, (size_t)h->L.P * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int dne_ga_eval(dne_handle *h, const int32_t *co, const int64_t *seeds, int n, float sigma, int tslimit,
+                           const uint32_t *env_seed, float *returns, float *signreturns, int32_t *lengths, uint8_t *bc) {
+    if (h->L.kind != DNE_KIND_GA) return h->fail("dne_ga_eval needs a GAAtariPolicy engine");
+    if (check_n(h, n)) return -1;
+    // Every child = parent chain + one fresh seed (ga.py:251-254).  Parents are materialised once into
+    // base slots (cached across generations by chain) and the child's last mutation is applied on the fly
+    // by the forward kernels, exactly like an ES perturbation with scale +sigma.
+    std::vector<std::vector<int64_t>> prefix(n);
+    std::vector<int64_t> off(n);
+    std::vector<float> sc(n);
+    std::map<std::vector<int64_t>, int> needed;
+    for (int i = 0; i < n; i++) {
+        const int len = co[i + 1] - co[i];
+        if (len < 1) return h->fail("member %d has an empty seed chain", i);
+        const int64_t *c = seeds + co[i];
+        if (len == 1) { prefix[i].assign(c, c + 1); off[i] = c[0]; sc[i] = 0.0f; }
+        else { prefix[i].assign(c, c + len - 1); off[i] = c[len - 1]; sc[i] = sigma; }
+        needed[prefix[i]] = -1;
+    }
+    size_t fresh = 0;
+    for (auto &kv : needed) fresh += h->ga_cache.count(kv.first) ? 0 : 1;
+    if (fresh > h->free_slots.size()) {
+        if (grow_bases(h, h->base_cap + (int)(fresh - h->free_slots.size()))) return -1;
+    }
+    for (auto &kv : needed) {
+        auto it = h->ga_cache.find(kv.first);
+        if (it != h->ga_cache.end()) { kv.second = it->second; continue; }
+        const int slot = h->free_slots.back();
+        h->free_slots.pop_back();
+        // longest cached proper prefix as the starting point
+        int src_slot = -1, src_len = 0;
+        std::vector<int64_t> p(kv.first);
+        while (p.size() > 1) {
+            p.pop_back();
+            auto jt = h->ga_cache.find(p);
+            if (jt != h->ga_cache.end()) { src_slot = jt->second; src_len = (int)p.size(); break; }
+        }
+        if (build_chain(h, slot, kv.first.data(), (int)kv.first.size(), sigma, src_slot, src_len)) return -1;
+        kv.second = slot;
+    }
+    HCHECK(h, hipGetLastError());
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    // keep only this generation's parents cached
+    for (auto it = h->ga_cache.begin(); it != h->ga_cache.end();) {
+        if (!needed.count(it->first)) { h->free_slots.push_back(it->second); it = h->ga_cache.erase(it); }
+        else ++it;
+    }
+    for (auto &kv : needed) h->ga_cache[kv.first] = kv.second;
+    std::vector<int32_t> slot(n);
+    for (int i = 0; i < n; i++) slot[i] = needed[prefix[i]];
+    if (dne_set_members(h, n, slot.data(), off.data(), sc.data())) return -1;
+    return eval_core(h, n, 1, tslimit, env_seed, returns, signreturns, lengths, bc);
+}
+
+// ------------------------------------------------------------------------------- reduce
+extern "C" int dne_centered_ranks(dne_handle *h, const float *x, int n, float *out) {
+    if (n < 2 || (size_t)2 * n > h->scratch_cap) return h->fail("dne_centered_ranks: n = %d unsupported", n);
+    HCHECK(h, hipMemcpyAsync(h->scratch_f, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_centered_ranks, dim3((n + 255) / 256), dim3(256), 0, h->stream, (const float *)h->scratch_f, n, h->scratch_f + n);
+    HCHECK(h, hipMemcpyAsync(out, h->scratch_f + n, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int weighted_sum_dev(dne_handle *h, const int64_t *idx_host, const float *w_dev, int n, float denom) {
+    for (int i = 0; i < n; i++)
+        if (check_noise_range(h, idx_host[i], h->L.P)) return -1;
+    HCHECK(h, hipMemcpyAsync(h->scratch_i, idx_host, n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipEventRecord(h->ev_a, h->stream));
+    hipLaunchKernelGGL(k_weighted_sum, dim3((h->L.P + 255) / 256), dim3(256), 0, h->stream, (const float *)h->noise,
+                       (const int64_t *)h->scratch_i, w_dev, n, h->L.P, denom, h->g);
+    HCHECK(h, hipEventRecord(h->ev_b, h->stream));
+    HCHECK(h, hipGetLastError());
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HCHECK(h, hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    h->prof.reduce_ms = ms;
+    return 0;
+}
+
+extern "C" int dne_weighted_sum(dne_handle *h, const int64_t *idx, const float *w, int n, float denom, float *g_host) {
+    if (n < 1 || (size_t)n > h->scratch_cap) return h->fail("dne_weighted_sum: n = %d unsupported", n);
+    HCHECK(h, hipMemcpyAsync(h->scratch_f, w, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (weighted_sum_dev(h, idx, h->scratch_f, n, denom)) return -1;
+    if (g_host) HCHECK(h, hipMemcpy(g_host, h->g, (size_t)h->L.P * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int dne_optimizer_reset(dne_handle *h) {
+    HCHECK(h, hipMemsetAsync(h->opt_m, 0, h->L.P * sizeof(float), h->stream));
+    HCHECK(h, hipMemsetAsync(h->opt_v, 0, h->L.P * sizeof(float), h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    h->opt_t = 0;
+    return 0;
+}
+
+extern "C" int dne_optimizer_step(dne_handle *h, int kind, float l2, double stepsize, double b1m, double b2, double eps,
+                                  double *ratio) {
+    const int P = h->L.P, nb = (P + 255) / 256;
+    h->opt_t += 1;   // optimizers.py:11
+    if (kind == DNE_OPT_ADAM) {
+        const double a = stepsize * std::sqrt(1.0 - std::pow(b2, (double)h->opt_t)) / (1.0 - std::pow(b1m, (double)h->opt_t));
+        hipLaunchKernelGGL(k_adam, dim3(nb), dim3(256), 0, h->stream, h->bases, h->opt_m, h->opt_v, (const float *)h->g, P, l2,
+                           (float)(-a), (float)b1m, (float)(1.0 - b1m), (float)b2, (float)(1.0 - b2), (float)eps, h->partial);
+    } else if (kind == DNE_OPT_SGD) {
+        hipLaunchKernelGGL(k_sgd, dim3(nb), dim3(256), 0, h->stream, h->bases, h->opt_v, (const float *)h->g, P, l2, (float)b1m,
+                           (float)(1.0 - b1m), (float)(-stepsize), h->partial);
+    } else {
+        return h->fail("unknown optimizer kind %d", kind);
+    }
+    HCHECK(h, hipGetLastError());
+    std::vector<double> part(2 * (size_t)nb);
+    HCHECK(h, hipMemcpyAsync(part.data(), h->partial, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    double ss = 0, tt = 0;
+    for (int b = 0; b < nb; b++) { ss += part[2 * b]; tt += part[2 * b + 1]; }
+    if (ratio) *ratio = std::sqrt(ss) / std::sqrt(tt);
+    return 0;
+}
+
+extern "C" int dne_es_update(dne_handle *h, const int64_t *idx, const float *returns_n2, const float *signreturns_n2, int n,
+                             int proc_mode, int opt_kind, float l2, double stepsize, double b1m, double b2, double eps,
+                             double *ratio) {
+    if (n < 1 || (size_t)5 * n > h->scratch_cap) return h->fail("dne_es_update: n = %d unsupported", n);
+    const int n2 = 2 * n;
+    float *x = h->scratch_f, *proc = h->scratch_f + n2, *w = h->scratch_f + 2 * n2;
+    if (proc_mode == DNE_PROC_CENTERED_RANK) {          // es.py:281-282
+        HCHECK(h, hipMemcpyAsync(x, returns_n2, n2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_centered_ranks, dim3((n2 + 255) / 256), dim3(256), 0, h->stream, (const float *)x, n2, proc);
+    } else if (proc_mode == DNE_PROC_SIGN) {            // es.py:283-284
+        if (!signreturns_n2) return h->fail("sign mode needs signreturns_n2");
+        HCHECK(h, hipMemcpyAsync(proc, signreturns_n2, n2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    } else if (proc_mode == DNE_PROC_CENTERED_SIGN_RANK) {   // es.py:285-286
+        if (!signreturns_n2) return h->fail("centered_sign_rank mode needs signreturns_n2");
+        HCHECK(h, hipMemcpyAsync(x, signreturns_n2, n2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_centered_ranks, dim3((n2 + 255) / 256), dim3(256), 0, h->stream, (const float *)x, n2, proc);
+    } else {
+        return h->fail("unknown return_proc_mode %d", proc_mode);
+    }
+    hipLaunchKernelGGL(k_pair_weights, dim3((n + 255) / 256), dim3(256), 0, h->stream, (const float *)proc, n, w);
+    if (weighted_sum_dev(h, idx, w, n, (float)n2)) return -1;   // es.py:296 g /= returns_n2.size
+    return dne_optimizer_step(h, opt_kind, l2, stepsize, b1m, b2, eps, ratio);
+}
+
+extern "C" int dne_ga_select(dne_handle *h, const float *returns, int m, int t, int32_t *out_idx) {
+    if (m < 1 || t < 1 || t > m || (size_t)2 * m > h->scratch_cap) return h->fail("dne_ga_select: bad sizes m = %d t = %d", m, t);
+    HCHECK(h, hipMemcpyAsync(h->scratch_f, returns, m * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    int32_t *out = (int32_t *)(h->scratch_f + m);
+    hipLaunchKernelGGL(k_ga_select, dim3((m + 255) / 256), dim3(256), 0, h->stream, (const float *)h->scratch_f, m, t, out);
+    HCHECK(h, hipMemcpyAsync(out_idx, out, t * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int dne_novelty(dne_handle *h, const uint8_t *archive, const int32_t *alen, int narch, const uint8_t *bc,
+                           int bc_len, int dim, int k, double *out) {
+    if (narch < 1 || bc_len < 1 || dim < 1 || k < 1) return h->fail("dne_novelty: bad sizes");
+    std::vector<int64_t> row0(narch);
+    int64_t rows = 0;
+    for (int a = 0; a < narch; a++) { if (alen[a] < 1) return h->fail("empty archive entry"); row0[a] = rows; rows += alen[a]; }
+    uint8_t *d_arch = nullptr, *d_bc = nullptr; int64_t *d_row0 = nullptr; int32_t *d_len = nullptr; long long *d_out = nullptr;
+    HCHECK(h, dalloc(&d_arch, (size_t)rows * dim)); HCHECK(h, dalloc(&d_bc, (size_t)bc_len * dim));
+    HCHECK(h, dalloc(&d_row0, narch)); HCHECK(h, dalloc(&d_len, narch)); HCHECK(h, dalloc(&d_out, 2 * (size_t)narch));
+    HCHECK(h, hipMemcpyAsync(d_arch, archive, (size_t)rows * dim, hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipMemcpyAsync(d_bc, bc, (size_t)bc_len * dim, hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipMemcpyAsync(d_row0, row0.data(), narch * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipMemcpyAsync(d_len, alen, narch * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_bc_sqdist, dim3(narch), dim3(256), 0, h->stream, (const uint8_t *)d_arch, (const int64_t *)d_row0,
+                       (const int32_t *)d_len, (const uint8_t *)d_bc, bc_len, dim, d_out);
+    std::vector<long long> ab(2 * (size_t)narch);
+    HCHECK(h, hipMemcpyAsync(ab.data(), d_out, ab.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    hipFree(d_arch); hipFree(d_bc); hipFree(d_row0); hipFree(d_len); hipFree(d_out);
+    std::vector<double> d(narch);
+    for (int a = 0; a < narch; a++) {   // nses.py:20 sqrt(a**2 + b**2) with a, b = the two Frobenius norms
+        const double na = std::sqrt((double)ab[2 * a]), nb = std::sqrt((double)ab[2 * a + 1]);
+        d[a] = std::sqrt(na * na + nb * nb);
+    }
+    std::sort(d.begin(), d.end());        // nses.py:29-31 k nearest, mean
+    const int kk = std::min(k, narch);
+    double s = 0;
+    for (int i = 0; i < kk; i++) s += d[i];
+    *out = s / kk;
+    return 0;
+}

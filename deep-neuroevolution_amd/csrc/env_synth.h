@@ -1,0 +1,243 @@
+// env_synth.h -- device-resident batched SynthAtari stepper + fused DeepMind preprocessing.
+//
+// Replaces, for the hot path, gym/ALE + es_distributed/atari_wrappers.py:204-222 (wrap_deepmind):
+//   NoopResetEnv :18-31, MaxAndSkipEnv :95-107 (4 raw frames, reward sum, max over the last 2 frames),
+//   FireResetEnv :40-48, WarpFrame :138-142 (gray -> PIL antialiased bilinear 84x84 -> u8 truncation),
+//   FrameStack :167-180 (4 frames on the channel axis), ScaledFloatFrame :183-186 (/255, fused into conv1).
+// The emulator itself is the SynthAtari fixture specified in DESIGN.md (ALE and ROMs are not available);
+// this file is an independent implementation of that written spec (the CPU oracle is another one).
+//
+// One workgroup (256 threads) per member.  Lane 0 advances the 128-byte RAM; the whole group then renders
+// max(frame_prev, frame_cur) as a byte image of colour pairs in LDS, runs PIL's two separable passes
+// (double accumulation, float32 intermediate, horizontal first) band by band, and shifts the new u8
+// frame into the member's [84][84][4] stack with one dword read-modify-write per pixel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dne {
+
+// RAM map (DESIGN.md "SynthAtari")
+enum : int {
+    RM_FC = 0, RM_RNG = 2, RM_PX = 6, RM_PROW = 7, RM_LIVES = 8, RM_OVER = 9, RM_TEMP = 10, RM_COOL = 11,
+    RM_OFF = 12, RM_VIS = 16, RM_IGLOO = 20, RM_LEVEL = 21, RM_SCORE = 22, RM_FREEZE = 25, RM_HZX = 26,
+    RM_HZA = 30, RM_DIR = 34, RM_LASTA = 38, RM_TICK = 39
+};
+
+struct ResizeTables {   // Pillow precompute_coeffs output for 160->84 (h) and 210->84 (v)
+    double kh[84 * 5];
+    double kv[84 * 7];
+    int bh[84 * 2];
+    int bv[84 * 2];
+    float gray2[256];   // gray(max(rgb[a], rgb[b])) for colour pair (a<<4)|b
+};
+
+__device__ __forceinline__ uint32_t ram_rand(uint8_t *ram) {
+    uint32_t s = ram[RM_RNG] | (ram[RM_RNG + 1] << 8) | (ram[RM_RNG + 2] << 16) | ((uint32_t)ram[RM_RNG + 3] << 24);
+    s = s * 1664525u + 1013904223u;
+    ram[RM_RNG] = s & 255; ram[RM_RNG + 1] = (s >> 8) & 255; ram[RM_RNG + 2] = (s >> 16) & 255; ram[RM_RNG + 3] = s >> 24;
+    return s >> 16;
+}
+
+__device__ inline void synth_reset(uint8_t *ram, uint32_t seed) {
+    for (int i = 0; i < 128; i++) ram[i] = 0;
+    uint32_t s = seed ^ 0x9E3779B9u;
+    ram[RM_RNG] = s & 255; ram[RM_RNG + 1] = (s >> 8) & 255; ram[RM_RNG + 2] = (s >> 16) & 255; ram[RM_RNG + 3] = s >> 24;
+    ram[RM_PX] = 76; ram[RM_LIVES] = 3; ram[RM_TEMP] = 45;
+    for (int r = 0; r < 4; r++) { ram[RM_OFF + r] = ram_rand(ram) % 160u; ram[RM_DIR + r] = r & 1; }
+    for (int r = 0; r < 4; r++) ram[RM_HZX + r] = ram_rand(ram) % 160u;
+}
+
+__device__ __forceinline__ bool synth_on_floe(const uint8_t *ram, int px, int r) {
+    int rel = (px + 164 - ram[RM_OFF + r]) % 160;
+    return (rel % 40) < 24;
+}
+
+// one raw emulator frame; returns the integer reward
+__device__ inline int synth_frame(uint8_t *ram, int a) {
+    if (ram[RM_OVER]) return 0;
+    int fc = ((ram[RM_FC] | (ram[RM_FC + 1] << 8)) + 1) & 0xffff;
+    ram[RM_FC] = fc & 255; ram[RM_FC + 1] = fc >> 8;
+    ram[RM_LASTA] = a;
+    int level = ram[RM_LEVEL];
+    const int speed = level >= 3 ? 2 : 1;
+    int reward = 0;
+    for (int r = 0; r < 4; r++) {
+        int o = ram[RM_OFF + r];
+        ram[RM_OFF + r] = ram[RM_DIR + r] ? (o + 160 - speed) % 160 : (o + speed) % 160;
+    }
+    for (int r = 0; r < 4; r++) {
+        if (ram[RM_HZA + r]) {
+            int x = ram[RM_HZX + r];
+            ram[RM_HZX + r] = ram[RM_DIR + r] ? (x + 1) % 160 : (x + 159) % 160;
+        } else if ((fc & 63) == 16 * r) {
+            if ((ram_rand(ram) & 3u) == 0u) { ram[RM_HZA + r] = 1; ram[RM_HZX + r] = ram[RM_DIR + r] ? 0 : 159; }
+        }
+    }
+    // ALE action set: NOOP FIRE UP RIGHT LEFT DOWN UR UL DR DL UF RF LF DF URF ULF DRF DLF
+    const int dx = (0x14948 >> a) & 1 ? 1 : ((0x29290 >> a) & 1 ? -1 : 0);   // RIGHT-ish bits / LEFT-ish bits
+    const int dy = (0x0C4C4 >> a) & 1 ? -1 : ((0x32320 >> a) & 1 ? 1 : 0);   // UP-ish / DOWN-ish
+    const bool fire = a == 1 || a >= 10;
+    bool died = false;
+    if (ram[RM_FREEZE] > 0) {
+        ram[RM_FREEZE]--;
+    } else {
+        int px = ram[RM_PX], prow = ram[RM_PROW];
+        if (prow > 0) px += ram[RM_DIR + prow - 1] ? -speed : speed;
+        px += 2 * dx;
+        px = px < 8 ? 8 : (px > 144 ? 144 : px);
+        if (ram[RM_COOL] > 0) {
+            ram[RM_COOL]--;
+        } else if (dy != 0) {
+            int tgt = prow + dy;
+            if (tgt < 0) {
+                if (ram[RM_IGLOO] >= 16 && px >= 104) {   // enter the finished igloo: level complete
+                    reward += 10 * ram[RM_TEMP] + 100;
+                    if (level < 255) level++;
+                    ram[RM_LEVEL] = level; ram[RM_IGLOO] = 0; ram[RM_TEMP] = 45; ram[RM_TICK] = 0;
+                    for (int r = 0; r < 4; r++) { ram[RM_VIS + r] = 0; ram[RM_HZA + r] = 0; }
+                    prow = 0; px = 76; ram[RM_FREEZE] = 16;
+                }
+            } else if (tgt <= 4) {
+                prow = tgt;
+                ram[RM_COOL] = 12;
+                if (prow > 0) {
+                    int r = prow - 1;
+                    if (synth_on_floe(ram, px, r)) {
+                        if (!ram[RM_VIS + r]) {
+                            ram[RM_VIS + r] = 1;
+                            reward += 10;
+                            if (ram[RM_IGLOO] < 16) ram[RM_IGLOO]++;
+                            if (ram[RM_VIS] & ram[RM_VIS + 1] & ram[RM_VIS + 2] & ram[RM_VIS + 3])
+                                ram[RM_VIS] = ram[RM_VIS + 1] = ram[RM_VIS + 2] = ram[RM_VIS + 3] = 0;
+                        }
+                    } else {
+                        died = true;
+                    }
+                }
+            }
+        } else if (fire && prow > 0 && ram[RM_IGLOO] > 0) {
+            ram[RM_DIR + prow - 1] ^= 1; ram[RM_IGLOO]--; ram[RM_COOL] = 12;
+        }
+        if (!died && prow > 0) {
+            int r = prow - 1;
+            if (!synth_on_floe(ram, px, r)) died = true;
+            else if (ram[RM_HZA + r]) {
+                int d = px + 4 - (int)ram[RM_HZX + r];
+                if ((d < 0 ? -d : d) < 8) died = true;
+            }
+        }
+        ram[RM_PX] = px; ram[RM_PROW] = prow;
+    }
+    if (++ram[RM_TICK] >= 48) {
+        ram[RM_TICK] = 0;
+        if (ram[RM_TEMP] > 0) ram[RM_TEMP]--;
+        if (ram[RM_TEMP] == 0) died = true;
+    }
+    if (died) {
+        if (ram[RM_LIVES] == 0) ram[RM_OVER] = 1; else ram[RM_LIVES]--;
+        ram[RM_PROW] = 0; ram[RM_PX] = 76; ram[RM_FREEZE] = 32; ram[RM_COOL] = 0;
+        ram[RM_HZA] = ram[RM_HZA + 1] = ram[RM_HZA + 2] = ram[RM_HZA + 3] = 0;
+        if (ram[RM_TEMP] == 0) ram[RM_TEMP] = 45;
+    }
+    if (reward) {
+        uint32_t sc = ram[RM_SCORE] | (ram[RM_SCORE + 1] << 8) | (ram[RM_SCORE + 2] << 16);
+        sc = (sc + reward / 10) & 0xffffffu;
+        ram[RM_SCORE] = sc & 255; ram[RM_SCORE + 1] = (sc >> 8) & 255; ram[RM_SCORE + 2] = sc >> 16;
+    }
+    return reward;
+}
+
+// palette index of screen pixel (x, y) for a RAM snapshot
+__device__ __forceinline__ int synth_pixel(const uint8_t *ram, int x, int y) {
+    const int prow = ram[RM_PROW], px = ram[RM_PX];
+    const int py = prow == 0 ? 62 : 48 + 32 * prow;
+    const bool blink = ram[RM_FREEZE] > 0 && (ram[RM_FC] & 4);
+    if (!blink && (unsigned)(x - px) < 8u && (unsigned)(y - py) < 16u) return 8;
+    if (y < 8 || y >= 208) return 0;
+    if (y < 16) {
+        if (x >= 8 && x < 8 + 2 * ram[RM_TEMP]) return 11;
+        int q = x - 120;
+        if (q >= 0 && q < 10 * ram[RM_LIVES] && (q % 10) < 6) return 12;
+        return 1;
+    }
+    if (y < 20) {
+        if (x >= 8 && x < 136 && ((x - 8) & 7) < 6) {
+            int sc = ram[RM_SCORE] | (ram[RM_SCORE + 1] << 8);
+            if ((sc >> ((x - 8) >> 3)) & 1) return 14;
+        }
+        return 1;
+    }
+    if (y < 64) {
+        if (x >= 112 && x < 144 && y >= 40) {
+            int ig = ram[RM_IGLOO];
+            if (ig >= 16 && x >= 124 && x < 132 && y >= 52) return 13;
+            if (((63 - y) / 6) * 4 + ((x - 112) >> 3) < ig) return 10;
+        }
+        return (ram[RM_LEVEL] & 1) ? 3 : 2;
+    }
+    if (y < 80) return 4;
+    const int r = (y - 80) >> 5, yo = (y - 80) & 31;
+    if (yo >= 4 && yo < 12 && ram[RM_HZA + r]) {
+        int d = x - (int)ram[RM_HZX + r];
+        if ((d < 0 ? -d : d) < 6) return 9;
+    }
+    if (yo >= 16 && yo < 28) {
+        int rel = (x + 160 - ram[RM_OFF + r]) % 160;
+        if ((rel % 40) < 24) return ram[RM_VIS + r] ? 7 : 6;
+    }
+    return (yo & 8) ? 15 : 5;
+}
+
+constexpr int ENV_BANDS = 3;            // output rows are produced in 3 bands of 28
+constexpr int ENV_BAND_ROWS = 28;
+constexpr int ENV_BAND_IN_MAX = 80;     // input rows a band can touch (70 + taps)
+
+struct EnvLds {
+    uint8_t ram_prev[128];
+    uint8_t ram_cur[128];
+    uint8_t img[ENV_BAND_IN_MAX * 160];     // colour pair (prev<<4 | cur) per pixel of the band
+    float tmp[ENV_BAND_IN_MAX * 84];        // horizontally resized band (float32 like PIL's temp image)
+    float gray2[256];
+    int misc[4];
+};
+
+// Render + warp max(prev, cur) and either shift it into the stack (fill == false) or fill all four
+// channels with it (fill == true, FrameStack reset).  Called by the whole 256-thread group.
+__device__ inline void synth_observe(EnvLds &s, const ResizeTables *__restrict__ T, uint32_t *__restrict__ stack, bool fill) {
+    const int tid = threadIdx.x;
+    for (int band = 0; band < ENV_BANDS; band++) {
+        const int yy0 = band * ENV_BAND_ROWS;
+        const int y_lo = T->bv[yy0 * 2];
+        const int last = yy0 + ENV_BAND_ROWS - 1;
+        const int y_hi = T->bv[last * 2] + T->bv[last * 2 + 1];   // exclusive
+        const int rows = y_hi - y_lo;
+        __syncthreads();
+        for (int i = tid; i < rows * 160; i += 256) {
+            int y = y_lo + i / 160, x = i % 160;
+            s.img[i] = (uint8_t)((synth_pixel(s.ram_prev, x, y) << 4) | synth_pixel(s.ram_cur, x, y));
+        }
+        __syncthreads();
+        for (int i = tid; i < rows * 84; i += 256) {   // horizontal pass
+            int yl = i / 84, xx = i % 84;
+            int xmin = T->bh[xx * 2], n = T->bh[xx * 2 + 1];
+            const double *k = T->kh + xx * 5;
+            double acc = 0.0;
+            for (int t = 0; t < n; t++) acc = acc + (double)s.gray2[s.img[yl * 160 + xmin + t]] * k[t];
+            s.tmp[i] = (float)acc;
+        }
+        __syncthreads();
+        for (int i = tid; i < ENV_BAND_ROWS * 84; i += 256) {   // vertical pass + u8 truncation + stack shift
+            int yy = yy0 + i / 84, xx = i % 84;
+            int ymin = T->bv[yy * 2], n = T->bv[yy * 2 + 1];
+            const double *k = T->kv + yy * 7;
+            double acc = 0.0;
+            for (int t = 0; t < n; t++) acc = acc + (double)s.tmp[(ymin - y_lo + t) * 84 + xx] * k[t];
+            uint32_t pix = (uint32_t)(uint8_t)(float)acc;
+            uint32_t *p = stack + yy * 84 + xx;
+            *p = fill ? pix * 0x01010101u : ((*p >> 8) | (pix << 24));
+        }
+    }
+}
+
+}  // namespace dne

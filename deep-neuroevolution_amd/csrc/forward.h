@@ -1,0 +1,424 @@
+// forward.h -- batched Nature-CNN policy forward with member-unique, never-materialised weights.
+//
+// Replaces ESAtariPolicy._make_net / GAAtariPolicy._make_net + act (es_distributed/policies.py:319-330,
+// 374-375, 449-459, 469-470) and the per-pair perturbation + 4 MB feed of es.py:412-419 /
+// tf_util.py:224-240: every weight is formed in registers as  base[p] + scale * noise[off + p]
+// (two fp32 roundings, exactly params + noise_stdev*noise.get(...)) while it streams from the
+// SharedNoiseTable device buffer, so an antithetic pair reads its 4 MB noise slice ONCE per env-step.
+//
+// Numerics contract (identical to the CPU oracle): each dot product is an fp32 fmaf chain in
+// (kh, kw, ci) / k order starting at 0; fc = 4 k-slices of 968 rows combined ((s0+s1)+(s2+s3)) + bias;
+// batch-norm is x*scale + shift with two roundings.  Built with -ffp-contract=off.
+//
+// Work decode shared by all kernels: step mode (F == 1) walks a list of active groups (ES: antithetic
+// pairs, GA: single members) and reads each member's own frame stack; reference mode (F > 1) runs F
+// reference frames through every member of a chunk (virtual batch norm, policies.py:399).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dne {
+
+struct Layout {
+    int kind, nact, P;
+    int c1w, c1b, bn1b, bn1g, c2w, c2b, bn2b, bn2g, fcw, fcb, bn3b, bn3g, ow, ob;
+};
+
+struct FwdArgs {
+    const float *noise;
+    const float *bases;      // [slots][base_stride]
+    size_t base_stride;
+    const int32_t *m_slot;   // per member
+    const int64_t *m_off;
+    const float *m_scale;
+    float *bn;               // [members][608]: s1[16] h1[16] s2[32] h2[32] s3[256] h3[256]
+    const int32_t *done;     // per member, step mode only
+    Layout L;
+};
+
+constexpr int OB_BYTES = 84 * 84 * 4;
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment
+typedef float f4a __attribute__((ext_vector_type(4)));
+
+struct Item {
+    int member, row;
+    const uint8_t *ob;
+    bool skip;
+};
+
+__device__ __forceinline__ Item decode_item(int b, const int *__restrict__ list, int gsize, int F, int member0,
+                                            const uint8_t *__restrict__ stacks, const uint8_t *__restrict__ ref,
+                                            const int32_t *__restrict__ done) {
+    Item it;
+    if (F == 1) {
+        int g = list ? list[b / gsize] : b / gsize;
+        it.member = g * gsize + b % gsize;
+        it.row = it.member;
+        it.ob = stacks + (size_t)it.member * OB_BYTES;
+        it.skip = done && done[it.member];
+    } else {
+        it.member = member0 + b / F;
+        it.row = b;
+        it.ob = ref + (size_t)(b % F) * OB_BYTES;
+        it.skip = false;
+    }
+    return it;
+}
+
+// ------------------------------------------------------------------------------------------ conv1
+// 8x8 stride 4 SAME(2,2) over the u8 [84][84][4] stack; /255 fused into the load through a 256-entry
+// table (exactly float32(u8)/255.0, atari_wrappers.py:186).  y1[row][441][16] raw (pre-BN).
+__global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict__ list, int gsize, int F, int member0,
+                                               const uint8_t *__restrict__ stacks, const uint8_t *__restrict__ ref,
+                                               float *__restrict__ y1) {
+    const Item it = decode_item(blockIdx.x, list, gsize, F, member0, stacks, ref, A.done);
+    if (it.skip) return;
+    __shared__ __attribute__((aligned(16))) float w_s[4096 + 16];
+    __shared__ float lut[256];
+    __shared__ uint32_t img[88 * 88];
+    const int tid = threadIdx.x;
+    const float *base = A.bases + (size_t)A.m_slot[it.member] * A.base_stride + A.L.c1w;
+    const float *eps = A.noise + A.m_off[it.member] + A.L.c1w;
+    const float sc = A.m_scale[it.member];
+    for (int i = tid; i < 4096 + 16; i += 256) {
+        float v = sc * eps[i];
+        w_s[i] = base[i] + v;
+    }
+    lut[tid] = (float)tid / 255.0f;
+    for (int i = tid; i < 88 * 88; i += 256) {
+        int y = i / 88 - 2, x = i % 88 - 2;
+        img[i] = ((unsigned)y < 84u && (unsigned)x < 84u) ? ((const uint32_t *)it.ob)[y * 84 + x] : 0u;
+    }
+    __syncthreads();
+    if (tid >= 221) return;
+    const int p0 = 2 * tid, p1 = 2 * tid + 1;
+    const bool has1 = p1 < 441;
+    const int oy0 = p0 / 21, ox0 = p0 % 21;
+    const int oy1 = has1 ? p1 / 21 : oy0, ox1 = has1 ? p1 % 21 : ox0;
+    float a0[16], a1[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) { a0[c] = 0.0f; a1[c] = 0.0f; }
+    for (int kh = 0; kh < 8; kh++) {
+        for (int kw = 0; kw < 8; kw++) {
+            const uint32_t q0 = img[(oy0 * 4 + kh) * 88 + ox0 * 4 + kw];
+            const uint32_t q1 = img[(oy1 * 4 + kh) * 88 + ox1 * 4 + kw];
+#pragma unroll
+            for (int ci = 0; ci < 4; ci++) {
+                const float x0 = lut[(q0 >> (8 * ci)) & 255u];
+                const float x1 = lut[(q1 >> (8 * ci)) & 255u];
+                const f4a *wk = (const f4a *)(w_s + ((kh * 8 + kw) * 4 + ci) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const f4a w = wk[q];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        a0[q * 4 + e] = __builtin_fmaf(x0, w[e], a0[q * 4 + e]);
+                        a1[q * 4 + e] = __builtin_fmaf(x1, w[e], a1[q * 4 + e]);
+                    }
+                }
+            }
+        }
+    }
+    float *o0 = y1 + ((size_t)it.row * 441 + p0) * 16;
+#pragma unroll
+    for (int c = 0; c < 16; c++) o0[c] = a0[c] + w_s[4096 + c];
+    if (has1) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) o0[16 + c] = a1[c] + w_s[4096 + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ conv2
+// 4x4 stride 2 SAME(1,2); input = relu(bn1(y1)) formed while staging; y2[row][121][32] raw.
+template <bool HAS_BN>
+__global__ __launch_bounds__(128) void k_conv2(FwdArgs A, const int *__restrict__ list, int gsize, int F, int member0,
+                                               const float *__restrict__ y1, float *__restrict__ y2) {
+    const Item it = decode_item(blockIdx.x, list, gsize, F, member0, nullptr, nullptr, A.done);
+    if (it.skip) return;
+    constexpr int PS = 17;   // LDS pixel stride (16 channels + 1 pad)
+    __shared__ __attribute__((aligned(16))) float w_s[8192 + 32];
+    __shared__ float a_s[24 * 24 * PS];
+    const int tid = threadIdx.x;
+    const float *base = A.bases + (size_t)A.m_slot[it.member] * A.base_stride + A.L.c2w;
+    const float *eps = A.noise + A.m_off[it.member] + A.L.c2w;
+    const float sc = A.m_scale[it.member];
+    for (int i = tid; i < 8192 + 32; i += 128) {
+        float v = sc * eps[i];
+        w_s[i] = base[i] + v;
+    }
+    for (int i = tid; i < 24 * 24 * PS; i += 128) a_s[i] = 0.0f;
+    __syncthreads();
+    const float *bn = A.bn + (size_t)it.member * 608;
+    const float *src = y1 + (size_t)it.row * 7056;
+    for (int i = tid; i < 7056; i += 128) {
+        const int c = i & 15, pix = i >> 4;
+        float t = src[i];
+        if (HAS_BN) {
+            t = t * bn[c];
+            t = t + bn[16 + c];
+        }
+        t = t > 0.0f ? t : 0.0f;
+        a_s[((pix / 21 + 1) * 24 + pix % 21 + 1) * PS + c] = t;
+    }
+    __syncthreads();
+    if (tid >= 122) return;
+    const int half = tid & 1, pp = tid >> 1;          // positions pp and pp + 61 (61 = 121 - 60), 16 channels each
+    const int p0 = pp, p1 = pp + 61;
+    const bool has1 = p1 < 121;
+    const int oy0 = p0 / 11, ox0 = p0 % 11;
+    const int oy1 = has1 ? p1 / 11 : oy0, ox1 = has1 ? p1 % 11 : ox0;
+    float a0[16], a1[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) { a0[c] = 0.0f; a1[c] = 0.0f; }
+    for (int kh = 0; kh < 4; kh++) {
+        for (int kw = 0; kw < 4; kw++) {
+            const float *x0p = a_s + ((oy0 * 2 + kh) * 24 + ox0 * 2 + kw) * PS;
+            const float *x1p = a_s + ((oy1 * 2 + kh) * 24 + ox1 * 2 + kw) * PS;
+#pragma unroll 4
+            for (int ci = 0; ci < 16; ci++) {
+                const float x0 = x0p[ci], x1 = x1p[ci];
+                const f4a *wk = (const f4a *)(w_s + ((kh * 4 + kw) * 16 + ci) * 32 + half * 16);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const f4a w = wk[q];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        a0[q * 4 + e] = __builtin_fmaf(x0, w[e], a0[q * 4 + e]);
+                        a1[q * 4 + e] = __builtin_fmaf(x1, w[e], a1[q * 4 + e]);
+                    }
+                }
+            }
+        }
+    }
+    float *o = y2 + (size_t)it.row * 3872;
+#pragma unroll
+    for (int c = 0; c < 16; c++) o[p0 * 32 + half * 16 + c] = a0[c] + w_s[8192 + half * 16 + c];
+    if (has1) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) o[p1 * 32 + half * 16 + c] = a1[c] + w_s[8192 + half * 16 + c];
+    }
+}
+
+// ------------------------------------------------------------------------- fc (+ out + argmax)
+// The HBM-bound kernel: streams the 3872x256 noise slice once per workgroup.  4 waves = the 4 k-slices;
+// lane l owns output columns 4l..4l+3 (one 16-byte load per lane per row = 1 KiB per wave-instruction).
+// NV activation vectors share the stream:
+//   step mode   NV = group size (ES antithetic pair: 2 members with scales +sigma/-sigma; GA: 1)
+//   ref mode    SHARED_W: NV = 16 reference frames of one member (same weights)
+// Activations are relu(bn2(y2)) formed per 64-row chunk in one VGPR per vector and broadcast with
+// v_readlane.  Step mode finishes with bn3 + relu, the 256 x nact output layer and the first-max argmax.
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+template <int NV, bool SHARED_W, bool HAS_BN>
+__global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ list, int n_local, int F, int member0,
+                                            const float *__restrict__ y2, float *__restrict__ y3,
+                                            int32_t *__restrict__ actions, float *__restrict__ logits_out) {
+    __shared__ float part[4][NV][256];
+    __shared__ float a3[SHARED_W ? 1 : NV][256];
+    __shared__ float lg[SHARED_W ? 1 : NV][32];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const Layout &L = A.L;
+    int member[NV], row[NV];
+    float scale[NV];
+    if (SHARED_W) {   // reference mode: blocks of one member stay on one XCD (block b runs on XCD b % 8)
+        const int nfg = F / NV, q = blockIdx.x >> 3, x = blockIdx.x & 7;
+        const int mloc = (q / nfg) * 8 + x, fg = q % nfg;
+        if (mloc >= n_local) return;
+#pragma unroll
+        for (int v = 0; v < NV; v++) { member[v] = member0 + mloc; row[v] = mloc * F + fg * NV + v; }
+    } else {
+        const int g = list ? list[blockIdx.x] : blockIdx.x;
+#pragma unroll
+        for (int v = 0; v < NV; v++) { member[v] = g * NV + v; row[v] = member[v]; }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; v++) scale[v] = A.m_scale[member[v]];
+    const int64_t off = A.m_off[member[0]];
+    const float *base = A.bases + (size_t)A.m_slot[member[0]] * A.base_stride;
+    const float *eps = A.noise + off + L.fcw + lane * 4;
+    const float *th = base + L.fcw + lane * 4;
+
+    const int ch = (8 * wv + lane) & 31;   // bn2 channel of this lane's activation rows (968 = 8 mod 32)
+    float s2[NV], h2[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        s2[v] = HAS_BN ? A.bn[(size_t)member[v] * 608 + 32 + ch] : 1.0f;
+        h2[v] = HAS_BN ? A.bn[(size_t)member[v] * 608 + 64 + ch] : 0.0f;
+    }
+    float acc[NV][4];
+#pragma unroll
+    for (int v = 0; v < NV; v++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[v][e] = 0.0f;
+
+    const int kbeg = 968 * wv;
+    for (int c = 0; c < 16; c++) {
+        const int k0 = kbeg + 64 * c;
+        const int nr = c < 15 ? 64 : 8;
+        float xv[NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            float t = 0.0f;
+            if (lane < nr) {
+                t = y2[(size_t)row[v] * 3872 + k0 + lane];
+                if (HAS_BN) {
+                    t = t * s2[v];
+                    t = t + h2[v];
+                }
+                t = t > 0.0f ? t : 0.0f;
+            }
+            xv[v] = t;
+        }
+#pragma unroll 8
+        for (int i = 0; i < nr; i++) {
+            const size_t ro = (size_t)(k0 + i) * 256;
+            const f4u e = *(const f4u *)(eps + ro);
+            const f4a t = *(const f4a *)(th + ro);
+            if (SHARED_W) {
+                f4a w;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { float pv = scale[0] * e[q]; w[q] = t[q] + pv; }
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    const float x = lane_bcast(xv[v], i);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[v][q] = __builtin_fmaf(x, w[q], acc[v][q]);
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    const float x = lane_bcast(xv[v], i);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        float pv = scale[v] * e[q];
+                        float w = t[q] + pv;
+                        acc[v][q] = __builtin_fmaf(x, w, acc[v][q]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; v++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) part[wv][v][lane * 4 + q] = acc[v][q];
+    __syncthreads();
+    for (int i = tid; i < NV * 256; i += 256) {
+        const int v = i >> 8, j = i & 255;
+        const float s01 = part[0][v][j] + part[1][v][j];
+        const float s23 = part[2][v][j] + part[3][v][j];
+        float s = s01 + s23;
+        float pv = scale[v] * A.noise[off + L.fcb + j];
+        const float bias = base[L.fcb + j] + pv;
+        s = s + bias;
+        y3[(size_t)row[v] * 256 + j] = s;
+        if (!SHARED_W) {
+            float t = s;
+            if (HAS_BN) {
+                t = t * A.bn[(size_t)member[v] * 608 + 96 + j];
+                t = t + A.bn[(size_t)member[v] * 608 + 352 + j];
+            }
+            a3[v][j] = t > 0.0f ? t : 0.0f;
+        }
+    }
+    if (SHARED_W) return;
+    __syncthreads();
+    const int nact = L.nact;
+    if (tid < NV * nact) {
+        const int v = tid / nact, a = tid % nact;
+        const float *wb = base + L.ow + a;
+        const float *we = A.noise + off + L.ow + a;
+        float s = 0.0f;
+#pragma unroll 8
+        for (int k = 0; k < 256; k++) {
+            float pv = scale[v] * we[k * nact];
+            float w = wb[k * nact] + pv;
+            s = __builtin_fmaf(a3[v][k], w, s);
+        }
+        float pv = scale[v] * A.noise[off + L.ob + a];
+        const float bias = base[L.ob + a] + pv;
+        lg[v][a] = s + bias;
+    }
+    __syncthreads();
+    if (tid < NV) {
+        const int v = tid;
+        int best = 0;
+        for (int a = 1; a < nact; a++)
+            if (lg[v][a] > lg[v][best]) best = a;   // tf.argmax: first maximum
+        actions[member[v]] = best;
+        if (logits_out)
+            for (int a = 0; a < nact; a++) logits_out[(size_t)member[v] * nact + a] = lg[v][a];
+    }
+}
+
+// -------------------------------------------------------------- virtual batch norm statistics
+// tf.contrib.layers.batch_norm(is_training=True, decay=0): batch moments over (N, H, W), biased
+// variance, written as per-channel scale = gamma * rsqrt(var + 1e-3), shift = beta - mean * scale
+// (tf.nn.batch_normalization).  Summation order = the oracle's: per frame sequential over positions,
+// then sequential over frames.  One workgroup per member of the chunk.
+template <int C, int NPOS>
+__global__ __launch_bounds__(256) void k_bn_stats(FwdArgs A, int member0, int F, const float *__restrict__ y,
+                                                  int bn_off, int beta_off, int gamma_off) {
+    extern __shared__ float bn_part[];   // [F][C] when NPOS > 1
+    __shared__ float mean_s[C];
+    const int mloc = blockIdx.x, member = member0 + mloc, tid = threadIdx.x;
+    const float *ym = y + (size_t)mloc * F * NPOS * C;
+    const float count = (float)(F * NPOS);
+    if (NPOS > 1) {
+        for (int i = tid; i < F * C; i += 256) {
+            const int n = i / C, c = i % C;
+            const float *p = ym + (size_t)n * NPOS * C + c;
+            float s = 0.0f;
+            for (int q = 0; q < NPOS; q++) s = s + p[(size_t)q * C];
+            bn_part[i] = s;
+        }
+        __syncthreads();
+    }
+    if (tid < C) {
+        float tot = 0.0f;
+        for (int n = 0; n < F; n++) tot = tot + (NPOS > 1 ? bn_part[n * C + tid] : (0.0f + ym[(size_t)n * C + tid]));
+        mean_s[tid] = tot / count;
+    }
+    __syncthreads();
+    if (NPOS > 1) {
+        for (int i = tid; i < F * C; i += 256) {
+            const int n = i / C, c = i % C;
+            const float *p = ym + (size_t)n * NPOS * C + c;
+            const float mean = mean_s[c];
+            float qv = 0.0f;
+            for (int q = 0; q < NPOS; q++) {
+                float d = p[(size_t)q * C] - mean;
+                qv = __builtin_fmaf(d, d, qv);
+            }
+            bn_part[i] = qv;
+        }
+        __syncthreads();
+    }
+    if (tid < C) {
+        const float mean = mean_s[tid];
+        float totq = 0.0f;
+        for (int n = 0; n < F; n++) {
+            float qv;
+            if (NPOS > 1) qv = bn_part[n * C + tid];
+            else { float d = ym[(size_t)n * C + tid] - mean; qv = __builtin_fmaf(d, d, 0.0f); }
+            totq = totq + qv;
+        }
+        const float var = totq / count;
+        const float *base = A.bases + (size_t)A.m_slot[member] * A.base_stride;
+        const float *eps = A.noise + A.m_off[member];
+        const float sc = A.m_scale[member];
+        float pb = sc * eps[beta_off + tid];
+        const float beta = base[beta_off + tid] + pb;
+        float pg = sc * eps[gamma_off + tid];
+        const float gamma = base[gamma_off + tid] + pg;
+        const float inv = 1.0f / sqrtf(var + 1e-3f);
+        const float s = inv * gamma;
+        const float ms = mean * s;
+        A.bn[(size_t)member * 608 + bn_off + tid] = s;
+        A.bn[(size_t)member * 608 + bn_off + C + tid] = beta - ms;
+    }
+}
+
+}  // namespace dne

@@ -1,0 +1,140 @@
+/*
+ * dne_hip.h -- C ABI of libdne_hip.so, the MI355X (gfx950) ES/GA rollout-and-aggregate engine.
+ *
+ * Drop-in boundary for the hot path of uber-research/deep-neuroevolution's es_distributed/ CPU path.
+ * The reference has no FFI on that path (its seams are Python call signatures); each entry
+ * point below names the reference code it replaces (paths relative to the upstream repository root).
+ * The reference-side binding a maintainer adds is the ctypes stub shown in INTEGRATION.md.
+ *
+ * Conventions: every call returns 0 on success, <0 on error (dne_last_error gives the text); the caller
+ * owns all host buffers, the engine owns all device memory; plain pointers and sizes only (no torch
+ * types); a handle is bound to one HIP device, one host thread per handle; no callbacks.
+ * "member" = one episode slot (one perturbed policy + one environment).  For ES, members 2i and 2i+1
+ * are the antithetic pair of noise index i (theta + sigma*eps, theta - sigma*eps).
+ */
+#ifndef DNE_HIP_H
+#define DNE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DNE_KIND_ES 0 /* ESAtariPolicy  es_distributed/policies.py:305-429 */
+#define DNE_KIND_GA 1 /* GAAtariPolicy  es_distributed/policies.py:433-513 */
+#define DNE_OB_BYTES (84 * 84 * 4)
+#define DNE_RAM_BYTES 128
+#define DNE_BN_FLOATS 608
+
+#define DNE_PROC_CENTERED_RANK 0      /* es.py:281-282 */
+#define DNE_PROC_SIGN 1               /* es.py:283-284 */
+#define DNE_PROC_CENTERED_SIGN_RANK 2 /* es.py:285-286 */
+
+#define DNE_OPT_ADAM 0 /* optimizers.py:35-50 */
+#define DNE_OPT_SGD 1  /* optimizers.py:23-32 */
+
+typedef struct dne_handle dne_handle;
+
+typedef struct {
+    int32_t device_id;
+    int32_t policy_kind;  /* DNE_KIND_* */
+    int32_t n_actions;    /* env.action_space.n (18 for Frostbite) */
+    int32_t max_members;  /* episode slots evaluated concurrently (ES: 2 * pairs per call) */
+    int32_t ref_count;    /* size of the virtual-batch-norm reference batch (es.py:160-162: 128); multiple of 16 */
+    int32_t ref_chunk;    /* members per reference-pass chunk (bounds scratch memory); 0 = default */
+    int32_t record_bc;    /* 1: keep behaviour characterisations (ES: RAM per step, GA: final RAM) */
+    int32_t bc_max_steps; /* ES BC capacity in steps per member (<= timestep limit) */
+    int32_t profile_events; /* 1: bracket hot kernels with HIP events (dne_get_profile) */
+    int32_t reserved[7];
+} dne_config;
+
+typedef struct { /* filled by dne_get_profile; times from HIP events on the engine's stream */
+    double eval_ms;       /* wall of the last dne_*_eval call (events) */
+    double fc_ms;         /* sum over launches of the streaming fc+act kernel in the last eval */
+    int64_t fc_launches;
+    int64_t fc_group_steps; /* sum over launches of groups processed (ES: pairs, GA: members) */
+    int64_t env_steps;    /* sum of episode lengths of the last eval */
+    double conv_ms, env_ms, ref_ms; /* other stages of the last eval (0 if not profiled) */
+    double reduce_ms;     /* last dne_weighted_sum / dne_es_update aggregate kernel */
+    double materialize_ms;/* last dne_materialize kernel */
+    double reserved[6];
+} dne_profile;
+
+/* ---- lifecycle ------------------------------------------------------------------------------------ */
+int dne_create(const dne_config *cfg, dne_handle **out);
+void dne_destroy(dne_handle *h);
+const char *dne_last_error(dne_handle *h); /* h may be NULL: error of the last failed dne_create */
+int dne_num_params(int policy_kind, int n_actions); /* Policy.num_params, policies.py:22 */
+int dne_get_profile(dne_handle *h, dne_profile *out);
+
+/* ---- SharedNoiseTable (es.py:51-67) as one device buffer --------------------------------------------- */
+int dne_noise_upload(dne_handle *h, const float *host, size_t count);          /* es.py:57-60 */
+int dne_noise_get(dne_handle *h, int64_t idx, int dim, float *out_host);        /* es.py:63-64 get(i, dim) */
+
+/* ---- flat parameters (tf_util.py:224-246 SetFromFlat/GetFlat; policies.py:99-103) -------------------- */
+int dne_set_theta(dne_handle *h, int slot, const float *theta, size_t n); /* slot 0 = the ES parent theta */
+int dne_get_theta(dne_handle *h, int slot, float *out, size_t n);
+int dne_set_ref_batch(dne_handle *h, const uint8_t *ref /*[ref_count][84][84][4]*/, int count); /* policies.py:332-335 */
+
+/* A1 es.py:412-419: out[i][0] = theta + sigma*noise[idx_i:], out[i][1] = theta - sigma*noise[idx_i:]
+ * written to an engine-owned device buffer; out_host (n*2*P floats) may be NULL */
+int dne_materialize(dne_handle *h, const int64_t *noise_idx, int n, float sigma, float *out_host);
+
+/* ---- batched environment (wrap_deepmind over the device-resident stepper; atari_wrappers.py:204-222) -
+ * shape follows the reference GPU tree's native op ABI (gym_tensorflow/tf_env.cpp:115-318) */
+int dne_env_reset(dne_handle *h, int n, const uint32_t *seeds);
+int dne_env_step(dne_handle *h, int n, const int32_t *actions, float *reward, int32_t *done);
+int dne_env_observation(dne_handle *h, int n, uint8_t *out /*[n][84][84][4]*/);
+int dne_env_ram(dne_handle *h, int n, uint8_t *out /*[n][128]*/);
+int dne_env_set_observation(dne_handle *h, int n, const uint8_t *obs /*[n][84][84][4]*/);
+
+/* ---- policy forward on explicit members (policies.py:319-330,374-375 / 449-459,469-470) ---------------
+ * member i uses theta_i = base[base_slot[i]] + scale[i] * noise[noise_off[i]:]   (ES: scale = +-sigma) */
+int dne_set_members(dne_handle *h, int n, const int32_t *base_slot, const int64_t *noise_off, const float *scale);
+int dne_ref_pass(dne_handle *h, int n);                                   /* policies.py:399 (ES only) */
+int dne_get_bn(dne_handle *h, int n, float *out /*[n][608] scale,shift per layer*/);
+int dne_act(dne_handle *h, int n, int32_t *actions, float *logits /*[n][n_actions] or NULL*/);
+int dne_debug_activations(dne_handle *h, int member, float *y1 /*7056*/, float *y2 /*3872*/, float *y3 /*256*/);
+
+/* ---- A1-A7: whole-batch evaluation ------------------------------------------------------------------ */
+/* es.py:411-426 for n pairs at once: returns_n2/signreturns_n2/lengths_n2 are [n][2] like Result (es.py:18-23).
+ * env_seed[2n]: per-episode environment seed (noop count = 1 + seed % 30).  bc (may be NULL, needs record_bc):
+ * [2n][bc_max_steps][128] RAM trajectories (policies.py:410,418) */
+int dne_es_eval(dne_handle *h, const int64_t *noise_idx, int n, float sigma, int tslimit,
+                const uint32_t *env_seed, float *returns_n2, float *signreturns_n2, int32_t *lengths_n2,
+                uint8_t *bc);
+/* generic: members set by dne_set_members, one episode each (eval episodes es.py:388-405 use scale 0) */
+int dne_eval_members(dne_handle *h, int n, int tslimit, const uint32_t *env_seed, float *returns,
+                     float *signreturns, int32_t *lengths, uint8_t *bc);
+/* ga.py:251-271 for n children: chains in CSR form; theta = normc(noise[s0]) + sigma*sum noise[s_k].
+ * bc (may be NULL): final RAM [n][128] (policies.py:510) */
+int dne_ga_eval(dne_handle *h, const int32_t *chain_offsets /*n+1*/, const int64_t *seeds, int n, float sigma,
+                int tslimit, const uint32_t *env_seed, float *returns, float *signreturns, int32_t *lengths,
+                uint8_t *bc);
+/* ga.py:151-158 / 256-264: rebuild one genome into base slot `slot` (and optionally copy it out) */
+int dne_ga_rebuild(dne_handle *h, int slot, const int64_t *seeds, int nseeds, float sigma, float *out_host);
+
+/* ---- A8-A10: on-device reduce ------------------------------------------------------------------------ */
+int dne_centered_ranks(dne_handle *h, const float *x, int n, float *out);           /* es.py:70-85, stable ties */
+/* es.py:291-296: g = (sum_i w[i] * noise[idx[i]:idx[i]+P]) / denom, kept on device; g_host may be NULL */
+int dne_weighted_sum(dne_handle *h, const int64_t *idx, const float *w, int n, float denom, float *g_host);
+/* es.py:298 + optimizers.py: theta(slot 0) <- theta + step(-g + l2coeff*theta) using the device g */
+int dne_optimizer_step(dne_handle *h, int opt_kind, float l2coeff, double stepsize, double beta1_or_momentum,
+                       double beta2, double epsilon, double *update_ratio);
+int dne_optimizer_reset(dne_handle *h); /* zero m, v, t (a fresh Adam/SGD, optimizers.py:24-27,36-43) */
+/* es.py:281-298 in one call: process returns (proc_mode), aggregate, optimizer step */
+int dne_es_update(dne_handle *h, const int64_t *idx, const float *returns_n2, const float *signreturns_n2,
+                  int n, int proc_mode, int opt_kind, float l2coeff, double stepsize, double beta1_or_momentum,
+                  double beta2, double epsilon, double *update_ratio);
+/* ga.py:145: indices of the top-T returns, ordered by (-return, arrival index) */
+int dne_ga_select(dne_handle *h, const float *returns, int m, int t, int32_t *out_idx);
+
+/* ---- A13 nses.py:12-32: novelty of one behaviour characterisation against an archive ------------------- */
+int dne_novelty(dne_handle *h, const uint8_t *archive /*concatenated rows*/, const int32_t *archive_len,
+                int narchive, const uint8_t *bc, int bc_len, int dim, int k, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,299 @@
+"""GPU parity tests proper: the HIP engine (through the C ABI, ctypes) against the CPU oracle on the same
+seeded inputs.  Bit-exact for every integer/byte/index quantity AND for the fp32 forward (the operation
+order is part of the contract), 1e-5 against the reference's BLAS-ordered update vector."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NREF = 16
+NACT = 18
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from dne_hip import _lib
+    return _lib
+
+
+@pytest.fixture(scope="module")
+def es_engine(hip, small_noise):
+    e = hip.Engine(hip.KIND_ES, NACT, max_members=64, ref_count=NREF, record_bc=True, bc_max_steps=80, profile_events=True)
+    e.noise_upload(small_noise)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def ga_engine(hip, small_noise):
+    e = hip.Engine(hip.KIND_GA, NACT, max_members=64, record_bc=True)
+    e.noise_upload(small_noise)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def ref_batch(oracle):
+    return oracle.get_ref_batch(seed=0, batch_size=NREF, nact=NACT)
+
+
+def test_library_loaded_is_in_tree(hip):
+    import os
+    lib = hip.load()
+    assert os.path.samefile(lib._name, hip.LIB_PATH)
+    assert hip.LIB_PATH.endswith(os.path.join("deep-neuroevolution_amd", "csrc", "libdne_hip.so"))
+
+
+def test_noise_get_and_materialize(es_engine, oracle, small_noise):
+    e = es_engine
+    L = oracle.layout(oracle.KIND_ES, NACT)
+    assert e.P == L.P == 1009058
+    th = oracle.es_init_theta(L, 0)
+    e.set_theta(th)
+    assert np.array_equal(e.get_theta(), th)
+    assert np.array_equal(e.noise_get(12345, 1000), small_noise[12345:13345])
+    idx = np.array([0, 1, 7, 2_990_941, 123_457], np.int64)
+    out = e.materialize(idx, 0.02)
+    for i, ix in enumerate(idx):
+        assert np.array_equal(out[i, 0], oracle.perturb(th, small_noise, ix, 0.02, +1))
+        assert np.array_equal(out[i, 1], oracle.perturb(th, small_noise, ix, 0.02, -1))
+    # gpu_implementation/es.py:182-183
+    assert np.abs((out[:, 0] + out[:, 1]) / 2 - th).max() < 1e-5
+    with pytest.raises(Exception):
+        e.materialize(np.array([small_noise.size - 10], np.int64), 0.02)
+
+
+def test_env_reset_and_step(es_engine, oracle):
+    e = es_engine
+    n = 24
+    seeds = np.array([0, 7, 29, 123456789, 5] + list(range(1000, 1000 + n - 5)), np.uint32)
+    e.env_reset(seeds)
+    envs = [oracle.WrappedEnv() for _ in range(n)]
+    obs = np.stack([env.reset(int(s)) for env, s in zip(envs, seeds)])
+    assert np.array_equal(e.env_observation(n), obs)
+    assert np.array_equal(e.env_ram(n), np.stack([env.ram() for env in envs]))
+    rs = np.random.RandomState(0)
+    alive = np.ones(n, bool)
+    for t in range(60):
+        acts = rs.randint(0, NACT, n)
+        acts[:4] = 5 if t % 3 else 13          # DOWN / DOWNFIRE pressure: deaths, early done inside a skip
+        rew, done = e.env_step(acts)
+        g_obs, g_ram = e.env_observation(n), e.env_ram(n)
+        for i in range(n):
+            if not alive[i]:
+                continue
+            ob, r, d = envs[i].step(int(acts[i]))
+            assert r == rew[i] and d == done[i], (t, i)
+            assert np.array_equal(g_ram[i], envs[i].ram()), (t, i)
+            assert np.array_equal(g_obs[i], ob), (t, i)
+            alive[i] = not d
+    assert (~alive).sum() >= 2   # the test really crossed game-over
+
+
+def test_env_golden_reference_wrappers(es_engine, golden):
+    """Same check against the frames produced by the REAL reference wrappers + PIL (tests/golden)."""
+    e = es_engine
+    seeds = golden["wrap_seeds"]
+    e.env_reset(seeds.astype(np.uint32))
+    ob = e.env_observation(len(seeds))
+    steps = min(len(golden["wrap_s%d_actions" % s]) for s in seeds)
+    worst = 0
+    for i, s in enumerate(seeds):
+        worst = max(worst, np.abs(ob[i].astype(int) - golden["wrap_s%d_obs" % s][0].astype(int)).max())
+    for t in range(steps):
+        acts = np.array([golden["wrap_s%d_actions" % s][t] for s in seeds], np.int32)
+        rew, done = e.env_step(acts)
+        ob, ram = e.env_observation(len(seeds)), e.env_ram(len(seeds))
+        for i, s in enumerate(seeds):
+            assert rew[i] == golden["wrap_s%d_rews" % s][t]
+            assert bool(done[i]) == bool(golden["wrap_s%d_dones" % s][t])
+            assert np.array_equal(ram[i], golden["wrap_s%d_rams" % s][t])
+            worst = max(worst, np.abs(ob[i].astype(int) - golden["wrap_s%d_obs" % s][t + 1].astype(int)).max())
+        if done.any():
+            break
+    assert worst <= 1   # BLAS gray-dot order in the reference: <= 1 LSB
+
+
+def _members(rs, n, hi):
+    off = rs.randint(0, hi, n).astype(np.int64)
+    return off
+
+
+def test_forward_es_bit_exact(es_engine, oracle, small_noise, ref_batch):
+    e, O = es_engine, oracle
+    L = O.layout(O.KIND_ES, NACT)
+    rs = np.random.RandomState(3)
+    th = O.es_init_theta(L, 0) + (0.01 * rs.randn(L.P)).astype(np.float32)
+    e.set_theta(th)
+    e.set_ref_batch(ref_batch)
+    n = 10
+    off = _members(rs, n, small_noise.size - L.P)
+    off[1] = off[0]                      # an antithetic pair
+    scale = np.full(n, 0.02, np.float32); scale[1] = -0.02; scale[2] = 0.0; scale[3] = 0.5
+    e.set_members(np.zeros(n, np.int32), off, scale)
+    obs = rs.randint(0, 256, (n, 84, 84, 4)).astype(np.uint8)
+    obs[4] = ref_batch[2]; obs[5] = 0; obs[6] = 255
+    e.env_set_observation(obs)
+    e.ref_pass(n)
+    bn = e.get_bn(n)
+    acts, logits = e.act(n)
+    for i in range(n):
+        thi = th + np.float32(scale[i]) * small_noise[off[i]:off[i] + L.P]
+        obn = O.es_ref_pass(L, thi, ref_batch)
+        assert np.array_equal(bn[i], obn), i
+        y1, y2, y3, lg = O.forward_debug(L, thi, obn, obs[i])
+        g1, g2, g3 = e.debug_activations(i)
+        assert np.array_equal(g1, y1), i
+        assert np.array_equal(g2, y2), i
+        assert np.array_equal(g3, y3), i
+        assert np.array_equal(logits[i], lg), i
+        assert acts[i] == O.act(L, thi, obn, obs[i])[0]
+
+
+def test_forward_ga_bit_exact(ga_engine, oracle, small_noise):
+    e, O = ga_engine, oracle
+    L = O.layout(O.KIND_GA, NACT)
+    assert e.P == L.P == 1008450
+    rs = np.random.RandomState(4)
+    parents = [[100], [200_000, 7], [2_900_000, 5, 123_456]]
+    ths = []
+    for s, chain in enumerate(parents, 1):
+        out = e.ga_rebuild(s, chain, 0.005)
+        ref = O.ga_rebuild(L, small_noise, chain, 0.005)
+        assert np.array_equal(out, ref), chain
+        ths.append(ref)
+    n = 6
+    slot = np.array([1, 2, 3, 1, 2, 3], np.int32)
+    off = _members(rs, n, small_noise.size - L.P)
+    scale = np.array([0.005, 0.005, 0.005, 0.0, 0.002, 0.005], np.float32)
+    e.set_members(slot, off, scale)
+    obs = rs.randint(0, 256, (n, 84, 84, 4)).astype(np.uint8)
+    e.env_set_observation(obs)
+    acts, logits = e.act(n)
+    for i in range(n):
+        thi = ths[slot[i] - 1] + np.float32(scale[i]) * small_noise[off[i]:off[i] + L.P]
+        y1, y2, y3, lg = O.forward_debug(L, thi, None, obs[i])
+        g1, g2, g3 = e.debug_activations(i)
+        assert np.array_equal(g1, y1) and np.array_equal(g2, y2) and np.array_equal(g3, y3), i
+        assert np.array_equal(logits[i], lg), i
+        assert acts[i] == int(np.argmax(lg))
+
+
+def test_es_eval_matches_oracle(es_engine, oracle, small_noise, ref_batch):
+    e, O = es_engine, oracle
+    L = O.layout(O.KIND_ES, NACT)
+    th = O.es_init_theta(L, 0)
+    e.set_theta(th)
+    e.set_ref_batch(ref_batch)
+    n, tslimit, sigma = 8, 70, 0.02
+    srs = np.random.RandomState(0)
+    idx = np.array([srs.randint(0, small_noise.size - L.P + 1) for _ in range(n)], np.int64)
+    seeds = np.random.RandomState(1000).randint(0, 2 ** 31, 2 * n).astype(np.uint32)
+    ret, sg, ln, bc = e.es_eval(idx, sigma, tslimit, seeds, want_bc=True)
+    oret, osg, oln = O.es_eval(L, th, small_noise, idx, sigma, tslimit, ref_batch, seeds)
+    assert np.array_equal(ln, oln)
+    assert np.array_equal(ret, oret)
+    assert np.array_equal(sg, osg)
+    assert ret.dtype == np.float32 and ln.dtype == np.int32 and ret.shape == ln.shape == (n, 2)   # es.py:246-248
+    assert ln.min() < tslimit <= ln.max()     # both early game-over and the cutoff were exercised
+    # behaviour characterisation (RAM per step) of one member
+    thp = O.perturb(th, small_noise, idx[2], sigma, -1)
+    r, s, l, obc = O.rollout(L, thp, ref_batch, seeds[5], tslimit, want_bc=True)
+    assert l == ln[2, 1] and np.array_equal(bc[5, :l], obc)
+    p = e.profile()
+    assert p["env_steps"] == ln.sum() and p["fc_ms"] > 0 and p["eval_ms"] >= p["fc_ms"]
+    # eval episode (es.py:388-405): unperturbed theta through the generic member API
+    e.set_members(np.zeros(2, np.int32), np.zeros(2, np.int64), np.zeros(2, np.float32))
+    r2, s2, l2 = e.eval_members(2, tslimit, seeds[:2])
+    for i in range(2):
+        orr = O.rollout(L, th, ref_batch, seeds[i], tslimit)
+        assert (r2[i], s2[i], l2[i]) == orr[:3]
+
+
+def test_reduce_and_update(es_engine, oracle, small_noise, golden):
+    e, O = es_engine, oracle
+    L = O.layout(O.KIND_ES, NACT)
+    for key in ("ranks_small_in", "ranks_tied_in", "ranks_distinct_in"):
+        x = golden[key]
+        assert np.array_equal(e.centered_ranks(x), O.centered_ranks(x.reshape(-1)).reshape(x.shape))
+    assert np.array_equal(e.centered_ranks(golden["ranks_distinct_in"]), golden["ranks_distinct_out"])
+    n = 96
+    srs = np.random.RandomState(0)
+    idx = np.array([srs.randint(0, small_noise.size - L.P + 1) for _ in range(n)], np.int64)
+    returns = (10 * np.random.RandomState(1).poisson(20, (n, 2))).astype(np.float32)     # SURVEY 8d micro-benchmark
+    proc = O.centered_ranks(returns.reshape(-1)).reshape(n, 2)
+    w = proc[:, 0] - proc[:, 1]
+    g = e.weighted_sum(idx, w, 2 * n)
+    og = O.weighted_sum(small_noise, idx, w, L.P, 2 * n)
+    assert g.dtype == np.float32 and g.shape == (L.P,)                                    # es.py:297
+    assert np.array_equal(g, og)
+    # reference formulation (es.py:115-122: chunks of np.dot) within the north star's 1e-5
+    ref = np.zeros(L.P, np.float32)
+    for s in range(0, n, 500):
+        ref += np.dot(w[s:s + 500], np.stack([small_noise[i:i + L.P] for i in idx[s:s + 500]]))
+    ref /= returns.size
+    assert np.abs(g - ref).max() < 1e-5
+    th0 = O.es_init_theta(L, 0)
+    for kind, mk in (("adam", lambda: O.Adam(th0, 0.01)), ("sgd", lambda: O.SGD(th0, 0.01, 0.9))):
+        e.set_theta(th0); e.optimizer_reset()
+        opt = mk()
+        for it in range(3):
+            rets = (10 * np.random.RandomState(5 + it).poisson(20, (n, 2))).astype(np.float32)
+            ratio = e.es_update(idx, rets, None, "centered_rank", kind, 0.005, 0.01)
+            og = O.es_gradient(small_noise, idx, rets, L.P)
+            oratio, oth = opt.update(og, 0.005)
+            assert np.array_equal(e.get_theta(), oth), (kind, it)
+            assert abs(ratio - oratio) <= 1e-9 * oratio
+
+
+def test_ga_eval_and_select(ga_engine, oracle, small_noise):
+    e, O = ga_engine, oracle
+    L = O.layout(O.KIND_GA, NACT)
+    sigma, tslimit = 0.005, 60
+    rs = np.random.RandomState(7)
+    hi = small_noise.size - L.P + 1
+    # generation 0: no parents (ga.py:253-254) ; generation 1: children of two parents
+    gen0 = [[int(rs.randint(hi))] for _ in range(6)]
+    seeds = rs.randint(0, 2 ** 31, 6).astype(np.uint32)
+    ret, sg, ln, bc = e.ga_eval(gen0, sigma, tslimit, seeds, want_bc=True)
+    for i, chain in enumerate(gen0):
+        th = O.ga_rebuild(L, small_noise, chain, sigma)
+        r, s, l, obc = O.rollout(L, th, None, seeds[i], tslimit, want_bc=True)
+        assert (ret[i], sg[i], ln[i]) == (r, s, l), i
+        assert np.array_equal(bc[i], obc)
+    parents = [gen0[1], gen0[4]]
+    gen1 = [parents[i % 2] + [int(rs.randint(hi))] for i in range(6)]
+    gen1[5] = gen1[5] + [int(rs.randint(hi))]       # a longer chain whose prefix is not cached
+    seeds = rs.randint(0, 2 ** 31, 6).astype(np.uint32)
+    ret, sg, ln = e.ga_eval(gen1, sigma, tslimit, seeds)
+    for i, chain in enumerate(gen1):
+        th = O.ga_rebuild(L, small_noise, chain, sigma)
+        assert (ret[i], sg[i], ln[i]) == O.rollout(L, th, None, seeds[i], tslimit)[:3], i
+    scores = np.array([30, 10, 30, 50, 10, 0, 50, 30], np.float32)
+    sel = e.ga_select(scores, 4)
+    assert np.array_equal(sel, O.ga_select(scores, 4)) and sel.tolist() == [3, 6, 0, 2]
+    assert scores[sel[0]] == scores.max()                                                  # ga.py:149
+
+
+def test_novelty(es_engine, oracle, golden):
+    lens = golden["nov_lens"]
+    arch, o = [], 0
+    for n in lens:
+        arch.append(golden["nov_arch"][o:o + n]); o += n
+    bc = golden["nov_bc"]
+    for k, key in ((10, "nov_k10"), (3, "nov_k3")):
+        v = es_engine.novelty(arch, bc, k)
+        assert v == oracle.novelty(arch, bc, k)
+        assert np.isclose(v, float(golden[key]), rtol=1e-13)
+
+
+def test_errors_are_loud(es_engine, hip):
+    e = es_engine
+    with pytest.raises(hip.DneError):
+        e.set_theta(np.zeros(10, np.float32))
+    with pytest.raises(hip.DneError):
+        e.es_eval(np.array([2 ** 40], np.int64), 0.02, 10, np.zeros(2, np.uint32))
+    with pytest.raises(hip.DneError):
+        e.env_step(np.array([99], np.int32))
+    with pytest.raises(hip.DneError):
+        e.env_reset(np.zeros(10 ** 6, np.uint32))
