@@ -1,0 +1,239 @@
+"""Host-side mirror of es_distributed/policies.py for the Atari policies, backed by the HIP engine.
+
+Keeps the reference's Policy surface (policies.py:15-113, 305-513): num_params, set_trainable_flat /
+get_trainable_flat, set_ref_batch, needs_ob_stat / needs_ref_batch, reinitialize, act, rollout, save / Load.
+The network itself never exists on the host: parameters are a flat float32 vector in the creation order
+of the reference's trainable variables (flat_layout below), the forward runs in libdne_hip.so.
+"""
+import pickle
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+
+
+def flat_layout(kind, nact):
+    """Offsets of each trainable variable in the flat vector (policies.py:21-24, tf_util.py:224-246).
+    ESAtariPolicy: tf.contrib.layers order (weights, biases, BN beta, BN gamma per layer), policies.py:319-330.
+    GAAtariPolicy: U.conv / U.dense order (w, b), policies.py:449-459 via tf_util.py:133-162."""
+    spec = OrderedDict()
+    o = 0
+
+    def add(name, shape):
+        nonlocal o
+        spec[name] = (o, tuple(shape))
+        o += int(np.prod(shape))
+
+    if kind == _lib.KIND_ES:
+        add("conv1/weights", (8, 8, 4, 16)); add("conv1/biases", (16,)); add("BatchNorm/beta", (16,)); add("BatchNorm/gamma", (16,))
+        add("conv2/weights", (4, 4, 16, 32)); add("conv2/biases", (32,)); add("BatchNorm_1/beta", (32,)); add("BatchNorm_1/gamma", (32,))
+        add("fc/weights", (3872, 256)); add("fc/biases", (256,)); add("BatchNorm_2/beta", (256,)); add("BatchNorm_2/gamma", (256,))
+        add("out/weights", (256, nact)); add("out/biases", (nact,))
+    else:
+        add("conv1/w", (8, 8, 4, 16)); add("conv1/b", (1, 1, 1, 16))
+        add("conv2/w", (4, 4, 16, 32)); add("conv2/b", (1, 1, 1, 32))
+        add("fc/w", (3872, 256)); add("fc/b", (256,))
+        add("out/w", (256, nact)); add("out/b", (nact,))
+    return spec, o
+
+
+def xavier_flat(nact, seed=0):
+    """Initial ESAtariPolicy parameters: tf.contrib.layers defaults (xavier-uniform weights, zero biases,
+    BN beta 0 / gamma 1) drawn from RandomState(seed) -- TF's own initialiser is unseeded."""
+    spec, P = flat_layout(_lib.KIND_ES, nact)
+    rs = np.random.RandomState(seed)
+    th = np.zeros(P, np.float32)
+    for name, (off, shape) in spec.items():
+        n = int(np.prod(shape))
+        if name.endswith("weights"):
+            rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+            lim = np.sqrt(6.0 / (shape[-2] * rf + shape[-1] * rf))
+            th[off:off + n] = rs.uniform(-lim, lim, n).astype(np.float32)
+        elif name.endswith("gamma"):
+            th[off:off + n] = 1.0
+    return th
+
+
+class _Space:
+    def __init__(self, shape=None, n=None):
+        self.shape, self.n = shape, n
+
+
+class HipAtariEnv:
+    """The engine's batched environment seen through the gym-style surface the reference drivers use
+    (es.py:131-133: gym.make + wrap_deepmind).  One instance = env slot 0 of an Engine."""
+    observation_space = _Space(shape=_lib.OB_SHAPE)
+
+    def __init__(self, engine, seed=0):
+        self.engine = engine
+        self.action_space = _Space(n=engine.n_actions)
+        self._episode = 0
+        self._seed = int(seed)
+        self.np_random = np.random.RandomState(seed)
+
+    def seed(self, seed):
+        self._seed, self._episode = int(seed), 0
+        self.np_random = np.random.RandomState(seed)
+
+    def next_episode_seed(self):
+        s = (self._seed + self._episode) & 0xFFFFFFFF
+        self._episode += 1
+        return s
+
+    def reset(self):
+        self.engine.env_reset(np.array([self.next_episode_seed()], np.uint32))
+        return self._ob()
+
+    def step(self, action):
+        rew, done = self.engine.env_step(np.array([action], np.int32))
+        return self._ob(), float(rew[0]), bool(done[0]), {}
+
+    def _ob(self):  # ScaledFloatFrame: float32(u8) / 255.0  (atari_wrappers.py:183-186)
+        return self.engine.env_observation(1)[0].astype(np.float32) / np.float32(255.0)
+
+    def _get_ram(self):
+        return self.engine.env_ram(1)[0]
+
+    @property
+    def unwrapped(self):
+        return self
+
+
+class Policy:
+    kind = None
+
+    def __init__(self, ob_space, ac_space, engine=None, **kwargs):
+        self.args, self.kwargs = (ob_space, ac_space), kwargs
+        self.ob_space_shape = tuple(ob_space.shape)
+        self.ac_space = ac_space
+        self.num_actions = ac_space.n
+        self.spec, self.num_params = flat_layout(self.kind, self.num_actions)
+        self.engine = engine
+        self._flat = np.zeros(self.num_params, np.float32)
+        assert self.num_params == _lib.num_params(self.kind, self.num_actions)
+
+    # policies.py:99-103
+    def set_trainable_flat(self, x):
+        x = np.asarray(x, np.float32)
+        assert x.shape == (self.num_params,)
+        self._flat = x.copy()
+        if self.engine is not None:
+            self.engine.set_theta(self._flat, slot=0)
+
+    def get_trainable_flat(self):
+        if self.engine is not None:
+            self._flat = self.engine.get_theta(0)
+        return self._flat.copy()
+
+    @property
+    def needs_ob_stat(self):
+        return False
+
+    def act(self, ob, random_stream=None):
+        """policies.py:374-375 / 469-470: argmax action for a batch of float observations in [0, 1]."""
+        obs = np.asarray(ob[0] if isinstance(ob, (list, tuple)) else ob, np.float32)
+        u8 = np.rint(obs * 255.0).astype(np.uint8).reshape((-1,) + _lib.OB_SHAPE)
+        n = u8.shape[0]
+        e = self.engine
+        e.env_set_observation(u8)
+        e.set_members(np.zeros(n, np.int32), np.zeros(n, np.int64), np.zeros(n, np.float32))
+        if self.kind == _lib.KIND_ES:
+            e.ref_pass(n)
+        return e.act(n)[0].astype(np.int64)
+
+    def rollout(self, env, *, render=False, timestep_limit=None, save_obs=False, random_stream=None,
+                worker_stats=None, policy_seed=None):
+        """policies.py:378-429 / 473-513: one episode of the current flat parameters.  Returns
+        (rews float32[T], T, novelty_vector) like the reference (ES: RAM per step, GA: final RAM)."""
+        e = self.engine
+        limit = _lib.ENV_MAX_EPISODE_STEPS if timestep_limit is None else min(timestep_limit, _lib.ENV_MAX_EPISODE_STEPS)
+        if policy_seed:
+            env.seed(policy_seed)
+        seed = env.next_episode_seed()
+        e.set_members(np.zeros(1, np.int32), np.zeros(1, np.int64), np.zeros(1, np.float32))
+        # a single episode needs per-step rewards: drive it step by step through the env ABI
+        e.env_reset(np.array([seed], np.uint32))
+        if self.kind == _lib.KIND_ES:
+            e.ref_pass(1)
+        rews, rams, obs = [], [], []
+        for _ in range(limit):
+            if save_obs:
+                obs.append(e.env_observation(1)[0].astype(np.float32) / np.float32(255.0))
+            a = e.act(1)[0]
+            rew, done = e.env_step(a)
+            rews.append(rew[0])
+            if self.kind == _lib.KIND_ES:
+                rams.append(e.env_ram(1)[0])
+            if done[0]:
+                break
+        nov = np.array(rams) if self.kind == _lib.KIND_ES else e.env_ram(1)[0]
+        rews = np.array(rews, dtype=np.float32)
+        if save_obs:
+            return rews, len(rews), np.array(obs), nov
+        return rews, len(rews), nov
+
+    # policies.py:49-67 (h5py is not available here: same content in an .npz container)
+    def save(self, filename):
+        flat = self.get_trainable_flat()
+        arrays = {name: flat[off:off + int(np.prod(shape))].reshape(shape) for name, (off, shape) in self.spec.items()}
+        np.savez(filename, __name__=type(self).__name__,
+                 __args_and_kwargs__=np.void(pickle.dumps(((tuple(self.ob_space_shape), self.num_actions), self.kwargs), protocol=-1)),
+                 **{k.replace("/", "__"): v for k, v in arrays.items()})
+
+    @classmethod
+    def Load(cls, filename, engine=None, extra_kwargs=None):
+        with np.load(filename, allow_pickle=False) as f:
+            (ob_shape, nact), kwargs = pickle.loads(f["__args_and_kwargs__"].tobytes())
+            if extra_kwargs:
+                kwargs.update(extra_kwargs)
+            pol = cls(_Space(shape=ob_shape), _Space(n=nact), engine=engine, **kwargs)
+            flat = np.zeros(pol.num_params, np.float32)
+            for name, (off, shape) in pol.spec.items():
+                flat[off:off + int(np.prod(shape))] = f[name.replace("/", "__")].reshape(-1)
+        pol.set_trainable_flat(flat)
+        return pol
+
+
+class ESAtariPolicy(Policy):
+    """policies.py:305-429: conv8s4x16 -> BN -> conv4s2x32 -> BN -> fc256 -> BN -> out, argmax; virtual batch norm."""
+    kind = _lib.KIND_ES
+
+    def set_ref_batch(self, ref_batch):  # policies.py:332-335
+        ref = np.asarray(ref_batch)
+        if ref.dtype != np.uint8:       # observations are exact multiples of 1/255 (atari_wrappers.py:183-186)
+            ref = np.rint(ref.astype(np.float32) * 255.0).astype(np.uint8)
+        self.ref_batch = ref
+        if self.engine is not None:
+            self.engine.set_ref_batch(ref)
+
+    @property
+    def needs_ref_batch(self):
+        return True
+
+    def reinitialize(self):
+        raise NotImplementedError("ESAtariPolicy has no reinitialize ops in the reference (layers.* variables)")
+
+    def initialize(self, seed=0):
+        self.set_trainable_flat(xavier_flat(self.num_actions, seed))
+
+
+class GAAtariPolicy(Policy):
+    """policies.py:433-513: same trunk without batch norm, U.conv/U.dense with column-normalising reinitialize."""
+    kind = _lib.KIND_GA
+
+    def __init__(self, ob_space, ac_space, nonlin_type="relu", ac_init_std=0.1, engine=None):
+        if nonlin_type != "relu":
+            raise NotImplementedError("the HIP engine implements nonlin_type='relu' (configurations/frostbite_ga.json)")
+        if ac_init_std != 0.1:
+            raise NotImplementedError("ac_init_std is fixed at the reference default 0.1 (policies.py:434)")
+        super().__init__(ob_space, ac_space, engine=engine, nonlin_type=nonlin_type, ac_init_std=ac_init_std)
+
+    @property
+    def needs_ref_batch(self):
+        return False
+
+    def set_from_seeds(self, seeds, noise_stdev):
+        """ga.py:256-264 / 151-158: theta = normc(noise[s0]) + noise_stdev * sum noise[s_k], built on device."""
+        self._flat = self.engine.ga_rebuild(0, np.asarray(seeds, np.int64), noise_stdev)
+        return self._flat
