@@ -50,7 +50,7 @@ __device__ inline void synth_reset(uint8_t *ram, uint32_t seed) {
 
 __device__ __forceinline__ bool synth_on_floe(const uint8_t *ram, int px, int r) {
     int rel = (px + 164 - ram[RM_OFF + r]) % 160;
-    return (rel % 40) < 24;
+    return (rel % 40) < 32;
 }
 
 // one raw emulator frame; returns the integer reward
@@ -83,9 +83,8 @@ __device__ inline int synth_frame(uint8_t *ram, int a) {
         ram[RM_FREEZE]--;
     } else {
         int px = ram[RM_PX], prow = ram[RM_PROW];
-        if (prow > 0) px += ram[RM_DIR + prow - 1] ? -speed : speed;
-        px += 2 * dx;
-        px = px < 8 ? 8 : (px > 144 ? 144 : px);
+        if (prow > 0) px = (px + (ram[RM_DIR + prow - 1] ? -speed : speed) + 2 * dx + 160) % 160;   // ice rows wrap
+        else { px += 2 * dx; px = px < 8 ? 8 : (px > 144 ? 144 : px); }
         if (ram[RM_COOL] > 0) {
             ram[RM_COOL]--;
         } else if (dy != 0) {
@@ -101,6 +100,7 @@ __device__ inline int synth_frame(uint8_t *ram, int a) {
             } else if (tgt <= 4) {
                 prow = tgt;
                 ram[RM_COOL] = 12;
+                if (prow == 0) px = px < 8 ? 8 : (px > 144 ? 144 : px);
                 if (prow > 0) {
                     int r = prow - 1;
                     if (synth_on_floe(ram, px, r)) {
@@ -153,7 +153,7 @@ __device__ __forceinline__ int synth_pixel(const uint8_t *ram, int x, int y) {
     const int prow = ram[RM_PROW], px = ram[RM_PX];
     const int py = prow == 0 ? 62 : 48 + 32 * prow;
     const bool blink = ram[RM_FREEZE] > 0 && (ram[RM_FC] & 4);
-    if (!blink && (unsigned)(x - px) < 8u && (unsigned)(y - py) < 16u) return 8;
+    if (!blink && (unsigned)(y - py) < 16u && ((x - px + 160) % 160) < 8) return 8;
     if (y < 8 || y >= 208) return 0;
     if (y < 16) {
         if (x >= 8 && x < 8 + 2 * ram[RM_TEMP]) return 11;
@@ -184,7 +184,7 @@ __device__ __forceinline__ int synth_pixel(const uint8_t *ram, int x, int y) {
     }
     if (yo >= 16 && yo < 28) {
         int rel = (x + 160 - ram[RM_OFF + r]) % 160;
-        if ((rel % 40) < 24) return ram[RM_VIS + r] ? 7 : 6;
+        if ((rel % 40) < 32) return ram[RM_VIS + r] ? 7 : 6;
     }
     return (yo & 8) ? 15 : 5;
 }

@@ -298,7 +298,7 @@ void orc_raw_reset(uint8_t *ram, uint32_t seed) {
 
 static int on_floe(const uint8_t *ram, int px, int r) {
     int rel = (px + 4 + 160 - ram[R_OFF + r]) % 160;
-    return (rel % 40) < 24;
+    return (rel % 40) < 32;
 }
 
 int orc_raw_frame(uint8_t *ram, int a) {
@@ -334,10 +334,14 @@ int orc_raw_frame(uint8_t *ram, int a) {
         ram[R_FREEZE]--;
     } else {
         int px = ram[R_PX], prow = ram[R_PROW];
-        if (prow > 0) px += ram[R_DIR + prow - 1] ? -speed : speed;
-        px += 2 * dx;
-        if (px < 8) px = 8;
-        if (px > 144) px = 144;
+        if (prow > 0) { /* carried by the floe; the screen wraps on the ice rows */
+            px += ram[R_DIR + prow - 1] ? -speed : speed;
+            px = (px + 2 * dx + 160) % 160;
+        } else {
+            px += 2 * dx;
+            if (px < 8) px = 8;
+            if (px > 144) px = 144;
+        }
         if (ram[R_COOL] > 0) {
             ram[R_COOL]--;
         } else if (dy != 0) {
@@ -358,6 +362,7 @@ int orc_raw_frame(uint8_t *ram, int a) {
             } else if (tgt <= 4) {
                 prow = tgt;
                 ram[R_COOL] = 12;
+                if (prow == 0) { if (px < 8) px = 8; if (px > 144) px = 144; }
                 if (prow > 0) {
                     int r = prow - 1;
                     if (on_floe(ram, px, r)) {
@@ -422,7 +427,7 @@ static uint8_t render_pixel(const uint8_t *ram, int x, int y) {
     int fc = ram[R_FC0] | (ram[R_FC1] << 8);
     int py0 = prow == 0 ? 62 : 80 + 32 * (prow - 1);
     int blink = ram[R_FREEZE] > 0 && (fc & 4);
-    if (!blink && x >= px && x < px + 8 && y >= py0 && y < py0 + 16) return 8;
+    if (!blink && ((x - px + 160) % 160) < 8 && y >= py0 && y < py0 + 16) return 8;
     if (y < 8) return 0;
     if (y < 16) {
         if (x >= 8 && x < 8 + 2 * ram[R_TEMP]) return 11;
@@ -457,7 +462,7 @@ static uint8_t render_pixel(const uint8_t *ram, int x, int y) {
         }
         if (yo >= 16 && yo < 28) {
             int rel = (x + 160 - ram[R_OFF + r]) % 160;
-            if ((rel % 40) < 24) return ram[R_VIS + r] ? 7 : 6;
+            if ((rel % 40) < 32) return ram[R_VIS + r] ? 7 : 6;
         }
         return ((yo >> 3) & 1) ? 15 : 5;
     }
