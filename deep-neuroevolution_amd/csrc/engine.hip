@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
+#include <cstdlib>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -34,89 +36,99 @@ struct EnvArgs {
     uint8_t *stacks;                 // [M][84][84][4]
     const ResizeTables *T;
     float *ret, *sign, *step_reward; // [M]
-    int32_t *len, *done;
+    int32_t *len, *done, *stepped;
     const int32_t *action;
     uint8_t *bc;
     int bc_mode;                     // 0 none, 1 RAM per step (ES, policies.py:410,418), 2 final RAM (GA, policies.py:510)
     int bc_max_steps;
 };
 
+// The emulator state is 40 live bytes per member (RAM bytes 40..127 stay zero).  The per-frame logic is
+// branchy scalar code, so it runs one member per lane (64 members per workgroup, RAM rows staged in LDS at
+// an 11-dword stride = conflict-free); the pixel work runs in a separate kernel with one workgroup per member.
+constexpr int RAM_STRIDE = 44;
+
 __device__ __forceinline__ void ram_copy(uint8_t *dst, const uint8_t *src) {
-    for (int j = 0; j < 32; j++) ((uint32_t *)dst)[j] = ((const uint32_t *)src)[j];
+    for (int j = 0; j < RAM_LIVE / 4; j++) ((uint32_t *)dst)[j] = ((const uint32_t *)src)[j];
 }
 
 // atari_wrappers.py:95-107: repeat the action 4 raw frames, sum rewards, stop at game over
-__device__ inline int skip4(EnvLds &s, int action, int *over) {
+__device__ inline int skip4(uint8_t *prev, uint8_t *cur, int action, int *over) {
     int tot = 0;
     *over = 0;
     for (int i = 0; i < 4; i++) {
-        ram_copy(s.ram_prev, s.ram_cur);
-        tot += synth_frame(s.ram_cur, action);
-        if (s.ram_cur[RM_OVER]) { *over = 1; break; }
+        ram_copy(prev, cur);
+        tot += synth_frame(cur, action);
+        if (cur[RM_OVER]) { *over = 1; break; }
     }
     return tot;
 }
 
-__global__ __launch_bounds__(256) void k_env_reset(EnvArgs E, const uint32_t *__restrict__ seeds, int n) {
-    __shared__ __attribute__((aligned(16))) EnvLds s;
-    const int m = blockIdx.x, tid = threadIdx.x;
-    s.gray2[tid] = E.T->gray2[tid];
-    if (tid == 0) {
-        const uint32_t seed = seeds[m];
-        synth_reset(s.ram_cur, seed);                    // env.reset()
-        ram_copy(s.ram_prev, s.ram_cur);
-        const int noops = 1 + (int)(seed % 30u);         // atari_wrappers.py:18-31 (count fixed by the seed)
-        for (int i = 0; i < noops; i++) { ram_copy(s.ram_prev, s.ram_cur); synth_frame(s.ram_cur, 0); }
-        int over;
-        skip4(s, 1, &over);                              // atari_wrappers.py:40-48 FIRE then action 2
-        skip4(s, 2, &over);
-        E.ret[m] = 0.0f; E.sign[m] = 0.0f; E.step_reward[m] = 0.0f; E.len[m] = 0; E.done[m] = 0;
+__global__ __launch_bounds__(64) void k_env_reset_logic(EnvArgs E, const uint32_t *__restrict__ seeds, int n) {
+    __shared__ __attribute__((aligned(16))) uint8_t rows[64][2][RAM_STRIDE];
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= n) return;
+    uint8_t *prev = rows[threadIdx.x][0], *cur = rows[threadIdx.x][1];
+    const uint32_t seed = seeds[m];
+    synth_reset(cur, seed);                          // env.reset()
+    ram_copy(prev, cur);
+    const int noops = 1 + (int)(seed % 30u);         // atari_wrappers.py:18-31 (count fixed by the seed)
+    for (int i = 0; i < noops; i++) { ram_copy(prev, cur); synth_frame(cur, 0); }
+    int over;
+    skip4(prev, cur, 1, &over);                      // atari_wrappers.py:40-48 FIRE then action 2
+    skip4(prev, cur, 2, &over);
+    uint32_t *gp = (uint32_t *)(E.ram_prev + (size_t)m * 128), *gc = (uint32_t *)(E.ram_cur + (size_t)m * 128);
+    for (int j = 0; j < 32; j++) {
+        gp[j] = j < RAM_LIVE / 4 ? ((const uint32_t *)prev)[j] : 0u;
+        gc[j] = j < RAM_LIVE / 4 ? ((const uint32_t *)cur)[j] : 0u;
     }
-    __syncthreads();
-    synth_observe(s, E.T, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), true);   // FrameStack reset: 4 copies
-    __syncthreads();
-    if (tid < 128) {
-        E.ram_prev[(size_t)m * 128 + tid] = s.ram_prev[tid];
-        E.ram_cur[(size_t)m * 128 + tid] = s.ram_cur[tid];
-    }
+    E.ret[m] = 0.0f; E.sign[m] = 0.0f; E.step_reward[m] = 0.0f; E.len[m] = 0; E.done[m] = 0; E.stepped[m] = 1;
 }
 
-__global__ __launch_bounds__(256) void k_env_step(EnvArgs E, const int *__restrict__ list, int gsize, int tslimit) {
+__global__ __launch_bounds__(64) void k_env_logic(EnvArgs E, const int *__restrict__ list, int gsize, int n_items, int tslimit) {
+    __shared__ __attribute__((aligned(16))) uint8_t rows[64][2][RAM_STRIDE];
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= n_items) return;
+    const int g = list ? list[b / gsize] : b / gsize;
+    const int m = g * gsize + b % gsize;
+    if (E.done[m]) { E.stepped[m] = 0; return; }
+    uint8_t *prev = rows[threadIdx.x][0], *cur = rows[threadIdx.x][1];
+    uint32_t *gp = (uint32_t *)(E.ram_prev + (size_t)m * 128), *gc = (uint32_t *)(E.ram_cur + (size_t)m * 128);
+    for (int j = 0; j < RAM_LIVE / 4; j++) { ((uint32_t *)prev)[j] = gp[j]; ((uint32_t *)cur)[j] = gc[j]; }
+    int over;
+    const int r = skip4(prev, cur, E.action[m], &over);
+    for (int j = 0; j < RAM_LIVE / 4; j++) { gp[j] = ((const uint32_t *)prev)[j]; gc[j] = ((const uint32_t *)cur)[j]; }
+    const int t = E.len[m];
+    if (E.bc_mode == 1 && t < E.bc_max_steps) {     // policies.py:410,418 RAM after every step
+        uint32_t *d = (uint32_t *)(E.bc + ((size_t)m * E.bc_max_steps + t) * 128);
+        for (int j = 0; j < RAM_LIVE / 4; j++) d[j] = ((const uint32_t *)cur)[j];
+    }
+    if (E.bc_mode == 2) {                           // policies.py:510 final RAM
+        uint32_t *d = (uint32_t *)(E.bc + (size_t)m * 128);
+        for (int j = 0; j < RAM_LIVE / 4; j++) d[j] = ((const uint32_t *)cur)[j];
+    }
+    E.ret[m] += (float)r;                                    // es.py:425 rews.sum()
+    E.sign[m] += (float)((r > 0) - (r < 0));                 // es.py:423 np.sign(rews).sum()
+    E.step_reward[m] = (float)r;
+    E.len[m] = t + 1;
+    E.stepped[m] = 1;
+    if (over || t + 1 >= tslimit) E.done[m] = 1;             // policies.py:401,424-425
+}
+
+// max over the last two raw frames + WarpFrame + FrameStack for every member stepped by the logic kernel
+__global__ __launch_bounds__(256) void k_env_render(EnvArgs E, const int *__restrict__ list, int gsize, int fill) {
     __shared__ __attribute__((aligned(16))) EnvLds s;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int g = list ? list[b / gsize] : b / gsize;
     const int m = g * gsize + b % gsize;
-    if (E.done[m]) return;
-    s.gray2[tid] = E.T->gray2[tid];
-    if (tid < 128) {
+    if (!E.stepped[m]) return;
+    synth_load_tables(s, E.T);
+    if (tid < 64) {
         s.ram_prev[tid] = E.ram_prev[(size_t)m * 128 + tid];
         s.ram_cur[tid] = E.ram_cur[(size_t)m * 128 + tid];
     }
     __syncthreads();
-    if (tid == 0) {
-        int over;
-        s.misc[0] = skip4(s, E.action[m], &over);
-        s.misc[1] = over;
-    }
-    __syncthreads();
-    synth_observe(s, E.T, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), false);
-    __syncthreads();
-    const int t = E.len[m];
-    if (tid < 128) {
-        E.ram_prev[(size_t)m * 128 + tid] = s.ram_prev[tid];
-        E.ram_cur[(size_t)m * 128 + tid] = s.ram_cur[tid];
-        if (E.bc_mode == 1 && t < E.bc_max_steps) E.bc[((size_t)m * E.bc_max_steps + t) * 128 + tid] = s.ram_cur[tid];
-        if (E.bc_mode == 2) E.bc[(size_t)m * 128 + tid] = s.ram_cur[tid];
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const int r = s.misc[0];
-        E.ret[m] += (float)r;                                    // es.py:425 rews.sum()
-        E.sign[m] += (float)((r > 0) - (r < 0));                 // es.py:423 np.sign(rews).sum()
-        E.step_reward[m] = (float)r;
-        E.len[m] = t + 1;
-        if (s.misc[1] || t + 1 >= tslimit) E.done[m] = 1;       // policies.py:401,424-425
-    }
+    synth_observe(s, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), fill != 0);
 }
 
 // order-preserving compaction of the active-group list
@@ -156,6 +168,8 @@ struct dne_handle {
     Layout L{};
     std::string err;
     hipStream_t stream = nullptr;
+    std::vector<hipStream_t> sub_streams;   // sub-batch streams (sub_streams[0] == stream)
+    int nsub = 2, sub_min_groups = 256, fc_grid = 256;
     int M = 0, F = 0, ref_chunk = 0;
     size_t base_stride = 0;
     // device memory
@@ -169,7 +183,7 @@ struct dne_handle {
     uint8_t *ram_prev = nullptr, *ram_cur = nullptr, *stacks = nullptr;
     ResizeTables *tables = nullptr;
     float *ret = nullptr, *sign = nullptr, *step_reward = nullptr, *logits = nullptr;
-    int32_t *len = nullptr, *done = nullptr, *action = nullptr;
+    int32_t *len = nullptr, *done = nullptr, *action = nullptr, *stepped = nullptr;
     uint32_t *seeds = nullptr;
     float *y1 = nullptr, *y2 = nullptr, *y3 = nullptr; size_t rows_cap = 0;
     int *list_a = nullptr, *list_b = nullptr, *count_dev = nullptr;
@@ -179,6 +193,7 @@ struct dne_handle {
     int64_t *scratch_i = nullptr;
     // profiling
     std::vector<hipEvent_t> ev_pool;
+    std::vector<hipEvent_t> fc_ring;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     dne_profile prof{};
     // GA parent cache: prefix chain -> base slot
@@ -204,7 +219,7 @@ struct dne_handle {
     EnvArgs env(int bc_mode) const {
         EnvArgs E;
         E.ram_prev = ram_prev; E.ram_cur = ram_cur; E.stacks = stacks; E.T = tables;
-        E.ret = ret; E.sign = sign; E.step_reward = step_reward; E.len = len; E.done = done; E.action = action;
+        E.ret = ret; E.sign = sign; E.step_reward = step_reward; E.len = len; E.done = done; E.stepped = stepped; E.action = action;
         E.bc = bc; E.bc_mode = bc ? bc_mode : 0; E.bc_max_steps = cfg.bc_max_steps;
         return E;
     }
@@ -331,6 +346,11 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
 #define CH(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { h->fail("%s -> %s", #expr, hipGetErrorString(_e)); return bail(0); } } while (0)
     CH(hipSetDevice(cfg->device_id));
     CH(hipStreamCreate(&h->stream));
+    h->sub_streams.push_back(h->stream);
+    if (const char *e = getenv("DNE_NSUB")) h->nsub = std::max(1, std::min(8, atoi(e)));
+    if (const char *e = getenv("DNE_FC_GRID")) h->fc_grid = std::max(1, atoi(e));
+    if (const char *e = getenv("DNE_SUB_MIN_GROUPS")) h->sub_min_groups = std::max(1, atoi(e));
+    for (int s = 1; s < h->nsub; s++) { hipStream_t st; CH(hipStreamCreate(&st)); h->sub_streams.push_back(st); }
     make_layout(cfg->policy_kind, cfg->n_actions, &h->L);
     h->M = cfg->max_members;
     h->F = cfg->policy_kind == DNE_KIND_ES ? (cfg->ref_count > 0 ? cfg->ref_count : 128) : 0;
@@ -359,11 +379,11 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     }
     CH(dalloc(&h->ret, M)); CH(dalloc(&h->sign, M)); CH(dalloc(&h->step_reward, M));
     CH(dalloc(&h->logits, M * cfg->n_actions));
-    CH(dalloc(&h->len, M)); CH(dalloc(&h->done, M)); CH(dalloc(&h->action, M)); CH(dalloc(&h->seeds, M));
+    CH(dalloc(&h->len, M)); CH(dalloc(&h->done, M)); CH(dalloc(&h->action, M)); CH(dalloc(&h->seeds, M)); CH(dalloc(&h->stepped, M));
     CH(hipMemset(h->done, 0, M * sizeof(int32_t))); CH(hipMemset(h->len, 0, M * sizeof(int32_t)));
     h->rows_cap = std::max<size_t>(M, (size_t)h->ref_chunk * std::max(h->F, 1));
     CH(dalloc(&h->y1, h->rows_cap * 7056)); CH(dalloc(&h->y2, h->rows_cap * 3872)); CH(dalloc(&h->y3, h->rows_cap * 256));
-    CH(dalloc(&h->list_a, M)); CH(dalloc(&h->list_b, M)); CH(dalloc(&h->count_dev, 1));
+    CH(dalloc(&h->list_a, M)); CH(dalloc(&h->list_b, M)); CH(dalloc(&h->count_dev, 8));
     if (cfg->record_bc) {
         h->bc_bytes = cfg->policy_kind == DNE_KIND_ES ? M * (size_t)std::max(cfg->bc_max_steps, 1) * 128 : M * 128;
         CH(dalloc(&h->bc, h->bc_bytes));
@@ -371,6 +391,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     h->scratch_cap = std::max<size_t>(4 * M + 64, 65536);
     CH(dalloc(&h->scratch_f, h->scratch_cap)); CH(dalloc(&h->scratch_i, h->scratch_cap));
     CH(hipEventCreate(&h->ev_a)); CH(hipEventCreate(&h->ev_b));
+    for (int i = 0; i < 64; i++) { hipEvent_t ev; CH(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); h->fc_ring.push_back(ev); }
     CH(hipDeviceSynchronize());
 #undef CH
 #undef CCHECK
@@ -384,13 +405,15 @@ extern "C" void dne_destroy(dne_handle *h) {
     hipDeviceSynchronize();
     void *ptrs[] = {h->noise, h->bases, h->opt_m, h->opt_v, h->g, h->partial, h->ref, h->m_slot, h->m_off, h->m_scale,
                     h->bn, h->ram_prev, h->ram_cur, h->stacks, h->tables, h->ret, h->sign, h->step_reward, h->logits,
-                    h->len, h->done, h->action, h->seeds, h->y1, h->y2, h->y3, h->list_a, h->list_b, h->count_dev,
+                    h->len, h->done, h->action, h->seeds, h->stepped, h->y1, h->y2, h->y3, h->list_a, h->list_b, h->count_dev,
                     h->bc, h->mat_out, h->scratch_f, h->scratch_i};
     for (void *p : ptrs)
         if (p) hipFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    for (hipEvent_t e : h->fc_ring) hipEventDestroy(e);
     if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->ev_b) hipEventDestroy(h->ev_b);
+    for (size_t s = 1; s < h->sub_streams.size(); s++) hipStreamDestroy(h->sub_streams[s]);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -470,6 +493,20 @@ extern "C" int dne_materialize(dne_handle *h, const int64_t *idx, int n, float s
     return 0;
 }
 
+static void launch_env_reset(dne_handle *h, int n) {
+    const EnvArgs E = h->env(0);
+    hipLaunchKernelGGL(k_env_reset_logic, dim3((n + 63) / 64), dim3(64), 0, h->stream, E, (const uint32_t *)h->seeds, n);
+    hipLaunchKernelGGL(k_env_render, dim3(n), dim3(256), 0, h->stream, E, (const int *)nullptr, 1, 1);   // FrameStack reset: 4 copies
+}
+
+static void launch_env_step(dne_handle *h, const EnvArgs &E, const int *list, int count, int gsize, int tslimit,
+                            hipStream_t st = nullptr) {
+    if (!st) st = h->stream;
+    const int items = count * gsize;
+    hipLaunchKernelGGL(k_env_logic, dim3((items + 63) / 64), dim3(64), 0, st, E, list, gsize, items, tslimit);
+    hipLaunchKernelGGL(k_env_render, dim3(items), dim3(256), 0, st, E, list, gsize, 0);
+}
+
 // ------------------------------------------------------------------------------- env ABI
 static int check_n(dne_handle *h, int n) {
     if (n <= 0 || n > h->M) return h->fail("n = %d outside [1, max_members = %d]", n, h->M);
@@ -479,7 +516,7 @@ static int check_n(dne_handle *h, int n) {
 extern "C" int dne_env_reset(dne_handle *h, int n, const uint32_t *seeds) {
     if (check_n(h, n)) return -1;
     HCHECK(h, hipMemcpyAsync(h->seeds, seeds, n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_env_reset, dim3(n), dim3(256), 0, h->stream, h->env(0), h->seeds, n);
+    launch_env_reset(h, n);
     HCHECK(h, hipGetLastError());
     HCHECK(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -491,7 +528,7 @@ extern "C" int dne_env_step(dne_handle *h, int n, const int32_t *actions, float 
         if (actions[i] < 0 || actions[i] >= h->cfg.n_actions) return h->fail("action %d out of range", actions[i]);
     HCHECK(h, hipMemcpyAsync(h->action, actions, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     HCHECK(h, hipMemsetAsync(h->step_reward, 0, n * sizeof(float), h->stream));
-    hipLaunchKernelGGL(k_env_step, dim3(n), dim3(256), 0, h->stream, h->env(0), (const int *)nullptr, 1, 0x7fffffff);
+    launch_env_step(h, h->env(0), nullptr, n, 1, 0x7fffffff);
     HCHECK(h, hipGetLastError());
     if (reward) HCHECK(h, hipMemcpyAsync(reward, h->step_reward, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     if (done) HCHECK(h, hipMemcpyAsync(done, h->done, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
@@ -545,7 +582,7 @@ static int ref_pass(dne_handle *h, int n) {
                            (const uint8_t *)h->stacks, (const uint8_t *)h->ref, h->y1);
         hipLaunchKernelGGL((k_bn_stats<16, 441>), dim3(nc), dim3(256), F * 16 * sizeof(float), h->stream, A, m0, F,
                            (const float *)h->y1, 0, h->L.bn1b, h->L.bn1g);
-        hipLaunchKernelGGL((k_conv2<true>), dim3(nc * F), dim3(128), 0, h->stream, A, (const int *)nullptr, 1, F, m0,
+        hipLaunchKernelGGL((k_conv2<true>), dim3(nc * F), dim3(256), 0, h->stream, A, (const int *)nullptr, 1, F, m0,
                            (const float *)h->y1, h->y2);
         hipLaunchKernelGGL((k_bn_stats<32, 121>), dim3(nc), dim3(256), F * 32 * sizeof(float), h->stream, A, m0, F,
                            (const float *)h->y2, 32, h->L.bn2b, h->L.bn2g);
@@ -576,19 +613,21 @@ extern "C" int dne_get_bn(dne_handle *h, int n, float *out) {
 }
 
 // one policy decision for the groups in `list` (count groups of gsize members)
-static void launch_forward(dne_handle *h, const int *list, int count, int gsize, bool use_done, float *logits) {
+static void launch_forward(dne_handle *h, const int *list, int count, int gsize, bool use_done, hipStream_t st = nullptr) {
+    if (!st) st = h->stream;
     const FwdArgs A = h->fwd(use_done);
     const bool es = h->L.kind == DNE_KIND_ES;
-    hipLaunchKernelGGL(k_conv1, dim3(count * gsize), dim3(256), 0, h->stream, A, list, gsize, 1, 0,
+    hipLaunchKernelGGL(k_conv1, dim3(count * gsize), dim3(256), 0, st, A, list, gsize, 1, 0,
                        (const uint8_t *)h->stacks, (const uint8_t *)nullptr, h->y1);
-    if (es) hipLaunchKernelGGL((k_conv2<true>), dim3(count * gsize), dim3(128), 0, h->stream, A, list, gsize, 1, 0, (const float *)h->y1, h->y2);
-    else hipLaunchKernelGGL((k_conv2<false>), dim3(count * gsize), dim3(128), 0, h->stream, A, list, gsize, 1, 0, (const float *)h->y1, h->y2);
+    if (es) hipLaunchKernelGGL((k_conv2<true>), dim3(count * gsize), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2);
+    else hipLaunchKernelGGL((k_conv2<false>), dim3(count * gsize), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2);
 }
 
-static void launch_fc(dne_handle *h, const int *list, int count, int gsize, float *logits) {
+static void launch_fc(dne_handle *h, const int *list, int count, int gsize, float *logits, hipStream_t st = nullptr) {
+    if (!st) st = h->stream;
     const FwdArgs A = h->fwd(false);
     const bool es = h->L.kind == DNE_KIND_ES;
-#define FC(NV, BN) hipLaunchKernelGGL((k_fc<NV, false, BN>), dim3(count), dim3(256), 0, h->stream, A, list, count, 1, 0, (const float *)h->y2, h->y3, h->action, logits)
+#define FC(NV, BN) hipLaunchKernelGGL((k_fc<NV, false, BN>), dim3(std::min(count, h->fc_grid)), dim3(256), 0, st, A, list, count, 1, 0, (const float *)h->y2, h->y3, h->action, logits)
     if (gsize == 2) { if (es) FC(2, true); else FC(2, false); }
     else { if (es) FC(1, true); else FC(1, false); }
 #undef FC
@@ -596,7 +635,7 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
 
 extern "C" int dne_act(dne_handle *h, int n, int32_t *actions, float *logits) {
     if (check_n(h, n)) return -1;
-    launch_forward(h, nullptr, n, 1, false, nullptr);
+    launch_forward(h, nullptr, n, 1, false);
     launch_fc(h, nullptr, n, 1, h->logits);
     HCHECK(h, hipGetLastError());
     HCHECK(h, hipStreamSynchronize(h->stream));
@@ -617,6 +656,9 @@ extern "C" int dne_debug_activations(dne_handle *h, int member, float *y1, float
 // ------------------------------------------------------------------------------- batch evaluation
 // policies.py:378-429 / 473-513 for n members at once: reset, (ES) reference pass, then lock-step
 // act -> env.step over the shrinking list of active groups until every episode is done.
+// The active groups are split into `nsub` independent sub-batches, each stepped on its own HIP stream: while
+// one sub-batch streams its noise slices through the HBM-bound fc kernel, another runs its MFMA convolutions
+// and its emulator frames, so the memory system and the matrix/vector pipes are busy at the same time.
 static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_t *env_seed, float *returns,
                      float *signreturns, int32_t *lengths, uint8_t *bc_out) {
     if (n % gsize) return h->fail("member count %d not a multiple of the group size %d", n, gsize);
@@ -625,38 +667,71 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     const bool prof = h->cfg.profile_events != 0;
     const int bc_mode = bc_out ? (h->L.kind == DNE_KIND_ES ? 1 : 2) : 0;
     if (bc_mode == 1) HCHECK(h, hipMemsetAsync(h->bc, 0, (size_t)n * h->cfg.bc_max_steps * 128, h->stream));
+    if (bc_mode == 2) HCHECK(h, hipMemsetAsync(h->bc, 0, (size_t)n * 128, h->stream));
     HCHECK(h, hipEventRecord(h->ev_a, h->stream));
     HCHECK(h, hipMemcpyAsync(h->seeds, env_seed, n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_env_reset, dim3(n), dim3(256), 0, h->stream, h->env(0), h->seeds, n);
-    size_t ne = 0;
-    if (prof) HCHECK(h, hipEventRecord(h->event(ne++), h->stream));
+    launch_env_reset(h, n);
+    if (prof) HCHECK(h, hipEventRecord(h->event(0), h->stream));
     if (ref_pass(h, n)) return -1;
-    if (prof) HCHECK(h, hipEventRecord(h->event(ne++), h->stream));
-    int count = n / gsize;
-    hipLaunchKernelGGL(k_iota, dim3((count + 255) / 256), dim3(256), 0, h->stream, h->list_a, count);
-    int *cur = h->list_a, *nxt = h->list_b;
+    HCHECK(h, hipEventRecord(h->event(1), h->stream));
+    const int groups = n / gsize;
+    hipLaunchKernelGGL(k_iota, dim3((groups + 255) / 256), dim3(256), 0, h->stream, h->list_a, groups);
+    HCHECK(h, hipStreamSynchronize(h->stream));
+
+    const int nsub = groups >= 2 * h->sub_min_groups ? std::min(h->nsub, (int)h->sub_streams.size()) : 1;
+    struct Sub { hipStream_t st; int *cur, *nxt; int count; int *count_dev; int host_count; size_t ev0; std::vector<int> step_counts; };
+    std::vector<Sub> subs(nsub);
+    size_t ne = 2;
+    for (int s = 0; s < nsub; s++) {
+        const int lo = (int)((long long)groups * s / nsub), hi = (int)((long long)groups * (s + 1) / nsub);
+        subs[s].st = h->sub_streams[s];
+        subs[s].cur = h->list_a + lo; subs[s].nxt = h->list_b + lo;   // disjoint windows of the two list buffers
+        subs[s].count = hi - lo;
+        subs[s].count_dev = h->count_dev + s;
+        subs[s].ev0 = 0;
+    }
     const EnvArgs E = h->env(bc_mode);
     int t = 0;
-    std::vector<int> step_counts;
     long long group_steps = 0;
-    while (count > 0 && t < tslimit) {
+    std::vector<std::array<size_t, 4>> evs;   // per launch set: event indices {before, after conv, after fc, after env}
+    auto total = [&]() { int c = 0; for (auto &s : subs) c += s.count; return c; };
+    hipEvent_t last_fc = nullptr;
+    size_t fc_ring_pos = 0;
+    while (total() > 0 && t < tslimit) {
         const int burst = std::min(16, tslimit - t);
-        for (int s = 0; s < burst; s++) {
-            launch_forward(h, cur, count, gsize, true, nullptr);
-            if (prof) HCHECK(h, hipEventRecord(h->event(ne++), h->stream));
-            launch_fc(h, cur, count, gsize, nullptr);
-            if (prof) HCHECK(h, hipEventRecord(h->event(ne++), h->stream));
-            hipLaunchKernelGGL(k_env_step, dim3(count * gsize), dim3(256), 0, h->stream, E, (const int *)cur, gsize, tslimit);
-            if (prof) HCHECK(h, hipEventRecord(h->event(ne++), h->stream));
-            step_counts.push_back(count);
-            group_steps += count;
+        for (int st = 0; st < burst; st++) {
+            for (auto &s : subs) {
+                if (s.count == 0) continue;
+                std::array<size_t, 4> e{};
+                if (prof) { e[0] = ne++; HCHECK(h, hipEventRecord(h->event(e[0]), s.st)); }
+                launch_forward(h, s.cur, s.count, gsize, true, s.st);
+                if (prof) { e[1] = ne++; HCHECK(h, hipEventRecord(h->event(e[1]), s.st)); }
+                // the fc kernels of all sub-batches take turns on the HBM pipe: each one waits for the previous
+                // one (on another stream), which keeps the sub-batches in anti-phase -- conv / emulator work of
+                // one sub-batch always runs under the fc stream of the other
+                if (nsub > 1 && last_fc) HCHECK(h, hipStreamWaitEvent(s.st, last_fc, 0));
+                launch_fc(h, s.cur, s.count, gsize, nullptr, s.st);
+                if (nsub > 1) { last_fc = h->fc_ring[fc_ring_pos++ % h->fc_ring.size()]; HCHECK(h, hipEventRecord(last_fc, s.st)); }
+                if (prof) { e[2] = ne++; HCHECK(h, hipEventRecord(h->event(e[2]), s.st)); }
+                launch_env_step(h, E, s.cur, s.count, gsize, tslimit, s.st);
+                if (prof) { e[3] = ne++; HCHECK(h, hipEventRecord(h->event(e[3]), s.st)); evs.push_back(e); }
+                s.step_counts.push_back(s.count);
+                group_steps += s.count;
+            }
         }
         t += burst;
-        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, (const int32_t *)h->done, gsize, (const int *)cur,
-                           count, nxt, h->count_dev);
-        HCHECK(h, hipMemcpyAsync(&count, h->count_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HCHECK(h, hipStreamSynchronize(h->stream));
-        std::swap(cur, nxt);
+        for (auto &s : subs) {
+            if (s.count == 0) continue;
+            hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s.st, (const int32_t *)h->done, gsize, (const int *)s.cur,
+                               s.count, s.nxt, s.count_dev);
+            HCHECK(h, hipMemcpyAsync(&s.host_count, s.count_dev, sizeof(int), hipMemcpyDeviceToHost, s.st));
+        }
+        for (auto &s : subs) {
+            if (s.count == 0) continue;
+            HCHECK(h, hipStreamSynchronize(s.st));
+            s.count = s.host_count;
+            std::swap(s.cur, s.nxt);
+        }
     }
     HCHECK(h, hipGetLastError());
     HCHECK(h, hipEventRecord(h->ev_b, h->stream));
@@ -670,19 +745,18 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     dne_profile &P = h->prof;
     P.eval_ms = ms;
     P.fc_ms = P.conv_ms = P.env_ms = P.ref_ms = 0;
-    P.fc_launches = (int64_t)step_counts.size();
+    P.fc_launches = 0;
+    for (auto &s : subs) P.fc_launches += (int64_t)s.step_counts.size();
     P.fc_group_steps = group_steps;
     P.env_steps = 0;
     for (int i = 0; i < n; i++) P.env_steps += lengths[i];
     if (prof) {
         HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[0], h->ev_pool[1]));
         P.ref_ms = ms;
-        for (size_t s = 0; s < step_counts.size(); s++) {
-            const size_t e = 2 + 3 * s;
-            hipEvent_t before = e == 2 ? h->ev_pool[1] : h->ev_pool[e - 1];
-            HCHECK(h, hipEventElapsedTime(&ms, before, h->ev_pool[e])); P.conv_ms += ms;
-            HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e], h->ev_pool[e + 1])); P.fc_ms += ms;
-            HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e + 1], h->ev_pool[e + 2])); P.env_ms += ms;
+        for (auto &e : evs) {
+            HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e[0]], h->ev_pool[e[1]])); P.conv_ms += ms;
+            HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e[1]], h->ev_pool[e[2]])); P.fc_ms += ms;
+            HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e[2]], h->ev_pool[e[3]])); P.env_ms += ms;
         }
     }
     return 0;

@@ -24,6 +24,8 @@ enum : int {
     RM_HZA = 30, RM_DIR = 34, RM_LASTA = 38, RM_TICK = 39
 };
 
+constexpr int RAM_LIVE = 40;   // highest used RAM byte is RM_TICK = 39
+
 struct ResizeTables {   // Pillow precompute_coeffs output for 160->84 (h) and 210->84 (v)
     double kh[84 * 5];
     double kv[84 * 7];
@@ -40,7 +42,7 @@ __device__ __forceinline__ uint32_t ram_rand(uint8_t *ram) {
 }
 
 __device__ inline void synth_reset(uint8_t *ram, uint32_t seed) {
-    for (int i = 0; i < 128; i++) ram[i] = 0;
+    for (int i = 0; i < RAM_LIVE; i++) ram[i] = 0;   // bytes RAM_LIVE..127 of the 128-byte RAM are always zero
     uint32_t s = seed ^ 0x9E3779B9u;
     ram[RM_RNG] = s & 255; ram[RM_RNG + 1] = (s >> 8) & 255; ram[RM_RNG + 2] = (s >> 16) & 255; ram[RM_RNG + 3] = s >> 24;
     ram[RM_PX] = 76; ram[RM_LIVES] = 3; ram[RM_TEMP] = 45;
@@ -189,54 +191,114 @@ __device__ __forceinline__ int synth_pixel(const uint8_t *ram, int x, int y) {
     return (yo & 8) ? 15 : 5;
 }
 
-constexpr int ENV_BANDS = 3;            // output rows are produced in 3 bands of 28
-constexpr int ENV_BAND_ROWS = 28;
-constexpr int ENV_BAND_IN_MAX = 80;     // input rows a band can touch (70 + taps)
+// Screen rows fall into 45 static classes (HUD bands, sky, igloo block rows, shore, 4-row strips of the
+// water) inside which every row has identical pixels, except where the 16-row player sprite of the
+// previous / current frame overlaps.  Only one representative row per (class, player-in-prev,
+// player-in-cur) key is rendered and horizontally resized (~50 of 210 rows); the vertical pass reads
+// through the row -> slot map.  Identical rows give bit-identical results, so this is exact.
+constexpr int ENV_MAX_ROWS = 80;   // 45 classes + at most 3 extra keys for each of the <= 10 classes a sprite touches
+
+struct ResizeLds {      // PIL tables padded to a fixed tap count with zero weights (x + y*0.0 is exact)
+    double kh[84 * 5];
+    double kv[84 * 7];
+    uint8_t xmin[84];
+    uint8_t ymin[84];
+};
 
 struct EnvLds {
+    ResizeLds R;
     uint8_t ram_prev[128];
     uint8_t ram_cur[128];
-    uint8_t img[ENV_BAND_IN_MAX * 160];     // colour pair (prev<<4 | cur) per pixel of the band
-    float tmp[ENV_BAND_IN_MAX * 84];        // horizontally resized band (float32 like PIL's temp image)
+    uint8_t slot_of_y[212];
+    int slot_of_key[192];
+    int rep_y[ENV_MAX_ROWS];
+    uint8_t img[ENV_MAX_ROWS * 160];        // colour pair (prev<<4 | cur) per pixel of each unique row
+    float tmp[ENV_MAX_ROWS * 84];           // horizontally resized unique rows (float32 like PIL's temp image)
     float gray2[256];
     int misc[4];
 };
 
-// Render + warp max(prev, cur) and either shift it into the stack (fill == false) or fill all four
-// channels with it (fill == true, FrameStack reset).  Called by the whole 256-thread group.
-__device__ inline void synth_observe(EnvLds &s, const ResizeTables *__restrict__ T, uint32_t *__restrict__ stack, bool fill) {
+__device__ __forceinline__ int synth_row_class(int y) {
+    if (y < 8 || y >= 208) return 0;
+    if (y < 16) return 1;
+    if (y < 20) return 2;
+    if (y < 40) return 3;
+    if (y < 64) return 4 + ((63 - y) / 6) * 2 + (y >= 52);
+    if (y < 80) return 12;
+    return 13 + ((y - 80) >> 2);
+}
+
+__device__ __forceinline__ bool synth_player_row(const uint8_t *ram, int y) {
+    const int prow = ram[RM_PROW];
+    const int py = prow == 0 ? 62 : 48 + 32 * prow;
+    const bool blink = ram[RM_FREEZE] > 0 && (ram[RM_FC] & 4);
+    return !blink && (unsigned)(y - py) < 16u;
+}
+
+__device__ inline void synth_load_tables(EnvLds &s, const ResizeTables *__restrict__ T) {
     const int tid = threadIdx.x;
-    for (int band = 0; band < ENV_BANDS; band++) {
-        const int yy0 = band * ENV_BAND_ROWS;
-        const int y_lo = T->bv[yy0 * 2];
-        const int last = yy0 + ENV_BAND_ROWS - 1;
-        const int y_hi = T->bv[last * 2] + T->bv[last * 2 + 1];   // exclusive
-        const int rows = y_hi - y_lo;
-        __syncthreads();
-        for (int i = tid; i < rows * 160; i += 256) {
-            int y = y_lo + i / 160, x = i % 160;
-            s.img[i] = (uint8_t)((synth_pixel(s.ram_prev, x, y) << 4) | synth_pixel(s.ram_cur, x, y));
+    // fixed 5 / 7 taps per output: windows that would leave the frame are shifted back inside and their
+    // weights shifted with them, zero weights filling the rest (0 + x*0.0 and acc + x*0.0 are exact)
+    for (int i = tid; i < 84 * 5; i += 256) {
+        const int xx = i / 5, t = i % 5, x0 = T->bh[xx * 2];
+        const int d = x0 + 5 > 160 ? x0 + 5 - 160 : 0;
+        s.R.kh[i] = t >= d ? T->kh[xx * 5 + t - d] : 0.0;
+        if (t == 0) s.R.xmin[xx] = (uint8_t)(x0 - d);
+    }
+    for (int i = tid; i < 84 * 7; i += 256) {
+        const int yy = i / 7, t = i % 7, y0 = T->bv[yy * 2];
+        const int d = y0 + 7 > 210 ? y0 + 7 - 210 : 0;
+        s.R.kv[i] = t >= d ? T->kv[yy * 7 + t - d] : 0.0;
+        if (t == 0) s.R.ymin[yy] = (uint8_t)(y0 - d);
+    }
+    s.gray2[tid] = T->gray2[tid];
+}
+
+// Render + warp max(prev, cur) and either shift it into the stack (fill == false) or fill all four
+// channels with it (fill == true, FrameStack reset).  Called by the whole 256-thread group after
+// synth_load_tables and after ram_prev / ram_cur are in LDS.
+__device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bool fill) {
+    const int tid = threadIdx.x;
+    if (tid < 192) s.slot_of_key[tid] = -1;
+    if (tid == 0) s.misc[2] = 0;
+    __syncthreads();
+    int key = 0;
+    if (tid < 210) {
+        key = synth_row_class(tid) * 4 + (synth_player_row(s.ram_prev, tid) ? 2 : 0) + (synth_player_row(s.ram_cur, tid) ? 1 : 0);
+        if (atomicCAS(&s.slot_of_key[key], -1, -2) == -1) {     // first row of this key claims a slot
+            const int slot = atomicAdd(&s.misc[2], 1);
+            s.rep_y[slot] = tid;
+            s.slot_of_key[key] = slot;
         }
-        __syncthreads();
-        for (int i = tid; i < rows * 84; i += 256) {   // horizontal pass
-            int yl = i / 84, xx = i % 84;
-            int xmin = T->bh[xx * 2], n = T->bh[xx * 2 + 1];
-            const double *k = T->kh + xx * 5;
-            double acc = 0.0;
-            for (int t = 0; t < n; t++) acc = acc + (double)s.gray2[s.img[yl * 160 + xmin + t]] * k[t];
-            s.tmp[i] = (float)acc;
-        }
-        __syncthreads();
-        for (int i = tid; i < ENV_BAND_ROWS * 84; i += 256) {   // vertical pass + u8 truncation + stack shift
-            int yy = yy0 + i / 84, xx = i % 84;
-            int ymin = T->bv[yy * 2], n = T->bv[yy * 2 + 1];
-            const double *k = T->kv + yy * 7;
-            double acc = 0.0;
-            for (int t = 0; t < n; t++) acc = acc + (double)s.tmp[(ymin - y_lo + t) * 84 + xx] * k[t];
-            uint32_t pix = (uint32_t)(uint8_t)(float)acc;
-            uint32_t *p = stack + yy * 84 + xx;
-            *p = fill ? pix * 0x01010101u : ((*p >> 8) | (pix << 24));
-        }
+    }
+    __syncthreads();
+    if (tid < 210) s.slot_of_y[tid] = (uint8_t)s.slot_of_key[key];
+    const int nu = s.misc[2];
+    for (int i = tid; i < nu * 160; i += 256) {
+        const int y = s.rep_y[i / 160], x = i % 160;
+        s.img[i] = (uint8_t)((synth_pixel(s.ram_prev, x, y) << 4) | synth_pixel(s.ram_cur, x, y));
+    }
+    __syncthreads();
+    for (int i = tid; i < nu * 84; i += 256) {   // horizontal pass over the unique rows
+        const int u = i / 84, xx = i % 84;
+        const uint8_t *px = s.img + u * 160 + s.R.xmin[xx];
+        const double *k = s.R.kh + xx * 5;
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < 5; t++) acc = acc + (double)s.gray2[px[t]] * k[t];
+        s.tmp[i] = (float)acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < 84 * 84; i += 256) {   // vertical pass + u8 truncation + stack shift
+        const int yy = i / 84, xx = i % 84;
+        const uint8_t *sl = s.slot_of_y + s.R.ymin[yy];
+        const double *k = s.R.kv + yy * 7;
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < 7; t++) acc = acc + (double)s.tmp[sl[t] * 84 + xx] * k[t];
+        const uint32_t pix = (uint32_t)(uint8_t)(float)acc;
+        uint32_t *p = stack + i;
+        *p = fill ? pix * 0x01010101u : ((*p >> 8) | (pix << 24));
     }
 }
 

@@ -68,89 +68,95 @@ __device__ __forceinline__ Item decode_item(int b, const int *__restrict__ list,
 // ------------------------------------------------------------------------------------------ conv1
 // 8x8 stride 4 SAME(2,2) over the u8 [84][84][4] stack; /255 fused into the load through a 256-entry
 // table (exactly float32(u8)/255.0, atari_wrappers.py:186).  y1[row][441][16] raw (pre-BN).
+// GEMM view: [441 positions] x [256 = (kh,kw,ci)] x [16 co] on v_mfma_f32_16x16x4_f32, which is bitwise a
+// k-ordered fp32 fmaf chain -- the oracle's order.  The 4 k-values of one MFMA are the 4 stacked frames
+// (ci) of one tap, so lane (l>>4) extracts byte (l>>4) of the tap's dword.  Each wave keeps the whole
+// perturbed weight set as B fragments in 64 VGPRs and walks 7 of the 28 position tiles, two at a time
+// (two independent accumulators cover the 40-cycle dependent-MFMA latency).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict__ list, int gsize, int F, int member0,
                                                const uint8_t *__restrict__ stacks, const uint8_t *__restrict__ ref,
                                                float *__restrict__ y1) {
     const Item it = decode_item(blockIdx.x, list, gsize, F, member0, stacks, ref, A.done);
     if (it.skip) return;
-    __shared__ __attribute__((aligned(16))) float w_s[4096 + 16];
     __shared__ float lut[256];
     __shared__ uint32_t img[88 * 88];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, ci = lane >> 4;
     const float *base = A.bases + (size_t)A.m_slot[it.member] * A.base_stride + A.L.c1w;
     const float *eps = A.noise + A.m_off[it.member] + A.L.c1w;
     const float sc = A.m_scale[it.member];
-    for (int i = tid; i < 4096 + 16; i += 256) {
-        float v = sc * eps[i];
-        w_s[i] = base[i] + v;
+    float b[64];
+#pragma unroll
+    for (int kk = 0; kk < 64; kk++) {
+        float v = sc * eps[64 * kk + lane];
+        b[kk] = base[64 * kk + lane] + v;
     }
+    float pb = sc * eps[4096 + lp];
+    const float bias = base[4096 + lp] + pb;
     lut[tid] = (float)tid / 255.0f;
     for (int i = tid; i < 88 * 88; i += 256) {
         int y = i / 88 - 2, x = i % 88 - 2;
         img[i] = ((unsigned)y < 84u && (unsigned)x < 84u) ? ((const uint32_t *)it.ob)[y * 84 + x] : 0u;
     }
     __syncthreads();
-    if (tid >= 221) return;
-    const int p0 = 2 * tid, p1 = 2 * tid + 1;
-    const bool has1 = p1 < 441;
-    const int oy0 = p0 / 21, ox0 = p0 % 21;
-    const int oy1 = has1 ? p1 / 21 : oy0, ox1 = has1 ? p1 % 21 : ox0;
-    float a0[16], a1[16];
+    float *out = y1 + (size_t)it.row * 7056;
+    for (int j = 0; j < 8; j += 2) {
+        const int tA = wv + 4 * j, tB = wv + 4 * (j + 1);
+        const bool hasB = j + 1 < 7;
+        const int pA = min(tA * 16 + lp, 440), pB = hasB ? min(tB * 16 + lp, 440) : 0;
+        const int oA = (pA / 21) * 4 * 88 + (pA % 21) * 4, oB = (pB / 21) * 4 * 88 + (pB % 21) * 4;
+        f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 16; c++) { a0[c] = 0.0f; a1[c] = 0.0f; }
-    for (int kh = 0; kh < 8; kh++) {
-        for (int kw = 0; kw < 8; kw++) {
-            const uint32_t q0 = img[(oy0 * 4 + kh) * 88 + ox0 * 4 + kw];
-            const uint32_t q1 = img[(oy1 * 4 + kh) * 88 + ox1 * 4 + kw];
+        for (int kh = 0; kh < 8; kh++) {
 #pragma unroll
-            for (int ci = 0; ci < 4; ci++) {
-                const float x0 = lut[(q0 >> (8 * ci)) & 255u];
-                const float x1 = lut[(q1 >> (8 * ci)) & 255u];
-                const f4a *wk = (const f4a *)(w_s + ((kh * 8 + kw) * 4 + ci) * 16);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const f4a w = wk[q];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        a0[q * 4 + e] = __builtin_fmaf(x0, w[e], a0[q * 4 + e]);
-                        a1[q * 4 + e] = __builtin_fmaf(x1, w[e], a1[q * 4 + e]);
-                    }
-                }
+            for (int kw = 0; kw < 8; kw++) {
+                const float xA = lut[(img[oA + kh * 88 + kw] >> (8 * ci)) & 255u];
+                const float xB = lut[(img[oB + kh * 88 + kw] >> (8 * ci)) & 255u];
+                accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xA, b[kh * 8 + kw], accA, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xB, b[kh * 8 + kw], accB, 0, 0, 0);
             }
         }
-    }
-    float *o0 = y1 + ((size_t)it.row * 441 + p0) * 16;
 #pragma unroll
-    for (int c = 0; c < 16; c++) o0[c] = a0[c] + w_s[4096 + c];
-    if (has1) {
-#pragma unroll
-        for (int c = 0; c < 16; c++) o0[16 + c] = a1[c] + w_s[4096 + c];
+        for (int r = 0; r < 4; r++) {   // D[row = 4*(l>>4) + r][col = l&15]
+            const int posA = tA * 16 + ci * 4 + r, posB = tB * 16 + ci * 4 + r;
+            if (posA < 441) out[posA * 16 + lp] = accA[r] + bias;
+            if (hasB && posB < 441) out[posB * 16 + lp] = accB[r] + bias;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------ conv2
 // 4x4 stride 2 SAME(1,2); input = relu(bn1(y1)) formed while staging; y2[row][121][32] raw.
+// GEMM view [121 -> 128 positions] x [256 = (kh,kw,ci)] x [32 co] on the same fp32 MFMA: wave w owns
+// co tile (w & 1) and position tiles 4*(w>>1) .. +3 (4 independent accumulators); its B fragments (the
+// perturbed weights of 16 output channels) live in 64 VGPRs, A comes from the padded activation image in LDS.
 template <bool HAS_BN>
-__global__ __launch_bounds__(128) void k_conv2(FwdArgs A, const int *__restrict__ list, int gsize, int F, int member0,
+__global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict__ list, int gsize, int F, int member0,
                                                const float *__restrict__ y1, float *__restrict__ y2) {
     const Item it = decode_item(blockIdx.x, list, gsize, F, member0, nullptr, nullptr, A.done);
     if (it.skip) return;
     constexpr int PS = 17;   // LDS pixel stride (16 channels + 1 pad)
-    __shared__ __attribute__((aligned(16))) float w_s[8192 + 32];
     __shared__ float a_s[24 * 24 * PS];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
+    const int nt = wv & 1, mt0 = 4 * (wv >> 1);
     const float *base = A.bases + (size_t)A.m_slot[it.member] * A.base_stride + A.L.c2w;
     const float *eps = A.noise + A.m_off[it.member] + A.L.c2w;
     const float sc = A.m_scale[it.member];
-    for (int i = tid; i < 8192 + 32; i += 128) {
-        float v = sc * eps[i];
-        w_s[i] = base[i] + v;
+    for (int i = tid; i < 24 * 24 * PS; i += 256) a_s[i] = 0.0f;
+    float b[64];
+#pragma unroll
+    for (int kk = 0; kk < 64; kk++) {
+        const int o = (4 * kk + lk) * 32 + nt * 16 + lp;
+        float v = sc * eps[o];
+        b[kk] = base[o] + v;
     }
-    for (int i = tid; i < 24 * 24 * PS; i += 128) a_s[i] = 0.0f;
+    float pb = sc * eps[8192 + nt * 16 + lp];
+    const float bias = base[8192 + nt * 16 + lp] + pb;
     __syncthreads();
     const float *bn = A.bn + (size_t)it.member * 608;
     const float *src = y1 + (size_t)it.row * 7056;
-    for (int i = tid; i < 7056; i += 128) {
+    for (int i = tid; i < 7056; i += 256) {
         const int c = i & 15, pix = i >> 4;
         float t = src[i];
         if (HAS_BN) {
@@ -161,42 +167,37 @@ __global__ __launch_bounds__(128) void k_conv2(FwdArgs A, const int *__restrict_
         a_s[((pix / 21 + 1) * 24 + pix % 21 + 1) * PS + c] = t;
     }
     __syncthreads();
-    if (tid >= 122) return;
-    const int half = tid & 1, pp = tid >> 1;          // positions pp and pp + 61 (61 = 121 - 60), 16 channels each
-    const int p0 = pp, p1 = pp + 61;
-    const bool has1 = p1 < 121;
-    const int oy0 = p0 / 11, ox0 = p0 % 11;
-    const int oy1 = has1 ? p1 / 11 : oy0, ox1 = has1 ? p1 % 11 : ox0;
-    float a0[16], a1[16];
+    int off[4];
+    f32x4 acc[4];
 #pragma unroll
-    for (int c = 0; c < 16; c++) { a0[c] = 0.0f; a1[c] = 0.0f; }
+    for (int m = 0; m < 4; m++) {
+        const int p = min((mt0 + m) * 16 + lp, 120);
+        off[m] = ((p / 11) * 2 * 24 + (p % 11) * 2) * PS + lk;
+        acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
     for (int kh = 0; kh < 4; kh++) {
+#pragma unroll
         for (int kw = 0; kw < 4; kw++) {
-            const float *x0p = a_s + ((oy0 * 2 + kh) * 24 + ox0 * 2 + kw) * PS;
-            const float *x1p = a_s + ((oy1 * 2 + kh) * 24 + ox1 * 2 + kw) * PS;
-#pragma unroll 4
-            for (int ci = 0; ci < 16; ci++) {
-                const float x0 = x0p[ci], x1 = x1p[ci];
-                const f4a *wk = (const f4a *)(w_s + ((kh * 4 + kw) * 16 + ci) * 32 + half * 16);
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const f4a w = wk[q];
+            for (int c4 = 0; c4 < 4; c4++) {   // k = (kh*4+kw)*16 + c4*4 + (l>>4)
+                const int kk = (kh * 4 + kw) * 4 + c4;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        a0[q * 4 + e] = __builtin_fmaf(x0, w[e], a0[q * 4 + e]);
-                        a1[q * 4 + e] = __builtin_fmaf(x1, w[e], a1[q * 4 + e]);
-                    }
+                for (int m = 0; m < 4; m++) {
+                    const float x = a_s[off[m] + (kh * 24 + kw) * PS + c4 * 4];
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, b[kk], acc[m], 0, 0, 0);
                 }
             }
         }
     }
     float *o = y2 + (size_t)it.row * 3872;
 #pragma unroll
-    for (int c = 0; c < 16; c++) o[p0 * 32 + half * 16 + c] = a0[c] + w_s[8192 + half * 16 + c];
-    if (has1) {
+    for (int m = 0; m < 4; m++)
 #pragma unroll
-        for (int c = 0; c < 16; c++) o[p1 * 32 + half * 16 + c] = a1[c] + w_s[8192 + half * 16 + c];
-    }
+        for (int r = 0; r < 4; r++) {   // D[row = 4*(l>>4) + r][col = l&15]
+            const int pos = (mt0 + m) * 16 + lk * 4 + r;
+            if (pos < 121) o[pos * 32 + nt * 16 + lp] = acc[m][r] + bias;
+        }
 }
 
 // ------------------------------------------------------------------------- fc (+ out + argmax)
@@ -220,6 +221,10 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
     __shared__ float lg[SHARED_W ? 1 : NV][32];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const Layout &L = A.L;
+    // step mode is persistent: a bounded grid walks the active groups, so the kernel occupies only a slice of
+    // every CU (it is HBM-bound and needs few waves) and leaves room for the conv / emulator kernels that
+    // run concurrently on the other sub-batch streams.  Reference mode launches one block per work item.
+    for (int item = blockIdx.x; item < (SHARED_W ? (int)blockIdx.x + 1 : n_local); item += gridDim.x) {
     int member[NV], row[NV];
     float scale[NV];
     if (SHARED_W) {   // reference mode: blocks of one member stay on one XCD (block b runs on XCD b % 8)
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
 #pragma unroll
         for (int v = 0; v < NV; v++) { member[v] = member0 + mloc; row[v] = mloc * F + fg * NV + v; }
     } else {
-        const int g = list ? list[blockIdx.x] : blockIdx.x;
+        const int g = list ? list[item] : item;
 #pragma unroll
         for (int v = 0; v < NV; v++) { member[v] = g * NV + v; row[v] = member[v]; }
     }
@@ -253,51 +258,78 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
 #pragma unroll
         for (int e = 0; e < 4; e++) acc[v][e] = 0.0f;
 
+    // 968 rows per slice = 121 batches of 8 rows; batch b+1 is in flight while batch b is consumed.
+    // Activations arrive in 64-row chunks (one VGPR per vector), the next chunk prefetched a chunk ahead.
     const int kbeg = 968 * wv;
-    for (int c = 0; c < 16; c++) {
-        const int k0 = kbeg + 64 * c;
+    auto load_x = [&](int c, float (&dst)[NV]) {
         const int nr = c < 15 ? 64 : 8;
-        float xv[NV];
 #pragma unroll
         for (int v = 0; v < NV; v++) {
             float t = 0.0f;
-            if (lane < nr) {
-                t = y2[(size_t)row[v] * 3872 + k0 + lane];
+            if (c < 16 && lane < nr) {
+                t = y2[(size_t)row[v] * 3872 + kbeg + 64 * c + lane];
                 if (HAS_BN) {
                     t = t * s2[v];
                     t = t + h2[v];
                 }
                 t = t > 0.0f ? t : 0.0f;
             }
-            xv[v] = t;
+            dst[v] = t;
         }
-#pragma unroll 8
-        for (int i = 0; i < nr; i++) {
-            const size_t ro = (size_t)(k0 + i) * 256;
-            const f4u e = *(const f4u *)(eps + ro);
-            const f4a t = *(const f4a *)(th + ro);
+    };
+    constexpr int RB = 8;
+    f4u e_cur[RB], e_nxt[RB];
+    f4a t_cur[RB], t_nxt[RB];
+    float xv[NV], xn[NV];
+    load_x(0, xv);
+    load_x(1, xn);
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+        const size_t ro = (size_t)(kbeg + i) * 256;
+        e_cur[i] = *(const f4u *)(eps + ro);
+        t_cur[i] = *(const f4a *)(th + ro);
+    }
+    for (int bt = 0; bt < 121; bt++) {
+        if (bt + 1 < 121) {
+#pragma unroll
+            for (int i = 0; i < RB; i++) {
+                const size_t ro = (size_t)(kbeg + (bt + 1) * RB + i) * 256;
+                e_nxt[i] = *(const f4u *)(eps + ro);
+                t_nxt[i] = *(const f4a *)(th + ro);
+            }
+        }
+        const int li = (bt & 7) * RB;
+#pragma unroll
+        for (int i = 0; i < RB; i++) {
             if (SHARED_W) {
                 f4a w;
 #pragma unroll
-                for (int q = 0; q < 4; q++) { float pv = scale[0] * e[q]; w[q] = t[q] + pv; }
+                for (int q = 0; q < 4; q++) { float pv = scale[0] * e_cur[i][q]; w[q] = t_cur[i][q] + pv; }
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
-                    const float x = lane_bcast(xv[v], i);
+                    const float x = lane_bcast(xv[v], li + i);
 #pragma unroll
                     for (int q = 0; q < 4; q++) acc[v][q] = __builtin_fmaf(x, w[q], acc[v][q]);
                 }
             } else {
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
-                    const float x = lane_bcast(xv[v], i);
+                    const float x = lane_bcast(xv[v], li + i);
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        float pv = scale[v] * e[q];
-                        float w = t[q] + pv;
+                        float pv = scale[v] * e_cur[i][q];
+                        float w = t_cur[i][q] + pv;
                         acc[v][q] = __builtin_fmaf(x, w, acc[v][q]);
                     }
                 }
             }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; i++) { e_cur[i] = e_nxt[i]; t_cur[i] = t_nxt[i]; }
+        if ((bt & 7) == 7) {   // chunk boundary: rotate the activation registers, prefetch the chunk after next
+#pragma unroll
+            for (int v = 0; v < NV; v++) xv[v] = xn[v];
+            load_x((bt >> 3) + 2, xn);
         }
     }
 #pragma unroll
@@ -350,6 +382,8 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
         actions[member[v]] = best;
         if (logits_out)
             for (int a = 0; a < nact; a++) logits_out[(size_t)member[v] * nact + a] = lg[v][a];
+    }
+    __syncthreads();   // LDS is reused by the next group
     }
 }
 
