@@ -97,7 +97,7 @@ __device__ inline int synth_frame(uint8_t *ram, int a) {
                     if (level < 255) level++;
                     ram[RM_LEVEL] = level; ram[RM_IGLOO] = 0; ram[RM_TEMP] = 45; ram[RM_TICK] = 0;
                     for (int r = 0; r < 4; r++) { ram[RM_VIS + r] = 0; ram[RM_HZA + r] = 0; }
-                    prow = 0; px = 76; ram[RM_FREEZE] = 16;
+                    prow = 0; px = 76; ram[RM_FREEZE] = 64;
                 }
             } else if (tgt <= 4) {
                 prow = tgt;
@@ -138,7 +138,7 @@ __device__ inline int synth_frame(uint8_t *ram, int a) {
     }
     if (died) {
         if (ram[RM_LIVES] == 0) ram[RM_OVER] = 1; else ram[RM_LIVES]--;
-        ram[RM_PROW] = 0; ram[RM_PX] = 76; ram[RM_FREEZE] = 32; ram[RM_COOL] = 0;
+        ram[RM_PROW] = 0; ram[RM_PX] = 76; ram[RM_FREEZE] = 128; ram[RM_COOL] = 0;
         ram[RM_HZA] = ram[RM_HZA + 1] = ram[RM_HZA + 2] = ram[RM_HZA + 3] = 0;
         if (ram[RM_TEMP] == 0) ram[RM_TEMP] = 45;
     }

@@ -357,7 +357,7 @@ int orc_raw_frame(uint8_t *ram, int a) {
                     ram[R_TICK] = 0;
                     prow = 0;
                     px = 76;
-                    ram[R_FREEZE] = 16;
+                    ram[R_FREEZE] = 64;
                 }
             } else if (tgt <= 4) {
                 prow = tgt;
@@ -408,7 +408,7 @@ int orc_raw_frame(uint8_t *ram, int a) {
         else ram[R_LIVES]--;
         ram[R_PROW] = 0;
         ram[R_PX] = 76;
-        ram[R_FREEZE] = 32;
+        ram[R_FREEZE] = 128; /* death sequence, about two seconds as in the real game */
         ram[R_COOL] = 0;
         for (int r = 0; r < 4; r++) ram[R_HZA + r] = 0;
         if (ram[R_TEMP] == 0) ram[R_TEMP] = 45;

@@ -1,0 +1,105 @@
+"""TEST-ONLY adapter: the CPU oracle behind the Engine method surface of dne_hip._lib, so that the host-side
+logic (drivers, in-process transport, sharding, all-gather) can be exercised without a GPU.  Lives under
+tests/ because only tests may call the oracle; the product never imports this."""
+import numpy as np
+
+import oracle as O
+
+
+class OracleEngine:
+    def __init__(self, kind, n_actions=18, max_members=64, ref_count=16, **kw):
+        self.kind, self.n_actions, self.max_members, self.ref_count = kind, n_actions, max_members, ref_count
+        self.L = O.layout(kind, n_actions)
+        self.P = self.L.P
+        self.bc_max_steps = kw.get("bc_max_steps", 0)
+        self.theta = np.zeros(self.P, np.float32)
+        self.noise = None
+        self.ref = None
+        self.opt = None
+        self.envs = [O.WrappedEnv() for _ in range(4)]
+        self.members = None
+        self.calls = []
+
+    def close(self):
+        pass
+
+    def noise_upload(self, noise):
+        self.noise = np.ascontiguousarray(noise, np.float32)
+
+    def set_theta(self, theta, slot=0):
+        assert slot == 0
+        self.theta = np.array(theta, np.float32)
+
+    def get_theta(self, slot=0):
+        return self.theta.copy()
+
+    def set_ref_batch(self, ref):
+        self.ref = np.ascontiguousarray(ref, np.uint8)
+
+    def optimizer_reset(self):
+        self.opt = None
+
+    def set_members(self, slot, off, scale):
+        self.members = (np.asarray(slot), np.asarray(off), np.asarray(scale, np.float32))
+
+    def _member_theta(self, i):
+        slot, off, scale = self.members
+        return self.theta + np.float32(scale[i]) * self.noise[off[i]:off[i] + self.P]
+
+    def es_eval(self, idx, sigma, tslimit, seeds, want_bc=False):
+        self.calls.append(("es_eval", len(idx)))
+        return O.es_eval(self.L, self.theta, self.noise, idx, sigma, tslimit, self.ref, seeds)
+
+    def eval_members(self, n, tslimit, seeds, want_bc=False):
+        out = [O.rollout(self.L, self._member_theta(i), self.ref, seeds[i], tslimit)[:3] for i in range(n)]
+        r, s, l = zip(*out)
+        return np.array(r, np.float32), np.array(s, np.float32), np.array(l, np.int32)
+
+    def es_update(self, idx, returns_n2, signreturns_n2, proc_mode, opt_kind, l2coeff, stepsize,
+                  beta1_or_momentum=0.9, beta2=0.999, epsilon=1e-8):
+        self.calls.append(("es_update", len(idx)))
+        rets = np.asarray(returns_n2, np.float32).reshape(-1, 2)
+        if proc_mode == "centered_rank":
+            proc = O.centered_ranks(rets.reshape(-1)).reshape(-1, 2)
+        elif proc_mode == "sign":
+            proc = np.asarray(signreturns_n2, np.float32).reshape(-1, 2)
+        else:
+            proc = O.centered_ranks(np.asarray(signreturns_n2, np.float32).reshape(-1)).reshape(-1, 2)
+        g = O.weighted_sum(self.noise, idx, proc[:, 0] - proc[:, 1], self.P, float(rets.size))
+        if self.opt is None:
+            self.opt = (O.Adam(self.theta, stepsize, beta1_or_momentum, beta2, epsilon) if opt_kind == "adam"
+                        else O.SGD(self.theta, stepsize, beta1_or_momentum))
+        self.opt.theta = self.theta.copy()
+        ratio, th = self.opt.update(g, l2coeff)
+        self.theta = th.copy()
+        return ratio
+
+    # single-env ABI (slot 0) used by HipAtariEnv / Policy.rollout
+    def env_reset(self, seeds):
+        for e, s in zip(self.envs, seeds):
+            e.reset(int(s))
+
+    def env_step(self, actions):
+        out = [self.envs[i].step(int(a)) for i, a in enumerate(np.atleast_1d(actions))]
+        return np.array([o[1] for o in out], np.float32), np.array([o[2] for o in out], bool)
+
+    def env_observation(self, n):
+        return np.stack([self.envs[i].ob() for i in range(n)])
+
+    def env_ram(self, n):
+        return np.stack([self.envs[i].ram() for i in range(n)])
+
+    def env_set_observation(self, obs):
+        self._obs = np.asarray(obs, np.uint8)
+
+    def ref_pass(self, n):
+        self._bn = [O.es_ref_pass(self.L, self._member_theta(i), self.ref) for i in range(n)] if self.kind == O.KIND_ES else [None] * n
+
+    def act(self, n):
+        acts, lgs = [], []
+        for i in range(n):
+            ob = self._obs[i] if getattr(self, "_obs", None) is not None else self.envs[i].ob()
+            a, lg = O.act(self.L, self._member_theta(i), self._bn[i] if self.kind == O.KIND_ES else None, ob)
+            acts.append(a); lgs.append(lg)
+        self._obs = None
+        return np.array(acts, np.int32), np.stack(lgs)

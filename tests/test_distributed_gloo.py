@@ -1,0 +1,81 @@
+"""CPU, world_size 2 over gloo: the N > 1 path (shard pairs round-robin -> evaluate -> all-gather 32-byte
+records -> redundant update) leaves bit-identical theta on every rank, equal to a serial emulation."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_PAIRS, TSLIMIT, GENS, NOISE = 6, 10, 2, 2_500_000
+OPT = {"type": "adam", "args": {"stepsize": 0.01}}
+
+
+def _config():
+    from dne_hip import es
+    return es.Config(l2coeff=0.005, noise_stdev=0.02, episodes_per_batch=2 * N_PAIRS, timesteps_per_batch=10,
+                     calc_obstat_prob=0.0, eval_prob=0.0, snapshot_freq=0, return_proc_mode="centered_rank",
+                     episode_cutoff_mode=TSLIMIT)
+
+
+def _make_engine():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    from oracle_engine import OracleEngine
+    from dne_hip import policies
+    eng = OracleEngine(0, ref_count=16)
+    eng.noise_upload(np.random.RandomState(123).randn(NOISE).astype(np.float32))
+    eng.set_theta(policies.xavier_flat(18, 0))
+    eng.set_ref_batch(O.get_ref_batch(seed=0, batch_size=16))
+    return eng
+
+
+def _rank_main(rank, world, port, q):
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "deep-neuroevolution_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from dne_hip import es
+    eng = _make_engine()
+    recs = []
+    for g in range(GENS):
+        rec, ratio = es.es_generation(eng, NOISE, _config(), N_PAIRS, g, TSLIMIT, OPT, rank, world)
+        recs.append(rec.tobytes())
+    q.put((rank, eng.get_theta().tobytes(), recs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_gloo_bit_identical():
+    import torch.multiprocessing as mp
+    from dne_hip import es
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=500) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, th0, rec0), (_, th1, rec1) = out
+    assert th0 == th1 and rec0 == rec1                      # every rank holds the same theta and the same records
+    # serial emulation: one engine evaluates both shards, merges in global pair order, updates once
+    eng = _make_engine()
+    cfg = _config()
+    for g in range(GENS):
+        full = np.zeros(N_PAIRS, es.RECORD)
+        for r in range(2):
+            mine, idx, seeds = es.generation_inputs(NOISE, eng.P, N_PAIRS, g, r, 2)
+            ret, sg, ln = eng.es_eval(idx, cfg.noise_stdev, TSLIMIT, seeds)
+            full[mine] = es.pack_records(idx, ret, ln, sg)
+        assert full.tobytes() == rec0[g]
+        eng.es_update(full["noise_idx"], full["ret"], full["aux"], "centered_rank", "adam", cfg.l2coeff, 0.01)
+    assert eng.get_theta().tobytes() == th0
+    rec = np.frombuffer(rec0[-1], es.RECORD)
+    assert rec["len"].min() >= 1 and rec["len"].max() <= TSLIMIT and rec["ret"].dtype == np.float32
