@@ -42,7 +42,9 @@ EXP = {
 def cpu_baseline(noise, theta, ref, sigma, tslimit, n_actions):
     """The CPU oracle, structured like the reference workers (one single-threaded process per core, one
     antithetic pair at a time, batch-1 forwards, a reference pass per episode: es.py:366-439, launch.py:117),
-    timed on a bounded sample of generation 0 of the same workload.  Checker only -- never the product path."""
+    timed on a bounded sample of generation 0 of the same workload.  Checker only -- never the product path.
+    The reference's workers never idle (they loop over tasks), so the rate is steps per busy core-second
+    times the core count: sum(steps) / (sum(worker busy seconds) / cores)."""
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
@@ -50,18 +52,20 @@ def cpu_baseline(noise, theta, ref, sigma, tslimit, n_actions):
     cores = os.cpu_count() or 1
     from dne_hip import es
     _, idx, seeds = es.generation_inputs(noise.size, theta.size, 2500, 0, 0, 1)
-    n = cores  # one pair per worker process
+    n = min(2 * cores, 2500)
     global _BASE
     _BASE = (noise, theta, ref, sigma, tslimit, n_actions, idx, seeds)
     ctx = mp.get_context("fork")
     t0 = time.time()
     with ctx.Pool(cores) as pool:
-        lens = pool.map(_cpu_pair, range(n), chunksize=1)
+        res = pool.map(_cpu_pair, range(n), chunksize=1)
     wall = time.time() - t0
-    steps = int(sum(lens))
-    return {"value": steps / wall, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "generation 0, first %d antithetic pairs (%d full episodes, %d env-steps), one pair per "
-                      "single-threaded worker process, %.1f s wall" % (n, 2 * n, steps, wall)}
+    steps = int(sum(r[0] for r in res))
+    busy = float(sum(r[1] for r in res))
+    return {"value": steps / (busy / cores), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "generation 0, first %d antithetic pairs (%d full episodes, %d env-steps) over %d single-threaded "
+                      "worker processes; %.1f busy core-seconds, %.1f s wall (wall-clock rate incl. stragglers and "
+                      "process start-up: %.0f steps/s)" % (n, 2 * n, steps, cores, busy, wall, steps / wall)}
 
 
 def _cpu_pair(i):
@@ -69,8 +73,23 @@ def _cpu_pair(i):
     import oracle as O
     noise, theta, ref, sigma, tslimit, n_actions, idx, seeds = _BASE
     L = O.layout(O.KIND_ES, n_actions)
+    t0 = time.time()
     _, _, ln = O.es_eval(L, theta, noise, idx[i:i + 1], sigma, tslimit, ref, seeds[2 * i:2 * i + 2])
-    return int(ln.sum())
+    return int(ln.sum()), time.time() - t0
+
+
+def _pmc_traffic(units_per_launch):
+    """HBM bytes per launch of the fc kernel from the committed rocprofv3 PMC passes (profiles/r01_pmc.json:
+    FETCH_SIZE doubled for the 16-byte streaming loads as MI355X_MICROARCH.md prescribes, plus WRITE_SIZE),
+    measured per unit at full width and scaled to this run's units per launch.  None if no profile is committed."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        per_unit = json.load(open(p))["k_fc_step"]["hbm_bytes_per_unit"]
+        return per_unit * units_per_launch
+    except Exception:
+        return None
 
 
 def main():
@@ -173,7 +192,7 @@ def main():
             out["roofline"] = {
                 "bound": "hbm", "kernel": "dne::k_fc<2,false,true> (streaming fc + bn + out + argmax)",
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                "traffic": None,
+                "traffic": _pmc_traffic(units_per_launch),
                 "algorithmic_bytes_per_unit": ALG_BYTES_PER_ENV_STEP, "unit_def": "one env-step of one member",
                 "units_per_launch": units_per_launch, "avg_launch_ms": avg_ms, "launches": int(fc_launches),
                 "note": "antithetic pairs share one read of their noise slice, so HBM traffic per unit is below the "

@@ -705,11 +705,11 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 std::array<size_t, 4> e{};
                 if (prof) { e[0] = ne++; HCHECK(h, hipEventRecord(h->event(e[0]), s.st)); }
                 launch_forward(h, s.cur, s.count, gsize, true, s.st);
-                if (prof) { e[1] = ne++; HCHECK(h, hipEventRecord(h->event(e[1]), s.st)); }
                 // the fc kernels of all sub-batches take turns on the HBM pipe: each one waits for the previous
                 // one (on another stream), which keeps the sub-batches in anti-phase -- conv / emulator work of
                 // one sub-batch always runs under the fc stream of the other
                 if (nsub > 1 && last_fc) HCHECK(h, hipStreamWaitEvent(s.st, last_fc, 0));
+                if (prof) { e[1] = ne++; HCHECK(h, hipEventRecord(h->event(e[1]), s.st)); }   // after the wait: brackets fc only
                 launch_fc(h, s.cur, s.count, gsize, nullptr, s.st);
                 if (nsub > 1) { last_fc = h->fc_ring[fc_ring_pos++ % h->fc_ring.size()]; HCHECK(h, hipEventRecord(last_fc, s.st)); }
                 if (prof) { e[2] = ne++; HCHECK(h, hipEventRecord(h->event(e[2]), s.st)); }
