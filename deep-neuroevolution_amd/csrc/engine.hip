@@ -34,7 +34,7 @@ static thread_local std::string g_create_error;
 struct EnvArgs {
     uint8_t *ram_prev, *ram_cur;     // [M][128]
     uint8_t *stacks;                 // [M][84][84][4]
-    const ResizeTables *T;
+    const ResizeLds *T;
     float *ret, *sign, *step_reward; // [M]
     int32_t *len, *done, *stepped;
     const int32_t *action;
@@ -169,7 +169,7 @@ struct dne_handle {
     std::string err;
     hipStream_t stream = nullptr;
     std::vector<hipStream_t> sub_streams;   // sub-batch streams (sub_streams[0] == stream)
-    int nsub = 2, sub_min_groups = 256, fc_grid = 256;
+    int nsub = 2, sub_min_groups = 256, fc_grid = 256, fc_tail_max = 96;
     int M = 0, F = 0, ref_chunk = 0;
     size_t base_stride = 0;
     // device memory
@@ -181,7 +181,7 @@ struct dne_handle {
     int32_t *m_slot = nullptr; int64_t *m_off = nullptr; float *m_scale = nullptr;
     float *bn = nullptr;
     uint8_t *ram_prev = nullptr, *ram_cur = nullptr, *stacks = nullptr;
-    ResizeTables *tables = nullptr;
+    ResizeLds *tables = nullptr;
     float *ret = nullptr, *sign = nullptr, *step_reward = nullptr, *logits = nullptr;
     int32_t *len = nullptr, *done = nullptr, *action = nullptr, *stepped = nullptr;
     uint32_t *seeds = nullptr;
@@ -285,9 +285,24 @@ static const uint8_t kPalette[16][3] = {
     {236, 236, 236}, {84, 138, 210},  {198, 108, 58},  {181, 83, 40},  {192, 192, 192}, {252, 252, 84},
     {92, 186, 92},   {74, 74, 74},    {252, 144, 144}, {0, 44, 160}};
 
-static void make_tables(ResizeTables *T) {
-    pil_coeffs(160, 84, 5, T->bh, T->kh);
-    pil_coeffs(210, 84, 7, T->bv, T->kv);
+static void make_tables(ResizeLds *T) {
+    // Fixed 5 / 7 taps per output pixel: windows that would leave the frame are shifted back inside and their
+    // weights shifted with them, zero weights filling the rest (0 + x*0.0 and acc + x*0.0 are exact no-ops).
+    double kh[84 * 5], kv[84 * 7];
+    int bh[84 * 2], bv[84 * 2];
+    pil_coeffs(160, 84, 5, bh, kh);
+    pil_coeffs(210, 84, 7, bv, kv);
+    memset(T, 0, sizeof(*T));
+    for (int xx = 0; xx < 84; xx++) {
+        const int x0 = bh[2 * xx], d = x0 + 5 > 160 ? x0 + 5 - 160 : 0;
+        T->xmin[xx] = (uint8_t)(x0 - d);
+        for (int t = 0; t < 5; t++) T->kh[xx * 5 + t] = t >= d ? kh[xx * 5 + t - d] : 0.0;
+    }
+    for (int yy = 0; yy < 84; yy++) {
+        const int y0 = bv[2 * yy], d = y0 + 7 > 210 ? y0 + 7 - 210 : 0;
+        T->ymin[yy] = (uint8_t)(y0 - d);
+        for (int t = 0; t < 7; t++) T->kv[yy * 7 + t] = t >= d ? kv[yy * 7 + t - d] : 0.0;
+    }
     for (int a = 0; a < 16; a++)
         for (int b = 0; b < 16; b++) {   // MaxAndSkip max (atari_wrappers.py:105) then WarpFrame gray (:139)
             const uint8_t r = std::max(kPalette[a][0], kPalette[b][0]);
@@ -348,6 +363,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipStreamCreate(&h->stream));
     h->sub_streams.push_back(h->stream);
     if (const char *e = getenv("DNE_NSUB")) h->nsub = std::max(1, std::min(8, atoi(e)));
+    if (const char *e = getenv("DNE_FC_TAIL_MAX")) h->fc_tail_max = std::max(0, atoi(e));
     if (const char *e = getenv("DNE_FC_GRID")) h->fc_grid = std::max(1, atoi(e));
     if (const char *e = getenv("DNE_SUB_MIN_GROUPS")) h->sub_min_groups = std::max(1, atoi(e));
     for (int s = 1; s < h->nsub; s++) { hipStream_t st; CH(hipStreamCreate(&st)); h->sub_streams.push_back(st); }
@@ -373,7 +389,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipMemset(h->stacks, 0, M * OB_BYTES));
     CH(dalloc(&h->tables, 1));
     {
-        ResizeTables T;
+        ResizeLds T;
         make_tables(&T);
         CH(hipMemcpy(h->tables, &T, sizeof(T), hipMemcpyHostToDevice));
     }
@@ -627,6 +643,17 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
     if (!st) st = h->stream;
     const FwdArgs A = h->fwd(false);
     const bool es = h->L.kind == DNE_KIND_ES;
+    if (count <= h->fc_tail_max) {   // latency-bound regime: 4 workgroups per group + a separate output-layer kernel
+#define FCT(NV, BN)                                                                                                          \
+    do {                                                                                                                     \
+        hipLaunchKernelGGL((k_fc_cols<NV, BN>), dim3(count * 4), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3);    \
+        hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(64), 0, st, A, list, (const float *)h->y3, h->action, logits); \
+    } while (0)
+        if (gsize == 2) { if (es) FCT(2, true); else FCT(2, false); }
+        else { if (es) FCT(1, true); else FCT(1, false); }
+#undef FCT
+        return;
+    }
 #define FC(NV, BN) hipLaunchKernelGGL((k_fc<NV, false, BN>), dim3(std::min(count, h->fc_grid)), dim3(256), 0, st, A, list, count, 1, 0, (const float *)h->y2, h->y3, h->action, logits)
     if (gsize == 2) { if (es) FC(2, true); else FC(2, false); }
     else { if (es) FC(1, true); else FC(1, false); }

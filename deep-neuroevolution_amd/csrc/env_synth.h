@@ -26,14 +26,6 @@ enum : int {
 
 constexpr int RAM_LIVE = 40;   // highest used RAM byte is RM_TICK = 39
 
-struct ResizeTables {   // Pillow precompute_coeffs output for 160->84 (h) and 210->84 (v)
-    double kh[84 * 5];
-    double kv[84 * 7];
-    int bh[84 * 2];
-    int bv[84 * 2];
-    float gray2[256];   // gray(max(rgb[a], rgb[b])) for colour pair (a<<4)|b
-};
-
 __device__ __forceinline__ uint32_t ram_rand(uint8_t *ram) {
     uint32_t s = ram[RM_RNG] | (ram[RM_RNG + 1] << 8) | (ram[RM_RNG + 2] << 16) | ((uint32_t)ram[RM_RNG + 3] << 24);
     s = s * 1664525u + 1013904223u;
@@ -150,43 +142,67 @@ __device__ inline int synth_frame(uint8_t *ram, int a) {
     return reward;
 }
 
-// palette index of screen pixel (x, y) for a RAM snapshot
-__device__ __forceinline__ int synth_pixel(const uint8_t *ram, int x, int y) {
-    const int prow = ram[RM_PROW], px = ram[RM_PX];
-    const int py = prow == 0 ? 62 : 48 + 32 * prow;
-    const bool blink = ram[RM_FREEZE] > 0 && (ram[RM_FC] & 4);
-    if (!blink && (unsigned)(y - py) < 16u && ((x - px + 160) % 160) < 8) return 8;
+// Everything the renderer needs from one RAM snapshot, unpacked once per thread into registers
+// (per-row fields stay packed four-to-a-dword and are selected with a shift).
+struct PixState {
+    int px, py, temp2, lives10, score, igloo, sky;
+    uint32_t off4, vis4, hzx4, hza4;
+    bool blink;
+};
+
+__device__ __forceinline__ PixState synth_pix_state(const uint8_t *ram) {
+    PixState p;
+    const int prow = ram[RM_PROW];
+    p.px = ram[RM_PX];
+    p.py = prow == 0 ? 62 : 48 + 32 * prow;
+    p.blink = ram[RM_FREEZE] > 0 && (ram[RM_FC] & 4);
+    p.temp2 = 8 + 2 * ram[RM_TEMP];
+    p.lives10 = 10 * ram[RM_LIVES];
+    p.score = ram[RM_SCORE] | (ram[RM_SCORE + 1] << 8);
+    p.igloo = ram[RM_IGLOO];
+    p.sky = (ram[RM_LEVEL] & 1) ? 3 : 2;
+    p.off4 = *(const uint32_t *)(ram + RM_OFF);
+    p.vis4 = *(const uint32_t *)(ram + RM_VIS);
+    p.hzx4 = ram[RM_HZX] | (ram[RM_HZX + 1] << 8) | (ram[RM_HZX + 2] << 16) | ((uint32_t)ram[RM_HZX + 3] << 24);
+    p.hza4 = ram[RM_HZA] | (ram[RM_HZA + 1] << 8) | (ram[RM_HZA + 2] << 16) | ((uint32_t)ram[RM_HZA + 3] << 24);
+    return p;
+}
+
+// palette index of screen pixel (x, y)
+__device__ __forceinline__ int synth_pixel(const PixState &p, int x, int y) {
+    if (!p.blink && (unsigned)(y - p.py) < 16u) {
+        int d = x - p.px;
+        d += d < 0 ? 160 : 0;
+        if (d < 8) return 8;
+    }
     if (y < 8 || y >= 208) return 0;
     if (y < 16) {
-        if (x >= 8 && x < 8 + 2 * ram[RM_TEMP]) return 11;
-        int q = x - 120;
-        if (q >= 0 && q < 10 * ram[RM_LIVES] && (q % 10) < 6) return 12;
+        if (x >= 8 && x < p.temp2) return 11;
+        const int q = x - 120;
+        if (q >= 0 && q < p.lives10 && (q % 10) < 6) return 12;
         return 1;
     }
     if (y < 20) {
-        if (x >= 8 && x < 136 && ((x - 8) & 7) < 6) {
-            int sc = ram[RM_SCORE] | (ram[RM_SCORE + 1] << 8);
-            if ((sc >> ((x - 8) >> 3)) & 1) return 14;
-        }
+        if (x >= 8 && x < 136 && ((x - 8) & 7) < 6 && ((p.score >> ((x - 8) >> 3)) & 1)) return 14;
         return 1;
     }
     if (y < 64) {
         if (x >= 112 && x < 144 && y >= 40) {
-            int ig = ram[RM_IGLOO];
-            if (ig >= 16 && x >= 124 && x < 132 && y >= 52) return 13;
-            if (((63 - y) / 6) * 4 + ((x - 112) >> 3) < ig) return 10;
+            if (p.igloo >= 16 && x >= 124 && x < 132 && y >= 52) return 13;
+            if (((63 - y) / 6) * 4 + ((x - 112) >> 3) < p.igloo) return 10;
         }
-        return (ram[RM_LEVEL] & 1) ? 3 : 2;
+        return p.sky;
     }
     if (y < 80) return 4;
-    const int r = (y - 80) >> 5, yo = (y - 80) & 31;
-    if (yo >= 4 && yo < 12 && ram[RM_HZA + r]) {
-        int d = x - (int)ram[RM_HZX + r];
+    const int r8 = ((y - 80) >> 5) * 8, yo = (y - 80) & 31;
+    if (yo >= 4 && yo < 12 && ((p.hza4 >> r8) & 255u)) {
+        const int d = x - (int)((p.hzx4 >> r8) & 255u);
         if ((d < 0 ? -d : d) < 6) return 9;
     }
     if (yo >= 16 && yo < 28) {
-        int rel = (x + 160 - ram[RM_OFF + r]) % 160;
-        if ((rel % 40) < 32) return ram[RM_VIS + r] ? 7 : 6;
+        int rel = x - (int)((p.off4 >> r8) & 255u);
+        rel += rel < 0 ? 160 : 0;
+        if ((rel % 40) < 32) return ((p.vis4 >> r8) & 255u) ? 7 : 6;
     }
     return (yo & 8) ? 15 : 5;
 }
@@ -203,6 +219,7 @@ struct ResizeLds {      // PIL tables padded to a fixed tap count with zero weig
     double kv[84 * 7];
     uint8_t xmin[84];
     uint8_t ymin[84];
+    float gray2[256];
 };
 
 struct EnvLds {
@@ -214,7 +231,6 @@ struct EnvLds {
     int rep_y[ENV_MAX_ROWS];
     uint8_t img[ENV_MAX_ROWS * 160];        // colour pair (prev<<4 | cur) per pixel of each unique row
     float tmp[ENV_MAX_ROWS * 84];           // horizontally resized unique rows (float32 like PIL's temp image)
-    float gray2[256];
     int misc[4];
 };
 
@@ -235,23 +251,12 @@ __device__ __forceinline__ bool synth_player_row(const uint8_t *ram, int y) {
     return !blink && (unsigned)(y - py) < 16u;
 }
 
-__device__ inline void synth_load_tables(EnvLds &s, const ResizeTables *__restrict__ T) {
-    const int tid = threadIdx.x;
-    // fixed 5 / 7 taps per output: windows that would leave the frame are shifted back inside and their
-    // weights shifted with them, zero weights filling the rest (0 + x*0.0 and acc + x*0.0 are exact)
-    for (int i = tid; i < 84 * 5; i += 256) {
-        const int xx = i / 5, t = i % 5, x0 = T->bh[xx * 2];
-        const int d = x0 + 5 > 160 ? x0 + 5 - 160 : 0;
-        s.R.kh[i] = t >= d ? T->kh[xx * 5 + t - d] : 0.0;
-        if (t == 0) s.R.xmin[xx] = (uint8_t)(x0 - d);
-    }
-    for (int i = tid; i < 84 * 7; i += 256) {
-        const int yy = i / 7, t = i % 7, y0 = T->bv[yy * 2];
-        const int d = y0 + 7 > 210 ? y0 + 7 - 210 : 0;
-        s.R.kv[i] = t >= d ? T->kv[yy * 7 + t - d] : 0.0;
-        if (t == 0) s.R.ymin[yy] = (uint8_t)(y0 - d);
-    }
-    s.gray2[tid] = T->gray2[tid];
+// copy the host-built table image (engine.hip: make_lds_tables) into LDS, 8 bytes per thread-step
+__device__ inline void synth_load_tables(EnvLds &s, const ResizeLds *__restrict__ T) {
+    static_assert(sizeof(ResizeLds) % 8 == 0, "ResizeLds is copied in 8-byte words");
+    const unsigned long long *src = (const unsigned long long *)T;
+    unsigned long long *dst = (unsigned long long *)&s.R;
+    for (int i = threadIdx.x; i < (int)(sizeof(ResizeLds) / 8); i += 256) dst[i] = src[i];
 }
 
 // Render + warp max(prev, cur) and either shift it into the stack (fill == false) or fill all four
@@ -274,9 +279,10 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     __syncthreads();
     if (tid < 210) s.slot_of_y[tid] = (uint8_t)s.slot_of_key[key];
     const int nu = s.misc[2];
+    const PixState pp = synth_pix_state(s.ram_prev), pc = synth_pix_state(s.ram_cur);
     for (int i = tid; i < nu * 160; i += 256) {
         const int y = s.rep_y[i / 160], x = i % 160;
-        s.img[i] = (uint8_t)((synth_pixel(s.ram_prev, x, y) << 4) | synth_pixel(s.ram_cur, x, y));
+        s.img[i] = (uint8_t)((synth_pixel(pp, x, y) << 4) | synth_pixel(pc, x, y));
     }
     __syncthreads();
     for (int i = tid; i < nu * 84; i += 256) {   // horizontal pass over the unique rows
@@ -285,7 +291,7 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
         const double *k = s.R.kh + xx * 5;
         double acc = 0.0;
 #pragma unroll
-        for (int t = 0; t < 5; t++) acc = acc + (double)s.gray2[px[t]] * k[t];
+        for (int t = 0; t < 5; t++) acc = acc + (double)s.R.gray2[px[t]] * k[t];
         s.tmp[i] = (float)acc;
     }
     __syncthreads();

@@ -387,6 +387,137 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
     }
 }
 
+// ------------------------------------------------------------ fc for small active counts (the tail)
+// When only a few episodes are still running, a lock-step is latency-bound: one workgroup per pair would
+// stream 4 MB through four waves.  Here each pair gets 4 workgroups (one per 64-column quarter), every lane
+// owns ONE output column (4-byte loads, 256 B per wave-row) and keeps 2 x 44 rows in flight, so a slice is 22
+// dependent batches instead of 121.  Same 4 k-slices, same chain order, same combine -> same bits.
+// The 256 x nact output layer + argmax needs all four quarters and runs in k_out.
+template <int NV, bool HAS_BN>
+__global__ __launch_bounds__(256) void k_fc_cols(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
+                                                 float *__restrict__ y3) {
+    __shared__ float xs[4][NV][968];
+    __shared__ float part[4][NV][64];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const Layout &L = A.L;
+    const int item = blockIdx.x >> 2, cq = blockIdx.x & 3;
+    const int g = list ? list[item] : item;
+    int member[NV];
+    float scale[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) { member[v] = g * NV + v; scale[v] = A.m_scale[member[v]]; }
+    const int64_t off = A.m_off[member[0]];
+    const float *base = A.bases + (size_t)A.m_slot[member[0]] * A.base_stride;
+    const int col = cq * 64 + lane;
+    const int kbeg = 968 * wv;
+    const float *eps = A.noise + off + L.fcw + (size_t)kbeg * 256 + col;
+    const float *th = base + L.fcw + (size_t)kbeg * 256 + col;
+    constexpr int RB = 44;
+    float e_cur[RB], t_cur[RB], e_nxt[RB], t_nxt[RB];
+#pragma unroll
+    for (int i = 0; i < RB; i++) { e_cur[i] = eps[(size_t)i * 256]; t_cur[i] = th[(size_t)i * 256]; }
+#pragma unroll
+    for (int v = 0; v < NV; v++)
+        for (int i = lane; i < 968; i += 64) {
+            float t = y2[(size_t)member[v] * 3872 + kbeg + i];
+            if (HAS_BN) {
+                const int ch = (kbeg + i) & 31;
+                t = t * A.bn[(size_t)member[v] * 608 + 32 + ch];
+                t = t + A.bn[(size_t)member[v] * 608 + 64 + ch];
+            }
+            xs[wv][v][i] = t > 0.0f ? t : 0.0f;
+        }
+    __syncthreads();
+    float acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) acc[v] = 0.0f;
+    for (int bt = 0; bt < 968 / RB; bt++) {
+        if (bt + 1 < 968 / RB) {
+#pragma unroll
+            for (int i = 0; i < RB; i++) {
+                e_nxt[i] = eps[(size_t)((bt + 1) * RB + i) * 256];
+                t_nxt[i] = th[(size_t)((bt + 1) * RB + i) * 256];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; i++) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                float pv = scale[v] * e_cur[i];
+                const float w = t_cur[i] + pv;
+                acc[v] = __builtin_fmaf(xs[wv][v][bt * RB + i], w, acc[v]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; i++) { e_cur[i] = e_nxt[i]; t_cur[i] = t_nxt[i]; }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; v++) part[wv][v][lane] = acc[v];
+    __syncthreads();
+    if (tid < NV * 64) {
+        const int v = tid >> 6, j = cq * 64 + (tid & 63);
+        const float s01 = part[0][v][tid & 63] + part[1][v][tid & 63];
+        const float s23 = part[2][v][tid & 63] + part[3][v][tid & 63];
+        float s = s01 + s23;
+        float pv = scale[v] * A.noise[off + L.fcb + j];
+        const float bias = base[L.fcb + j] + pv;
+        y3[(size_t)member[v] * 256 + j] = s + bias;
+    }
+}
+
+// bn3 + relu + out layer (256 x nact, k-ordered chain) + first-max argmax from y3, one wave per group
+template <int NV, bool HAS_BN>
+__global__ __launch_bounds__(64) void k_out(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y3,
+                                            int32_t *__restrict__ actions, float *__restrict__ logits_out) {
+    __shared__ float a3[NV][256];
+    __shared__ float lg[NV][32];
+    const int tid = threadIdx.x;
+    const Layout &L = A.L;
+    const int g = list ? list[blockIdx.x] : blockIdx.x;
+    const int nact = L.nact;
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        const int m = g * NV + v;
+        for (int j = tid; j < 256; j += 64) {
+            float t = y3[(size_t)m * 256 + j];
+            if (HAS_BN) {
+                t = t * A.bn[(size_t)m * 608 + 96 + j];
+                t = t + A.bn[(size_t)m * 608 + 352 + j];
+            }
+            a3[v][j] = t > 0.0f ? t : 0.0f;
+        }
+    }
+    __syncthreads();
+    if (tid < NV * nact) {
+        const int v = tid / nact, a = tid % nact, m = g * NV + v;
+        const float sc = A.m_scale[m];
+        const int64_t off = A.m_off[m];
+        const float *base = A.bases + (size_t)A.m_slot[m] * A.base_stride;
+        const float *wb = base + L.ow + a;
+        const float *we = A.noise + off + L.ow + a;
+        float s = 0.0f;
+#pragma unroll 16
+        for (int k = 0; k < 256; k++) {
+            float pv = sc * we[k * nact];
+            float w = wb[k * nact] + pv;
+            s = __builtin_fmaf(a3[v][k], w, s);
+        }
+        float pv = sc * A.noise[off + L.ob + a];
+        const float bias = base[L.ob + a] + pv;
+        lg[v][a] = s + bias;
+    }
+    __syncthreads();
+    if (tid < NV) {
+        const int v = tid, m = g * NV + v;
+        int best = 0;
+        for (int a = 1; a < nact; a++)
+            if (lg[v][a] > lg[v][best]) best = a;
+        actions[m] = best;
+        if (logits_out)
+            for (int a = 0; a < nact; a++) logits_out[(size_t)m * nact + a] = lg[v][a];
+    }
+}
+
 // -------------------------------------------------------------- virtual batch norm statistics
 // tf.contrib.layers.batch_norm(is_training=True, decay=0): batch moments over (N, H, W), biased
 // variance, written as per-channel scale = gamma * rsqrt(var + 1e-3), shift = beta - mean * scale

@@ -18,7 +18,7 @@ def hip():
 
 @pytest.fixture(scope="module")
 def es_engine(hip, small_noise):
-    e = hip.Engine(hip.KIND_ES, NACT, max_members=64, ref_count=NREF, record_bc=True, bc_max_steps=80, profile_events=True)
+    e = hip.Engine(hip.KIND_ES, NACT, max_members=64, ref_count=NREF, record_bc=True, bc_max_steps=224, profile_events=True)
     e.noise_upload(small_noise)
     yield e
     e.close()
@@ -74,9 +74,9 @@ def test_env_reset_and_step(es_engine, oracle):
     assert np.array_equal(e.env_ram(n), np.stack([env.ram() for env in envs]))
     rs = np.random.RandomState(0)
     alive = np.ones(n, bool)
-    for t in range(60):
+    for t in range(230):
         acts = rs.randint(0, NACT, n)
-        acts[:4] = 5 if t % 3 else 13          # DOWN / DOWNFIRE pressure: deaths, early done inside a skip
+        acts[:6] = 5 if t % 3 else 13          # DOWN / DOWNFIRE pressure: deaths, early done inside a skip
         rew, done = e.env_step(acts)
         g_obs, g_ram = e.env_observation(n), e.env_ram(n)
         for i in range(n):
@@ -185,7 +185,7 @@ def test_es_eval_matches_oracle(es_engine, oracle, small_noise, ref_batch):
     th = O.es_init_theta(L, 0)
     e.set_theta(th)
     e.set_ref_batch(ref_batch)
-    n, tslimit, sigma = 8, 70, 0.02
+    n, tslimit, sigma = 8, 220, 0.02
     srs = np.random.RandomState(0)
     idx = np.array([srs.randint(0, small_noise.size - L.P + 1) for _ in range(n)], np.int64)
     seeds = np.random.RandomState(1000).randint(0, 2 ** 31, 2 * n).astype(np.uint32)
