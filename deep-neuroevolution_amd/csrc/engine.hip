@@ -692,7 +692,8 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     if (tslimit <= 0) return h->fail("timestep limit must be positive");
     if (bc_out && !h->bc) return h->fail("behaviour characterisations requested but the engine was created with record_bc = 0");
     const bool prof = h->cfg.profile_events != 0;
-    const int bc_mode = bc_out ? (h->L.kind == DNE_KIND_ES ? 1 : 2) : 0;
+    // record_bc engines always record (the trajectories feed dne_novelty_batch on the device); bc_out only controls the download
+    const int bc_mode = h->bc ? (h->L.kind == DNE_KIND_ES ? 1 : 2) : 0;
     if (bc_mode == 1) HCHECK(h, hipMemsetAsync(h->bc, 0, (size_t)n * h->cfg.bc_max_steps * 128, h->stream));
     if (bc_mode == 2) HCHECK(h, hipMemsetAsync(h->bc, 0, (size_t)n * 128, h->stream));
     HCHECK(h, hipEventRecord(h->ev_a, h->stream));
@@ -956,6 +957,22 @@ extern "C" int dne_optimizer_reset(dne_handle *h) {
     return 0;
 }
 
+extern "C" int dne_optimizer_get_state(dne_handle *h, float *m, float *v, int32_t *t) {
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    if (m) HCHECK(h, hipMemcpy(m, h->opt_m, (size_t)h->L.P * sizeof(float), hipMemcpyDeviceToHost));
+    if (v) HCHECK(h, hipMemcpy(v, h->opt_v, (size_t)h->L.P * sizeof(float), hipMemcpyDeviceToHost));
+    if (t) *t = h->opt_t;
+    return 0;
+}
+
+extern "C" int dne_optimizer_set_state(dne_handle *h, const float *m, const float *v, int32_t t) {
+    if (t < 0) return h->fail("optimizer step count must be >= 0");
+    if (m) HCHECK(h, hipMemcpy(h->opt_m, m, (size_t)h->L.P * sizeof(float), hipMemcpyHostToDevice));
+    if (v) HCHECK(h, hipMemcpy(h->opt_v, v, (size_t)h->L.P * sizeof(float), hipMemcpyHostToDevice));
+    h->opt_t = t;
+    return 0;
+}
+
 extern "C" int dne_optimizer_step(dne_handle *h, int kind, float l2, double stepsize, double b1m, double b2, double eps,
                                   double *ratio) {
     const int P = h->L.P, nb = (P + 255) / 256;
@@ -1043,5 +1060,43 @@ extern "C" int dne_novelty(dne_handle *h, const uint8_t *archive, const int32_t 
     double s = 0;
     for (int i = 0; i < kk; i++) s += d[i];
     *out = s / kk;
+    return 0;
+}
+
+extern "C" int dne_novelty_batch(dne_handle *h, const uint8_t *archive, const int32_t *alen, int narch, int n,
+                                 const int32_t *lengths, int k, double *out) {
+    if (h->L.kind != DNE_KIND_ES || !h->bc) return h->fail("dne_novelty_batch needs an ES engine created with record_bc = 1");
+    if (check_n(h, n)) return -1;
+    if (narch < 1 || k < 1) return h->fail("dne_novelty_batch: bad sizes");
+    std::vector<int64_t> row0(narch);
+    int64_t rows = 0;
+    for (int a = 0; a < narch; a++) { if (alen[a] < 1) return h->fail("empty archive entry"); row0[a] = rows; rows += alen[a]; }
+    for (int i = 0; i < n; i++)
+        if (lengths[i] < 1 || lengths[i] > h->cfg.bc_max_steps) return h->fail("member %d: trajectory length %d outside the recorded capacity %d", i, lengths[i], h->cfg.bc_max_steps);
+    uint8_t *d_arch = nullptr; int64_t *d_row0 = nullptr; int32_t *d_alen = nullptr, *d_len = nullptr; long long *d_out = nullptr;
+    HCHECK(h, dalloc(&d_arch, (size_t)rows * 128)); HCHECK(h, dalloc(&d_row0, narch)); HCHECK(h, dalloc(&d_alen, narch));
+    HCHECK(h, dalloc(&d_len, n)); HCHECK(h, dalloc(&d_out, (size_t)n * narch * 2));
+    HCHECK(h, hipMemcpyAsync(d_arch, archive, (size_t)rows * 128, hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipMemcpyAsync(d_row0, row0.data(), narch * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipMemcpyAsync(d_alen, alen, narch * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipMemcpyAsync(d_len, lengths, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_bc_sqdist_batch, dim3(narch, n), dim3(256), 0, h->stream, (const uint8_t *)d_arch, (const int64_t *)d_row0,
+                       (const int32_t *)d_alen, (const uint8_t *)h->bc, (const int32_t *)d_len, h->cfg.bc_max_steps, narch, d_out);
+    std::vector<long long> ab((size_t)n * narch * 2);
+    HCHECK(h, hipMemcpyAsync(ab.data(), d_out, ab.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    hipFree(d_arch); hipFree(d_row0); hipFree(d_alen); hipFree(d_len); hipFree(d_out);
+    std::vector<double> d(narch);
+    const int kk = std::min(k, narch);
+    for (int i = 0; i < n; i++) {
+        for (int a = 0; a < narch; a++) {   // nses.py:12-20
+            const double na = std::sqrt((double)ab[((size_t)i * narch + a) * 2]), nb = std::sqrt((double)ab[((size_t)i * narch + a) * 2 + 1]);
+            d[a] = std::sqrt(na * na + nb * nb);
+        }
+        std::sort(d.begin(), d.end());      // nses.py:29-31
+        double s = 0;
+        for (int j = 0; j < kk; j++) s += d[j];
+        out[i] = s / kk;
+    }
     return 0;
 }

@@ -196,4 +196,38 @@ __global__ __launch_bounds__(256) void k_bc_sqdist(const uint8_t *__restrict__ a
     if (threadIdx.x == 0) { out[2 * a] = ra[0]; out[2 * a + 1] = rb[0]; }
 }
 
+// batched form over the engine-resident trajectories: block (a, i) = archive entry a vs member i
+__global__ __launch_bounds__(256) void k_bc_sqdist_batch(const uint8_t *__restrict__ archive, const int64_t *__restrict__ arow0,
+                                                         const int32_t *__restrict__ alen, const uint8_t *__restrict__ bc,
+                                                         const int32_t *__restrict__ lens, int bc_stride_rows, int narch,
+                                                         long long *__restrict__ out /*[n][narch][2]*/) {
+    const int a = blockIdx.x, i = blockIdx.y, dim = 128;
+    const uint8_t *x = archive + arow0[a] * dim;
+    const uint8_t *y = bc + (size_t)i * bc_stride_rows * dim;
+    const int n = alen[a], m = lens[i];
+    const int lo = n < m ? n : m, hi = n < m ? m : n;
+    long long sa = 0, sb = 0;
+    for (int e = threadIdx.x; e < hi * (dim / 4); e += 256) {   // 4 bytes per thread-step
+        const int r = e / (dim / 4), d4 = e % (dim / 4);
+        const int xi = r < n ? r : n - 1, yi = r < m ? r : m - 1;
+        const uint32_t xv = *(const uint32_t *)(x + (size_t)xi * dim + 4 * d4);
+        const uint32_t yv = *(const uint32_t *)(y + (size_t)yi * dim + 4 * d4);
+        int s = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int df = (int)((xv >> (8 * b)) & 255u) - (int)((yv >> (8 * b)) & 255u);
+            s += df * df;
+        }
+        if (r < lo) sa += s; else sb += s;
+    }
+    __shared__ long long ra[256], rb[256];
+    ra[threadIdx.x] = sa; rb[threadIdx.x] = sb;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { ra[threadIdx.x] += ra[threadIdx.x + s]; rb[threadIdx.x] += rb[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[((size_t)i * narch + a) * 2] = ra[0]; out[((size_t)i * narch + a) * 2 + 1] = rb[0]; }
+}
+
 }  // namespace dne

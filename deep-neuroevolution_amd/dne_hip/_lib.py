@@ -255,6 +255,15 @@ class Engine:
     def optimizer_reset(self):
         self._ck(self.lib.dne_optimizer_reset(self.h))
 
+    def optimizer_get_state(self):
+        m = np.empty(self.P, np.float32); v = np.empty(self.P, np.float32); t = C.c_int32()
+        self._ck(self.lib.dne_optimizer_get_state(self.h, _ptr(m, C.c_float), _ptr(v, C.c_float), C.byref(t)))
+        return m, v, t.value
+
+    def optimizer_set_state(self, m, v, t):
+        m = _arr(m, np.float32); v = _arr(v, np.float32)
+        self._ck(self.lib.dne_optimizer_set_state(self.h, _ptr(m, C.c_float), _ptr(v, C.c_float), int(t)))
+
     def optimizer_step(self, kind, l2coeff, stepsize, beta1_or_momentum=0.9, beta2=0.999, epsilon=1e-8):
         ratio = C.c_double()
         self._ck(self.lib.dne_optimizer_step(self.h, OPT_KINDS[kind], C.c_float(l2coeff), C.c_double(stepsize),
@@ -287,6 +296,17 @@ class Engine:
         self._ck(self.lib.dne_novelty(self.h, _ptr(cat, C.c_uint8), _ptr(lens, C.c_int32), len(arch), _ptr(bc, C.c_uint8),
                                       int(bc.shape[0]), int(dim), int(k), C.byref(out)))
         return out.value
+
+    def novelty_batch(self, archive, lengths, k):
+        """novelty of every member's RAM trajectory recorded by the last es_eval (kept on the device)"""
+        arch = [_arr(a, np.uint8).reshape(-1, RAM_BYTES) for a in archive]
+        lens = _arr([a.shape[0] for a in arch], np.int32)
+        cat = _arr(np.concatenate(arch), np.uint8)
+        ln = _arr(np.asarray(lengths).reshape(-1), np.int32)
+        out = np.empty(ln.size, np.float64)
+        self._ck(self.lib.dne_novelty_batch(self.h, _ptr(cat, C.c_uint8), _ptr(lens, C.c_int32), len(arch), int(ln.size),
+                                            _ptr(ln, C.c_int32), int(k), _ptr(out, C.c_double)))
+        return out
 
     def profile(self):
         p = Profile()

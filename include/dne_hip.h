@@ -123,6 +123,10 @@ int dne_weighted_sum(dne_handle *h, const int64_t *idx, const float *w, int n, f
 int dne_optimizer_step(dne_handle *h, int opt_kind, float l2coeff, double stepsize, double beta1_or_momentum,
                        double beta2, double epsilon, double *update_ratio);
 int dne_optimizer_reset(dne_handle *h); /* zero m, v, t (a fresh Adam/SGD, optimizers.py:24-27,36-43) */
+/* nses.py:95-117,283-284 keeps one optimizer per meta-population member: swap its state in and out
+ * (Adam: m, v, t ; SGD: v in `v`, m ignored).  Pointers may be NULL to skip a field. */
+int dne_optimizer_get_state(dne_handle *h, float *m, float *v, int32_t *t);
+int dne_optimizer_set_state(dne_handle *h, const float *m, const float *v, int32_t t);
 /* es.py:281-298 in one call: process returns (proc_mode), aggregate, optimizer step */
 int dne_es_update(dne_handle *h, const int64_t *idx, const float *returns_n2, const float *signreturns_n2,
                   int n, int proc_mode, int opt_kind, float l2coeff, double stepsize, double beta1_or_momentum,
@@ -133,6 +137,11 @@ int dne_ga_select(dne_handle *h, const float *returns, int m, int t, int32_t *ou
 /* ---- A13 nses.py:12-32: novelty of one behaviour characterisation against an archive ------------------- */
 int dne_novelty(dne_handle *h, const uint8_t *archive /*concatenated rows*/, const int32_t *archive_len,
                 int narchive, const uint8_t *bc, int bc_len, int dim, int k, double *out);
+/* nses.py:381-382 for a whole evaluated batch: novelty of each of the n members' RAM trajectories recorded by
+ * the last dne_es_eval / dne_eval_members (record_bc engines; member i has lengths[i] rows of 128 bytes, which
+ * never leave the device) against the archive */
+int dne_novelty_batch(dne_handle *h, const uint8_t *archive, const int32_t *archive_len, int narchive, int n,
+                      const int32_t *lengths, int k, double *out);
 
 #ifdef __cplusplus
 }

@@ -48,12 +48,81 @@ class OracleEngine:
 
     def es_eval(self, idx, sigma, tslimit, seeds, want_bc=False):
         self.calls.append(("es_eval", len(idx)))
-        return O.es_eval(self.L, self.theta, self.noise, idx, sigma, tslimit, self.ref, seeds)
+        if not self.bc_max_steps:
+            return O.es_eval(self.L, self.theta, self.noise, idx, sigma, tslimit, self.ref, seeds)
+        n = len(idx)
+        ret = np.zeros((n, 2), np.float32); sg = np.zeros((n, 2), np.float32); ln = np.zeros((n, 2), np.int32)
+        self.bcs = []
+        for i in range(n):
+            for s in range(2):
+                th = O.perturb(self.theta, self.noise, idx[i], sigma, 1 if s == 0 else -1)
+                r, q, l, bc = O.rollout(self.L, th, self.ref, seeds[2 * i + s], tslimit, want_bc=True)
+                ret[i, s], sg[i, s], ln[i, s] = r, q, l
+                self.bcs.append(bc)
+        return ret, sg, ln
 
     def eval_members(self, n, tslimit, seeds, want_bc=False):
-        out = [O.rollout(self.L, self._member_theta(i), self.ref, seeds[i], tslimit)[:3] for i in range(n)]
+        out = [O.rollout(self.L, self._member_theta(i), self.ref, seeds[i], tslimit, want_bc=want_bc) for i in range(n)]
+        r = np.array([o[0] for o in out], np.float32); s = np.array([o[1] for o in out], np.float32)
+        l = np.array([o[2] for o in out], np.int32)
+        if not want_bc:
+            return r, s, l
+        if self.kind == O.KIND_ES:
+            bc = np.zeros((n, max(self.bc_max_steps, int(l.max())), 128), np.uint8)
+            for i, o in enumerate(out):
+                bc[i, :l[i]] = o[3]
+        else:
+            bc = np.stack([o[3] for o in out])
+        return r, s, l, bc
+
+    def novelty(self, archive, bc, k):
+        return O.novelty(archive, bc, k)
+
+    def novelty_batch(self, archive, lengths, k):
+        return np.array([O.novelty(archive, b, k) for b in self.bcs])
+
+    def centered_ranks(self, x):
+        x = np.asarray(x, np.float32)
+        return O.centered_ranks(x.reshape(-1)).reshape(x.shape)
+
+    def weighted_sum(self, idx, w, denom, copy_out=True):
+        self.g = O.weighted_sum(self.noise, idx, w, self.P, denom)
+        return self.g if copy_out else None
+
+    def optimizer_step(self, kind, l2coeff, stepsize, beta1_or_momentum=0.9, beta2=0.999, epsilon=1e-8):
+        if self.opt is None:
+            self.opt = (O.Adam(self.theta, stepsize, beta1_or_momentum, beta2, epsilon) if kind == "adam"
+                        else O.SGD(self.theta, stepsize, beta1_or_momentum))
+        self.opt.theta = self.theta.copy()
+        ratio, th = self.opt.update(self.g, l2coeff)
+        self.theta = th.copy()
+        return ratio
+
+    def optimizer_get_state(self):
+        if self.opt is None:
+            return np.zeros(self.P, np.float32), np.zeros(self.P, np.float32), 0
+        return getattr(self.opt, "m", np.zeros(self.P, np.float32)).copy(), self.opt.v.copy(), getattr(self.opt, "t", 0)
+
+    def optimizer_set_state(self, m, v, t):
+        self.opt = O.Adam(self.theta, 0.01)
+        self.opt.m, self.opt.v, self.opt.t = np.array(m, np.float32), np.array(v, np.float32), int(t)
+        self._adam_args_pending = True
+
+    def ga_rebuild(self, slot, seeds, sigma, copy_out=True):
+        th = O.ga_rebuild(self.L, self.noise, seeds, sigma)
+        if slot == 0:
+            self.theta = th.copy()
+        return th
+
+    def ga_eval(self, chains, sigma, tslimit, seeds, want_bc=False):
+        self.calls.append(("ga_eval", len(chains)))
+        out = [O.rollout(self.L, O.ga_rebuild(self.L, self.noise, c, sigma), None, seeds[i], tslimit)[:3]
+               for i, c in enumerate(chains)]
         r, s, l = zip(*out)
         return np.array(r, np.float32), np.array(s, np.float32), np.array(l, np.int32)
+
+    def ga_select(self, returns, t):
+        return O.ga_select(returns, t)
 
     def es_update(self, idx, returns_n2, signreturns_n2, proc_mode, opt_kind, l2coeff, stepsize,
                   beta1_or_momentum=0.9, beta2=0.999, epsilon=1e-8):

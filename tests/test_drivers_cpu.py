@@ -1,0 +1,65 @@
+"""CPU: the GA and NS-ES driver mirrors (dne_hip/ga.py, dne_hip/nses.py) over the in-process transport with the
+oracle standing in for the GPU engine -- protocol, chain bookkeeping, truncation, novelty plumbing."""
+import threading
+
+import numpy as np
+import pytest
+
+
+def _ga_exp(children, parents, tslimit):
+    return {"config": {"calc_obstat_prob": 0.0, "episodes_per_batch": children, "eval_prob": 0.0, "l2coeff": 0.005,
+                       "noise_stdev": 0.005, "snapshot_freq": 0, "timesteps_per_batch": 10,
+                       "return_proc_mode": "centered_rank", "episode_cutoff_mode": tslimit},
+            "population_size": parents, "num_elites": 1, "env_id": "FrostbiteNoFrameskip-v4",
+            "policy": {"args": {"nonlin_type": "relu"}, "type": "GAAtariPolicy"}}
+
+
+def test_ga_master_worker(oracle, tmp_path):
+    from oracle_engine import OracleEngine
+    from dne_hip import dist, es, ga
+    dist.reset_brokers()
+    exp = _ga_exp(children=6, parents=3, tslimit=25)
+    noise = es.SharedNoiseTable(count=2_500_000)
+    me, we = OracleEngine(1), OracleEngine(1)
+    cfg = {"unix_socket_path": "/tmp/test_ga.sock"}
+    out = {}
+    tm = threading.Thread(target=lambda: out.update(r=ga.run_master(cfg, str(tmp_path), exp, engine=me, noise=noise, max_iters=3)), daemon=True)
+    tm.start()
+    ga.run_worker(cfg, cfg, noise, engine=we, max_tasks=3, seed=11)
+    tm.join(timeout=300)
+    assert not tm.is_alive()
+    policy, population, score = out["r"]
+    assert len(population) == 3 and all(isinstance(c, list) for c in population)
+    assert [len(c) for c in population] != [1, 1, 1]          # chains grew over generations (ga.py:252)
+    assert np.all(np.diff(score) <= 0)                          # ordered by (-return, arrival)
+    # elite theta in slot 0 = normc(noise[s0]) + sigma * sum noise[s_k]   (ga.py:151-158)
+    L = oracle.layout(1, 18)
+    assert np.array_equal(policy.get_trainable_flat(), oracle.ga_rebuild(L, noise.noise, population[0], 0.005))
+    # every chain starts from a generation-0 seed and every child = some parent + one index
+    assert all(0 <= s <= noise.noise.size - L.P for c in population for s in c)
+    assert [c[0] for c in we.calls] == ["ga_eval"] * 3 and we.calls[0][1] == 6
+
+
+def test_nses_master_worker(oracle, tmp_path):
+    from oracle_engine import OracleEngine
+    from dne_hip import dist, es, nses
+    dist.reset_brokers()
+    exp = {"config": {"calc_obstat_prob": 0.0, "episodes_per_batch": 4, "eval_prob": 0.0, "l2coeff": 0.005,
+                      "noise_stdev": 0.02, "snapshot_freq": 0, "timesteps_per_batch": 10,
+                      "return_proc_mode": "centered_sign_rank", "episode_cutoff_mode": 10},
+           "env_id": "FrostbiteNoFrameskip-v4", "algo_type": "nsr",
+           "novelty_search": {"k": 2, "population_size": 2, "num_rollouts": 1, "selection_method": "novelty_prob"},
+           "optimizer": {"args": {"stepsize": 0.01}, "type": "adam"}, "policy": {"args": {}, "type": "ESAtariPolicy"}}
+    noise = es.SharedNoiseTable(count=2_500_000)
+    me, we = OracleEngine(0, ref_count=16, bc_max_steps=10), OracleEngine(0, ref_count=16, bc_max_steps=10)
+    cfg = {"unix_socket_path": "/tmp/test_ns.sock"}
+    out = {}
+    tm = threading.Thread(target=lambda: out.update(r=nses.run_master(cfg, str(tmp_path), exp, engine=me, noise=noise, max_iters=2)), daemon=True)
+    tm.start()
+    nses.run_worker(cfg, cfg, noise, engine=we, max_tasks=2, seed=5)
+    tm.join(timeout=300)
+    assert not tm.is_alive()
+    theta_dict, archive = out["r"]
+    assert len(theta_dict) == 2 and len(archive) == 2 + 2      # pop_size initial BCs + one per iteration (nses.py:112,247)
+    assert all(a.dtype == np.uint8 and a.shape[1] == 128 and 1 <= a.shape[0] <= 10 for a in archive)
+    assert any(not np.array_equal(theta_dict[p], __import__("dne_hip.policies", fromlist=["x"]).xavier_flat(18, p)) for p in (0, 1))

@@ -297,3 +297,70 @@ def test_errors_are_loud(es_engine, hip):
         e.env_step(np.array([99], np.int32))
     with pytest.raises(hip.DneError):
         e.env_reset(np.zeros(10 ** 6, np.uint32))
+
+
+def test_novelty_batch_and_optimizer_state(es_engine, oracle, small_noise, ref_batch):
+    e, O = es_engine, oracle
+    L = O.layout(O.KIND_ES, NACT)
+    th = O.es_init_theta(L, 0)
+    e.set_theta(th)
+    e.set_ref_batch(ref_batch)
+    n, tslimit, sigma = 3, 40, 0.02
+    idx = np.array([11, 500_000, 2_000_000], np.int64)
+    seeds = np.arange(6, dtype=np.uint32) + 77
+    ret, sg, ln = e.es_eval(idx, sigma, tslimit, seeds)          # trajectories stay on the device
+    rs = np.random.RandomState(2)
+    archive = [rs.randint(0, 256, (m, 128)).astype(np.uint8) for m in (40, 7, 55, 40, 23)]
+    nov = e.novelty_batch(archive, ln, 3)
+    for i in range(n):
+        for s in range(2):
+            thp = O.perturb(th, small_noise, idx[i], sigma, 1 if s == 0 else -1)
+            _, _, l, bc = O.rollout(L, thp, ref_batch, seeds[2 * i + s], tslimit, want_bc=True)
+            assert l == ln[i, s]
+            assert nov[2 * i + s] == O.novelty(archive, bc, 3)
+    # optimizer state round trip (nses.py keeps one optimizer per meta-population member)
+    e.optimizer_reset()
+    g_idx = np.array([5, 9], np.int64)
+    e.es_update(g_idx, ret[:2], None, "centered_rank", "adam", 0.005, 0.01)
+    m, v, t = e.optimizer_get_state()
+    th1 = e.get_theta()
+    assert t == 1 and m.any() and v.any()
+    e.es_update(g_idx, ret[:2], None, "centered_rank", "adam", 0.005, 0.01)
+    th2 = e.get_theta()
+    e.set_theta(th1); e.optimizer_set_state(m, v, t)
+    e.es_update(g_idx, ret[:2], None, "centered_rank", "adam", 0.005, 0.01)
+    assert np.array_equal(e.get_theta(), th2)
+
+
+def test_ga_driver_on_device(hip, oracle, small_noise, tmp_path):
+    """dne_hip.ga master/worker over the real engine for two generations; elite theta checked against the oracle."""
+    import threading
+    from dne_hip import dist, es, ga
+    dist.reset_brokers()
+    exp = {"config": {"calc_obstat_prob": 0.0, "episodes_per_batch": 12, "eval_prob": 0.0, "l2coeff": 0.005,
+                      "noise_stdev": 0.005, "snapshot_freq": 0, "timesteps_per_batch": 10,
+                      "return_proc_mode": "centered_rank", "episode_cutoff_mode": 30},
+           "population_size": 4, "num_elites": 1, "env_id": "FrostbiteNoFrameskip-v4",
+           "policy": {"args": {"nonlin_type": "relu"}, "type": "GAAtariPolicy"}}
+    noise = es.SharedNoiseTable(count=small_noise.size)
+    me = hip.Engine(hip.KIND_GA, NACT, max_members=16)
+    we = hip.Engine(hip.KIND_GA, NACT, max_members=16)
+    cfg = {"unix_socket_path": "/tmp/gpu_ga.sock"}
+    out = {}
+    tm = threading.Thread(target=lambda: out.update(r=ga.run_master(cfg, str(tmp_path), exp, engine=me, noise=noise, max_iters=2)), daemon=True)
+    tm.start()
+    ga.run_worker(cfg, cfg, noise, engine=we, max_tasks=2, seed=3)
+    tm.join(timeout=120)
+    assert not tm.is_alive()
+    policy, population, score = out["r"]
+    L = oracle.layout(oracle.KIND_GA, NACT)
+    assert np.array_equal(policy.get_trainable_flat(), oracle.ga_rebuild(L, small_noise, population[0], 0.005))
+    # the elite's score is reproducible by the oracle with the same env seed stream
+    rs = np.random.RandomState(3); rs.randint(2 ** 31)
+    hi = small_noise.size - L.P + 1
+    gen0 = [[int(rs.randint(0, hi))] for _ in range(12)]
+    seeds0 = rs.randint(0, 2 ** 32, size=12, dtype=np.uint64).astype(np.uint32)
+    r0 = np.array([oracle.rollout(L, oracle.ga_rebuild(L, small_noise, c, 0.005), None, seeds0[i], 30)[0] for i, c in enumerate(gen0)], np.float32)
+    sel = oracle.ga_select(r0, 4)
+    assert score.max() >= r0[sel[0]]                                # elites are never lost (ga.py:136-137)
+    me.close(); we.close()
