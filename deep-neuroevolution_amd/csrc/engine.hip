@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void k_env_logic(EnvArgs E, const int *__restri
 }
 
 // max over the last two raw frames + WarpFrame + FrameStack for every member stepped by the logic kernel
-__global__ __launch_bounds__(256) void k_env_render(EnvArgs E, const int *__restrict__ list, int gsize, int fill) {
+__global__ __launch_bounds__(1024) void k_env_render(EnvArgs E, const int *__restrict__ list, int gsize, int fill) {
     __shared__ __attribute__((aligned(16))) EnvLds s;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int g = list ? list[b / gsize] : b / gsize;
@@ -520,7 +520,7 @@ static void launch_env_step(dne_handle *h, const EnvArgs &E, const int *list, in
     if (!st) st = h->stream;
     const int items = count * gsize;
     hipLaunchKernelGGL(k_env_logic, dim3((items + 63) / 64), dim3(64), 0, st, E, list, gsize, items, tslimit);
-    hipLaunchKernelGGL(k_env_render, dim3(items), dim3(256), 0, st, E, list, gsize, 0);
+    hipLaunchKernelGGL(k_env_render, dim3(items), dim3(items <= 192 ? 1024 : 256), 0, st, E, list, gsize, 0);
 }
 
 // ------------------------------------------------------------------------------- env ABI

@@ -256,14 +256,14 @@ __device__ inline void synth_load_tables(EnvLds &s, const ResizeLds *__restrict_
     static_assert(sizeof(ResizeLds) % 8 == 0, "ResizeLds is copied in 8-byte words");
     const unsigned long long *src = (const unsigned long long *)T;
     unsigned long long *dst = (unsigned long long *)&s.R;
-    for (int i = threadIdx.x; i < (int)(sizeof(ResizeLds) / 8); i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < (int)(sizeof(ResizeLds) / 8); i += blockDim.x) dst[i] = src[i];
 }
 
 // Render + warp max(prev, cur) and either shift it into the stack (fill == false) or fill all four
-// channels with it (fill == true, FrameStack reset).  Called by the whole 256-thread group after
+// channels with it (fill == true, FrameStack reset).  Called by the whole workgroup (>= 256 threads) after
 // synth_load_tables and after ram_prev / ram_cur are in LDS.
 __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bool fill) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nthr = blockDim.x;   // 256 threads normally, 1024 when few members remain
     if (tid < 192) s.slot_of_key[tid] = -1;
     if (tid == 0) s.misc[2] = 0;
     __syncthreads();
@@ -280,12 +280,12 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     if (tid < 210) s.slot_of_y[tid] = (uint8_t)s.slot_of_key[key];
     const int nu = s.misc[2];
     const PixState pp = synth_pix_state(s.ram_prev), pc = synth_pix_state(s.ram_cur);
-    for (int i = tid; i < nu * 160; i += 256) {
+    for (int i = tid; i < nu * 160; i += nthr) {
         const int y = s.rep_y[i / 160], x = i % 160;
         s.img[i] = (uint8_t)((synth_pixel(pp, x, y) << 4) | synth_pixel(pc, x, y));
     }
     __syncthreads();
-    for (int i = tid; i < nu * 84; i += 256) {   // horizontal pass over the unique rows
+    for (int i = tid; i < nu * 84; i += nthr) {   // horizontal pass over the unique rows
         const int u = i / 84, xx = i % 84;
         const uint8_t *px = s.img + u * 160 + s.R.xmin[xx];
         const double *k = s.R.kh + xx * 5;
@@ -295,7 +295,7 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
         s.tmp[i] = (float)acc;
     }
     __syncthreads();
-    for (int i = tid; i < 84 * 84; i += 256) {   // vertical pass + u8 truncation + stack shift
+    for (int i = tid; i < 84 * 84; i += nthr) {   // vertical pass + u8 truncation + stack shift
         const int yy = i / 84, xx = i % 84;
         const uint8_t *sl = s.slot_of_y + s.R.ymin[yy];
         const double *k = s.R.kv + yy * 7;

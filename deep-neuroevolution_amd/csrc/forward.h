@@ -95,9 +95,25 @@ __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict_
     float pb = sc * eps[4096 + lp];
     const float bias = base[4096 + lp] + pb;
     lut[tid] = (float)tid / 255.0f;
-    for (int i = tid; i < 88 * 88; i += 256) {
-        int y = i / 88 - 2, x = i % 88 - 2;
-        img[i] = ((unsigned)y < 84u && (unsigned)x < 84u) ? ((const uint32_t *)it.ob)[y * 84 + x] : 0u;
+    {   // stage the frame stack: all 28 loads of a thread are issued before the first LDS write (a rolled loop
+        // would pay one L2 round trip per element); the 2-pixel zero border is written separately
+        uint32_t px[28];
+#pragma unroll
+        for (int j = 0; j < 28; j++) {
+            const int e = tid + 256 * j;
+            px[j] = e < 7056 ? ((const uint32_t *)it.ob)[e] : 0u;
+        }
+        for (int i = tid; i < 688; i += 256) {
+            int r, c;
+            if (i < 352) { r = i / 88; r = r < 2 ? r : 84 + r; c = i % 88; }
+            else { const int j = i - 352; r = 2 + j / 4; c = j % 4; c = c < 2 ? c : 84 + c; }
+            img[r * 88 + c] = 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 28; j++) {
+            const int e = tid + 256 * j;
+            if (e < 7056) img[(e / 84 + 2) * 88 + e % 84 + 2] = px[j];
+        }
     }
     __syncthreads();
     float *out = y1 + (size_t)it.row * 7056;
@@ -143,7 +159,15 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
     const float *base = A.bases + (size_t)A.m_slot[it.member] * A.base_stride + A.L.c2w;
     const float *eps = A.noise + A.m_off[it.member] + A.L.c2w;
     const float sc = A.m_scale[it.member];
-    for (int i = tid; i < 24 * 24 * PS; i += 256) a_s[i] = 0.0f;
+    const float *bn = A.bn + (size_t)it.member * 608;
+    const float *src = y1 + (size_t)it.row * 7056;
+    float yv[28];   // all of this thread's activation loads in flight at once (its channel is tid & 15 throughout)
+#pragma unroll
+    for (int j = 0; j < 28; j++) {
+        const int e = tid + 256 * j;
+        yv[j] = e < 7056 ? src[e] : 0.0f;
+    }
+    const float s1 = HAS_BN ? bn[tid & 15] : 1.0f, h1 = HAS_BN ? bn[16 + (tid & 15)] : 0.0f;
     float b[64];
 #pragma unroll
     for (int kk = 0; kk < 64; kk++) {
@@ -153,18 +177,25 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
     }
     float pb = sc * eps[8192 + nt * 16 + lp];
     const float bias = base[8192 + nt * 16 + lp] + pb;
-    __syncthreads();
-    const float *bn = A.bn + (size_t)it.member * 608;
-    const float *src = y1 + (size_t)it.row * 7056;
-    for (int i = tid; i < 7056; i += 256) {
-        const int c = i & 15, pix = i >> 4;
-        float t = src[i];
-        if (HAS_BN) {
-            t = t * bn[c];
-            t = t + bn[16 + c];
+    for (int pix = tid; pix < 24 * 24; pix += 256) {   // zero only the SAME-padding ring (disjoint from the fill)
+        const int y = pix / 24, x = pix % 24;
+        if (y < 1 || y > 21 || x < 1 || x > 21)
+#pragma unroll
+            for (int c = 0; c < 16; c++) a_s[pix * PS + c] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 28; j++) {
+        const int e = tid + 256 * j;
+        if (e < 7056) {
+            const int c = e & 15, pix = e >> 4;
+            float t = yv[j];
+            if (HAS_BN) {
+                t = t * s1;
+                t = t + h1;
+            }
+            t = t > 0.0f ? t : 0.0f;
+            a_s[((pix / 21 + 1) * 24 + pix % 21 + 1) * PS + c] = t;
         }
-        t = t > 0.0f ? t : 0.0f;
-        a_s[((pix / 21 + 1) * 24 + pix % 21 + 1) * PS + c] = t;
     }
     __syncthreads();
     int off[4];
