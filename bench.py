@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--noise-count", type=int, default=250_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-events", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                    "exercise the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--single-device", action="store_true", help="testing aid: every rank uses GPU 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,12 +116,18 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    gather_device = device if args.backend == "nccl" else None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from dne_hip import _lib, es, policies
     n_pairs = args.pop // 2
@@ -144,7 +153,7 @@ def main():
 
     gen = 0
     for _ in range(args.warmup):
-        es.es_generation(engine, noise.noise.size, config, n_pairs, gen, args.tslimit, EXP["optimizer"], rank, world, device)
+        es.es_generation(engine, noise.noise.size, config, n_pairs, gen, args.tslimit, EXP["optimizer"], rank, world, gather_device)
         gen += 1
     barrier()
     t0 = time.time()
@@ -152,7 +161,7 @@ def main():
     fc_ms = fc_launches = fc_units = 0
     stage = {"conv_ms": 0.0, "env_ms": 0.0, "ref_ms": 0.0, "reduce_ms": 0.0, "eval_ms": 0.0}
     for _ in range(args.steps):
-        rec, ratio = es.es_generation(engine, noise.noise.size, config, n_pairs, gen, args.tslimit, EXP["optimizer"], rank, world, device)
+        rec, ratio = es.es_generation(engine, noise.noise.size, config, n_pairs, gen, args.tslimit, EXP["optimizer"], rank, world, gather_device)
         gen += 1
         p = engine.profile()
         steps_local += p["env_steps"]
@@ -161,7 +170,7 @@ def main():
             stage[k] += p[k]
     barrier()
     wall = time.time() - t0
-    tot = torch.tensor([float(steps_local), wall], dtype=torch.float64, device=device)
+    tot = torch.tensor([float(steps_local), wall], dtype=torch.float64, device=gather_device if gather_device is not None else "cpu")
     if world > 1:
         steps_t = tot[0:1].clone(); wall_t = tot[1:2].clone()
         dist.all_reduce(steps_t, op=dist.ReduceOp.SUM)

@@ -169,7 +169,7 @@ struct dne_handle {
     std::string err;
     hipStream_t stream = nullptr;
     std::vector<hipStream_t> sub_streams;   // sub-batch streams (sub_streams[0] == stream)
-    int nsub = 2, sub_min_groups = 256, fc_grid = 256, fc_tail_max = 96;
+    int nsub = 2, sub_min_groups = 256, fc_grid = 512, fc_tail_max = 96, fc_rb = 4;
     int M = 0, F = 0, ref_chunk = 0;
     size_t base_stride = 0;
     // device memory
@@ -364,6 +364,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     h->sub_streams.push_back(h->stream);
     if (const char *e = getenv("DNE_NSUB")) h->nsub = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("DNE_FC_TAIL_MAX")) h->fc_tail_max = std::max(0, atoi(e));
+    if (const char *e = getenv("DNE_FC_RB")) h->fc_rb = atoi(e);
     if (const char *e = getenv("DNE_FC_GRID")) h->fc_grid = std::max(1, atoi(e));
     if (const char *e = getenv("DNE_SUB_MIN_GROUPS")) h->sub_min_groups = std::max(1, atoi(e));
     for (int s = 1; s < h->nsub; s++) { hipStream_t st; CH(hipStreamCreate(&st)); h->sub_streams.push_back(st); }
@@ -603,7 +604,7 @@ static int ref_pass(dne_handle *h, int n) {
         hipLaunchKernelGGL((k_bn_stats<32, 121>), dim3(nc), dim3(256), F * 32 * sizeof(float), h->stream, A, m0, F,
                            (const float *)h->y2, 32, h->L.bn2b, h->L.bn2g);
         const int nfg = F / 8;
-        hipLaunchKernelGGL((k_fc<8, true, true>), dim3((nc + 7) / 8 * 8 * nfg), dim3(256), 0, h->stream, A,
+        hipLaunchKernelGGL((k_fc<8, true, true, 4>), dim3((nc + 7) / 8 * 8 * nfg), dim3(256), 0, h->stream, A,
                            (const int *)nullptr, nc, F, m0, (const float *)h->y2, h->y3, (int32_t *)nullptr,
                            (float *)nullptr);
         hipLaunchKernelGGL((k_bn_stats<256, 1>), dim3(nc), dim3(256), 0, h->stream, A, m0, F, (const float *)h->y3,
@@ -654,9 +655,11 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
 #undef FCT
         return;
     }
-#define FC(NV, BN) hipLaunchKernelGGL((k_fc<NV, false, BN>), dim3(std::min(count, h->fc_grid)), dim3(256), 0, st, A, list, count, 1, 0, (const float *)h->y2, h->y3, h->action, logits)
-    if (gsize == 2) { if (es) FC(2, true); else FC(2, false); }
-    else { if (es) FC(1, true); else FC(1, false); }
+#define FC(NV, BN, RB) hipLaunchKernelGGL((k_fc<NV, false, BN, RB>), dim3(std::min(count, h->fc_grid)), dim3(256), 0, st, A, list, count, 1, 0, (const float *)h->y2, h->y3, h->action, logits)
+#define FCR(NV, BN) do { if (h->fc_rb == 2) FC(NV, BN, 2); else if (h->fc_rb == 8) FC(NV, BN, 8); else FC(NV, BN, 4); } while (0)
+    if (gsize == 2) { if (es) FCR(2, true); else FCR(2, false); }
+    else { if (es) FCR(1, true); else FCR(1, false); }
+#undef FCR
 #undef FC
 }
 

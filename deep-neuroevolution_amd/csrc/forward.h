@@ -243,7 +243,7 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-template <int NV, bool SHARED_W, bool HAS_BN>
+template <int NV, bool SHARED_W, bool HAS_BN, int RB>
 __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ list, int n_local, int F, int member0,
                                             const float *__restrict__ y2, float *__restrict__ y3,
                                             int32_t *__restrict__ actions, float *__restrict__ logits_out) {
@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
     // step mode is persistent: a bounded grid walks the active groups, so the kernel occupies only a slice of
     // every CU (it is HBM-bound and needs few waves) and leaves room for the conv / emulator kernels that
     // run concurrently on the other sub-batch streams.  Reference mode launches one block per work item.
+    if (!SHARED_W) __builtin_amdgcn_s_setprio(3);   // keep the HBM stream's load issue ahead of co-resident conv / emulator waves
     for (int item = blockIdx.x; item < (SHARED_W ? (int)blockIdx.x + 1 : n_local); item += gridDim.x) {
     int member[NV], row[NV];
     float scale[NV];
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
             dst[v] = t;
         }
     };
-    constexpr int RB = 8;
+    // RB rows per batch (968 and 64 are multiples of 2, 4 and 8)
     f4u e_cur[RB], e_nxt[RB];
     f4a t_cur[RB], t_nxt[RB];
     float xv[NV], xn[NV];
@@ -320,8 +321,9 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
         e_cur[i] = *(const f4u *)(eps + ro);
         t_cur[i] = *(const f4a *)(th + ro);
     }
-    for (int bt = 0; bt < 121; bt++) {
-        if (bt + 1 < 121) {
+    constexpr int NB = 968 / RB, BPC = 64 / RB;   // batches per slice, batches per 64-row activation chunk
+    for (int bt = 0; bt < NB; bt++) {
+        if (bt + 1 < NB) {
 #pragma unroll
             for (int i = 0; i < RB; i++) {
                 const size_t ro = (size_t)(kbeg + (bt + 1) * RB + i) * 256;
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
                 t_nxt[i] = *(const f4a *)(th + ro);
             }
         }
-        const int li = (bt & 7) * RB;
+        const int li = (bt % BPC) * RB;
 #pragma unroll
         for (int i = 0; i < RB; i++) {
             if (SHARED_W) {
@@ -357,10 +359,10 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
         }
 #pragma unroll
         for (int i = 0; i < RB; i++) { e_cur[i] = e_nxt[i]; t_cur[i] = t_nxt[i]; }
-        if ((bt & 7) == 7) {   // chunk boundary: rotate the activation registers, prefetch the chunk after next
+        if (bt % BPC == BPC - 1) {   // chunk boundary: rotate the activation registers, prefetch the chunk after next
 #pragma unroll
             for (int v = 0; v < NV; v++) xv[v] = xn[v];
-            load_x((bt >> 3) + 2, xn);
+            load_x(bt / BPC + 2, xn);
         }
     }
 #pragma unroll
