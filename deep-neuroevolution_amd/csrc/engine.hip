@@ -185,7 +185,7 @@ struct dne_handle {
     float *ret = nullptr, *sign = nullptr, *step_reward = nullptr, *logits = nullptr;
     int32_t *len = nullptr, *done = nullptr, *action = nullptr, *stepped = nullptr;
     uint32_t *seeds = nullptr;
-    float *y1 = nullptr, *y2 = nullptr, *y3 = nullptr; size_t rows_cap = 0;
+    float *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *y3p = nullptr; size_t rows_cap = 0;
     int *list_a = nullptr, *list_b = nullptr, *count_dev = nullptr;
     uint8_t *bc = nullptr; size_t bc_bytes = 0;
     float *mat_out = nullptr; size_t mat_cap = 0;
@@ -400,6 +400,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipMemset(h->done, 0, M * sizeof(int32_t))); CH(hipMemset(h->len, 0, M * sizeof(int32_t)));
     h->rows_cap = std::max<size_t>(M, (size_t)h->ref_chunk * std::max(h->F, 1));
     CH(dalloc(&h->y1, h->rows_cap * 7056)); CH(dalloc(&h->y2, h->rows_cap * 3872)); CH(dalloc(&h->y3, h->rows_cap * 256));
+    if (h->F) CH(dalloc(&h->y3p, (size_t)h->ref_chunk * 4 * h->F * 256));
     CH(dalloc(&h->list_a, M)); CH(dalloc(&h->list_b, M)); CH(dalloc(&h->count_dev, 8));
     if (cfg->record_bc) {
         h->bc_bytes = cfg->policy_kind == DNE_KIND_ES ? M * (size_t)std::max(cfg->bc_max_steps, 1) * 128 : M * 128;
@@ -422,7 +423,7 @@ extern "C" void dne_destroy(dne_handle *h) {
     hipDeviceSynchronize();
     void *ptrs[] = {h->noise, h->bases, h->opt_m, h->opt_v, h->g, h->partial, h->ref, h->m_slot, h->m_off, h->m_scale,
                     h->bn, h->ram_prev, h->ram_cur, h->stacks, h->tables, h->ret, h->sign, h->step_reward, h->logits,
-                    h->len, h->done, h->action, h->seeds, h->stepped, h->y1, h->y2, h->y3, h->list_a, h->list_b, h->count_dev,
+                    h->len, h->done, h->action, h->seeds, h->stepped, h->y1, h->y2, h->y3, h->y3p, h->list_a, h->list_b, h->count_dev,
                     h->bc, h->mat_out, h->scratch_f, h->scratch_i};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -603,12 +604,20 @@ static int ref_pass(dne_handle *h, int n) {
                            (const float *)h->y1, h->y2);
         hipLaunchKernelGGL((k_bn_stats<32, 121>), dim3(nc), dim3(256), F * 32 * sizeof(float), h->stream, A, m0, F,
                            (const float *)h->y2, 32, h->L.bn2b, h->L.bn2g);
-        const int nfg = F / 8;
-        hipLaunchKernelGGL((k_fc<8, true, true, 4>), dim3((nc + 7) / 8 * 8 * nfg), dim3(256), 0, h->stream, A,
-                           (const int *)nullptr, nc, F, m0, (const float *)h->y2, h->y3, (int32_t *)nullptr,
-                           (float *)nullptr);
-        hipLaunchKernelGGL((k_bn_stats<256, 1>), dim3(nc), dim3(256), 0, h->stream, A, m0, F, (const float *)h->y3,
-                           96, h->L.bn3b, h->L.bn3g);
+        if (F == 16 || F == 32 || F == 64 || F == 128) {   // matrix-core path
+            const int grid = (nc + 7) / 8 * 8 * 16;
+#define FCREF(MT) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid), dim3(256), 0, h->stream, A, nc, m0, (const float *)h->y2, h->y3p)
+            if (F == 16) FCREF(1); else if (F == 32) FCREF(2); else if (F == 64) FCREF(4); else FCREF(8);
+#undef FCREF
+            hipLaunchKernelGGL(k_bn3_partials, dim3(nc), dim3(256), 0, h->stream, A, m0, F, (const float *)h->y3p);
+        } else {
+            const int nfg = F / 8;
+            hipLaunchKernelGGL((k_fc<8, true, true, 4>), dim3((nc + 7) / 8 * 8 * nfg), dim3(256), 0, h->stream, A,
+                               (const int *)nullptr, nc, F, m0, (const float *)h->y2, h->y3, (int32_t *)nullptr,
+                               (float *)nullptr);
+            hipLaunchKernelGGL((k_bn_stats<256, 1>), dim3(nc), dim3(256), 0, h->stream, A, m0, F, (const float *)h->y3,
+                               96, h->L.bn3b, h->L.bn3g);
+        }
     }
     HCHECK(h, hipGetLastError());
     return 0;

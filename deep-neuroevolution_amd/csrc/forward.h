@@ -420,6 +420,136 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
     }
 }
 
+// ------------------------------------------------------- fc of the reference pass on the matrix cores
+// Virtual batch norm pushes F reference frames through every member's perturbed network (policies.py:399):
+// per member a [F x 3872] x [3872 x 256] GEMM with member-unique weights.  16 workgroups per member = 4 k-slices
+// x 4 column slabs (kept on one XCD so the member's activations are shared through its L2); wave w owns 16
+// columns and all F frames (MT = F/16 accumulators); activations stream through a double-buffered LDS tile of
+// 44 k-values, weights are formed per lane as theta + sigma*eps straight into the B operand.  The MFMA's
+// k-ordered fmaf chain per slice + the ((s0+s1)+(s2+s3)) + bias combine (k_bn3_partials) are the oracle's order.
+template <int MT>
+__global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int member0, const float *__restrict__ y2,
+                                                float *__restrict__ y3p /*[n_local][4][F][256]*/) {
+    constexpr int F = MT * 16, KC = 44, XS = KC + 1, NST = 968 / KC, KK = KC / 4;
+    constexpr int LD = (F * KC + 255) / 256;
+    __shared__ float xs[2][F * XS];
+    __shared__ float bn2[64];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
+    const Layout &L = A.L;
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int mloc = (q >> 4) * 8 + x, sub = q & 15, sl = sub >> 2, cs = sub & 3;
+    if (mloc >= n_local) return;
+    const int member = member0 + mloc;
+    const float sc = A.m_scale[member];
+    const int kbeg = 968 * sl, col = cs * 64 + wv * 16 + lp;
+    const float *eps = A.noise + A.m_off[member] + L.fcw + (size_t)(kbeg + lk) * 256 + col;
+    const float *th = A.bases + (size_t)A.m_slot[member] * A.base_stride + L.fcw + (size_t)(kbeg + lk) * 256 + col;
+    const float *ysrc = y2 + (size_t)mloc * F * 3872 + kbeg;
+    if (tid < 64) bn2[tid] = A.bn[(size_t)member * 608 + 32 + tid];   // scale[32] then shift[32]
+    float yr[LD], er[KK], tr[KK];
+    auto load_stage = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < LD; j++) {
+            const int e = tid + 256 * j;
+            yr[j] = e < F * KC ? ysrc[(size_t)(e / KC) * 3872 + st * KC + e % KC] : 0.0f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+            const size_t ro = (size_t)(st * KC + 4 * kk) * 256;
+            er[kk] = eps[ro];
+            tr[kk] = th[ro];
+        }
+    };
+    auto store_stage = [&](int st, int buf) {
+#pragma unroll
+        for (int j = 0; j < LD; j++) {
+            const int e = tid + 256 * j;
+            if (e < F * KC) {
+                const int ch = (kbeg + st * KC + e % KC) & 31;
+                float t = yr[j] * bn2[ch];
+                t = t + bn2[32 + ch];
+                xs[buf][(e / KC) * XS + e % KC] = t > 0.0f ? t : 0.0f;
+            }
+        }
+    };
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_stage(0);
+    __syncthreads();          // bn2 visible
+    store_stage(0, 0);
+    float w[KK];
+#pragma unroll
+    for (int kk = 0; kk < KK; kk++) { float pv = sc * er[kk]; w[kk] = tr[kk] + pv; }
+    __syncthreads();
+    for (int st = 0; st < NST; st++) {
+        const int buf = st & 1;
+        if (st + 1 < NST) load_stage(st + 1);
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const float a = xs[buf][(m * 16 + lp) * XS + 4 * kk + lk];
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[kk], acc[m], 0, 0, 0);
+            }
+        }
+        if (st + 1 < NST) {
+            store_stage(st + 1, buf ^ 1);
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) { float pv = sc * er[kk]; w[kk] = tr[kk] + pv; }
+        }
+        __syncthreads();
+    }
+    float *out = y3p + ((size_t)(mloc * 4 + sl) * F) * 256 + col;
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) out[(size_t)(m * 16 + lk * 4 + r) * 256] = acc[m][r];
+}
+
+// bn3 statistics from the four k-slice partials: y3 = ((p0+p1)+(p2+p3)) + bias per frame, then the batch
+// moments over the F frames in frame order (same order as k_bn_stats<256, 1>); one thread per column.
+__global__ __launch_bounds__(256) void k_bn3_partials(FwdArgs A, int member0, int F, const float *__restrict__ y3p) {
+    const int mloc = blockIdx.x, member = member0 + mloc, j = threadIdx.x;
+    const Layout &L = A.L;
+    const float *base = A.bases + (size_t)A.m_slot[member] * A.base_stride;
+    const float *eps = A.noise + A.m_off[member];
+    const float sc = A.m_scale[member];
+    float pbias = sc * eps[L.fcb + j];
+    const float bias = base[L.fcb + j] + pbias;
+    const float *p = y3p + (size_t)mloc * 4 * F * 256 + j;
+    const size_t ss = (size_t)F * 256;
+    const float count = (float)F;
+    float tot = 0.0f;
+    for (int n = 0; n < F; n++) {
+        const float s01 = p[(size_t)n * 256] + p[ss + (size_t)n * 256];
+        const float s23 = p[2 * ss + (size_t)n * 256] + p[3 * ss + (size_t)n * 256];
+        float v = s01 + s23;
+        v = v + bias;
+        tot = tot + (0.0f + v);
+    }
+    const float mean = tot / count;
+    float totq = 0.0f;
+    for (int n = 0; n < F; n++) {
+        const float s01 = p[(size_t)n * 256] + p[ss + (size_t)n * 256];
+        const float s23 = p[2 * ss + (size_t)n * 256] + p[3 * ss + (size_t)n * 256];
+        float v = s01 + s23;
+        v = v + bias;
+        const float d = v - mean;
+        totq = totq + __builtin_fmaf(d, d, 0.0f);
+    }
+    const float var = totq / count;
+    float pb = sc * eps[L.bn3b + j];
+    const float beta = base[L.bn3b + j] + pb;
+    float pg = sc * eps[L.bn3g + j];
+    const float gamma = base[L.bn3g + j] + pg;
+    const float inv = 1.0f / sqrtf(var + 1e-3f);
+    const float s = inv * gamma;
+    const float ms = mean * s;
+    A.bn[(size_t)member * 608 + 96 + j] = s;
+    A.bn[(size_t)member * 608 + 352 + j] = beta - ms;
+}
+
 // ------------------------------------------------------------ fc for small active counts (the tail)
 // When only a few episodes are still running, a lock-step is latency-bound: one workgroup per pair would
 // stream 4 MB through four waves.  Here each pair gets 4 workgroups (one per 64-column quarter), every lane

@@ -364,3 +364,26 @@ def test_ga_driver_on_device(hip, oracle, small_noise, tmp_path):
     sel = oracle.ga_select(r0, 4)
     assert score.max() >= r0[sel[0]]                                # elites are never lost (ga.py:136-137)
     me.close(); we.close()
+
+
+def test_ref_pass_full_reference_batch(hip, oracle, small_noise):
+    """The 128-frame virtual-batch-norm pass of the real configuration (MT = 8 matrix-core path)."""
+    O = oracle
+    L = O.layout(O.KIND_ES, NACT)
+    ref = O.get_ref_batch(seed=0, batch_size=128, nact=NACT)
+    e = hip.Engine(hip.KIND_ES, NACT, max_members=24, ref_count=128, ref_chunk=16)
+    e.noise_upload(small_noise)
+    th = O.es_init_theta(L, 1)
+    e.set_theta(th)
+    e.set_ref_batch(ref)
+    n = 20                       # two chunks (16 + 4) and a partially filled XCD group
+    rs = np.random.RandomState(8)
+    off = rs.randint(0, small_noise.size - L.P, n).astype(np.int64)
+    scale = np.where(np.arange(n) % 2 == 0, 0.02, -0.02).astype(np.float32)
+    e.set_members(np.zeros(n, np.int32), off, scale)
+    e.ref_pass(n)
+    bn = e.get_bn(n)
+    for i in (0, 1, 7, 15, 16, 19):
+        thi = th + np.float32(scale[i]) * small_noise[off[i]:off[i] + L.P]
+        assert np.array_equal(bn[i], O.es_ref_pass(L, thi, ref)), i
+    e.close()
