@@ -169,6 +169,7 @@ struct dne_handle {
     std::string err;
     hipStream_t stream = nullptr;
     std::vector<hipStream_t> sub_streams;   // sub-batch streams (sub_streams[0] == stream)
+    int dbg_skip = 0;   // DNE_DEBUG_SKIP bitmask (timing experiments only): 1 conv1, 2 conv2, 4 render
     int nsub = 2, sub_min_groups = 256, fc_grid = 512, fc_tail_max = 96, fc_rb = 4;
     int M = 0, F = 0, ref_chunk = 0;
     size_t base_stride = 0;
@@ -364,6 +365,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     h->sub_streams.push_back(h->stream);
     if (const char *e = getenv("DNE_NSUB")) h->nsub = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("DNE_FC_TAIL_MAX")) h->fc_tail_max = std::max(0, atoi(e));
+    if (const char *e = getenv("DNE_DEBUG_SKIP")) h->dbg_skip = atoi(e);
     if (const char *e = getenv("DNE_FC_RB")) h->fc_rb = atoi(e);
     if (const char *e = getenv("DNE_FC_GRID")) h->fc_grid = std::max(1, atoi(e));
     if (const char *e = getenv("DNE_SUB_MIN_GROUPS")) h->sub_min_groups = std::max(1, atoi(e));
@@ -522,6 +524,7 @@ static void launch_env_step(dne_handle *h, const EnvArgs &E, const int *list, in
     if (!st) st = h->stream;
     const int items = count * gsize;
     hipLaunchKernelGGL(k_env_logic, dim3((items + 63) / 64), dim3(64), 0, st, E, list, gsize, items, tslimit);
+    if (h->dbg_skip & 4) return;
     hipLaunchKernelGGL(k_env_render, dim3(items), dim3(items <= 192 ? 1024 : 256), 0, st, E, list, gsize, 0);
 }
 
@@ -643,8 +646,10 @@ static void launch_forward(dne_handle *h, const int *list, int count, int gsize,
     if (!st) st = h->stream;
     const FwdArgs A = h->fwd(use_done);
     const bool es = h->L.kind == DNE_KIND_ES;
+    if (!(h->dbg_skip & 1))
     hipLaunchKernelGGL(k_conv1, dim3(count * gsize), dim3(256), 0, st, A, list, gsize, 1, 0,
                        (const uint8_t *)h->stacks, (const uint8_t *)nullptr, h->y1);
+    if (h->dbg_skip & 2) return;
     if (es) hipLaunchKernelGGL((k_conv2<true>), dim3(count * gsize), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2);
     else hipLaunchKernelGGL((k_conv2<false>), dim3(count * gsize), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2);
 }
@@ -664,7 +669,8 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
 #undef FCT
         return;
     }
-#define FC(NV, BN, RB) hipLaunchKernelGGL((k_fc<NV, false, BN, RB>), dim3(std::min(count, h->fc_grid)), dim3(256), 0, st, A, list, count, 1, 0, (const float *)h->y2, h->y3, h->action, logits)
+    const int fc_blocks = std::min(count, h->fc_grid);   // persistent grid (an even groups-per-block split measured slower)
+#define FC(NV, BN, RB) hipLaunchKernelGGL((k_fc<NV, false, BN, RB>), dim3(fc_blocks), dim3(256), 0, st, A, list, count, 1, 0, (const float *)h->y2, h->y3, h->action, logits)
 #define FCR(NV, BN) do { if (h->fc_rb == 2) FC(NV, BN, 2); else if (h->fc_rb == 8) FC(NV, BN, 8); else FC(NV, BN, 4); } while (0)
     if (gsize == 2) { if (es) FCR(2, true); else FCR(2, false); }
     else { if (es) FCR(1, true); else FCR(1, false); }
