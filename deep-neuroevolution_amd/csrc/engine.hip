@@ -38,6 +38,7 @@ struct EnvArgs {
     float *ret, *sign, *step_reward; // [M]
     int32_t *len, *done, *stepped;
     const int32_t *action;
+    int32_t *step_counter;           // one counter per launch set: members actually stepped (profiling)
     uint8_t *bc;
     int bc_mode;                     // 0 none, 1 RAM per step (ES, policies.py:410,418), 2 final RAM (GA, policies.py:510)
     int bc_max_steps;
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(64) void k_env_logic(EnvArgs E, const int *__restri
     E.step_reward[m] = (float)r;
     E.len[m] = t + 1;
     E.stepped[m] = 1;
+    if (E.step_counter) atomicAdd(E.step_counter, 1);
     if (over || t + 1 >= tslimit) E.done[m] = 1;             // policies.py:401,424-425
 }
 
@@ -185,6 +187,7 @@ struct dne_handle {
     ResizeLds *tables = nullptr;
     float *ret = nullptr, *sign = nullptr, *step_reward = nullptr, *logits = nullptr;
     int32_t *len = nullptr, *done = nullptr, *action = nullptr, *stepped = nullptr;
+    int32_t *launch_units = nullptr; size_t launch_units_cap = 0;
     uint32_t *seeds = nullptr;
     float *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *y3p = nullptr; size_t rows_cap = 0;
     int *list_a = nullptr, *list_b = nullptr, *count_dev = nullptr;
@@ -220,7 +223,7 @@ struct dne_handle {
     EnvArgs env(int bc_mode) const {
         EnvArgs E;
         E.ram_prev = ram_prev; E.ram_cur = ram_cur; E.stacks = stacks; E.T = tables;
-        E.ret = ret; E.sign = sign; E.step_reward = step_reward; E.len = len; E.done = done; E.stepped = stepped; E.action = action;
+        E.ret = ret; E.sign = sign; E.step_reward = step_reward; E.len = len; E.done = done; E.stepped = stepped; E.action = action; E.step_counter = nullptr;
         E.bc = bc; E.bc_mode = bc ? bc_mode : 0; E.bc_max_steps = cfg.bc_max_steps;
         return E;
     }
@@ -425,7 +428,7 @@ extern "C" void dne_destroy(dne_handle *h) {
     hipDeviceSynchronize();
     void *ptrs[] = {h->noise, h->bases, h->opt_m, h->opt_v, h->g, h->partial, h->ref, h->m_slot, h->m_off, h->m_scale,
                     h->bn, h->ram_prev, h->ram_cur, h->stacks, h->tables, h->ret, h->sign, h->step_reward, h->logits,
-                    h->len, h->done, h->action, h->seeds, h->stepped, h->y1, h->y2, h->y3, h->y3p, h->list_a, h->list_b, h->count_dev,
+                    h->len, h->done, h->action, h->seeds, h->stepped, h->launch_units, h->y1, h->y2, h->y3, h->y3p, h->list_a, h->list_b, h->count_dev,
                     h->bc, h->mat_out, h->scratch_f, h->scratch_i};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -736,10 +739,21 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
         subs[s].count_dev = h->count_dev + s;
         subs[s].ev0 = 0;
     }
-    const EnvArgs E = h->env(bc_mode);
+    EnvArgs E = h->env(bc_mode);
     int t = 0;
     long long group_steps = 0;
-    std::vector<std::array<size_t, 4>> evs;   // per launch set: event indices {before, after conv, after fc, after env}
+    std::vector<std::array<size_t, 4>> evs;
+    std::vector<char> ev_full;   // per launch set: did it use the streaming kernel (k_fc) rather than the tail path
+    if (prof) {
+        const size_t need = (size_t)nsub * (size_t)tslimit + 64;
+        if (need > h->launch_units_cap) {
+            if (h->launch_units) HCHECK(h, hipFree(h->launch_units));
+            HCHECK(h, dalloc(&h->launch_units, need));
+            h->launch_units_cap = need;
+        }
+        HCHECK(h, hipMemsetAsync(h->launch_units, 0, need * sizeof(int32_t), h->stream));
+        HCHECK(h, hipStreamSynchronize(h->stream));
+    }   // per launch set: event indices {before, after conv, after fc, after env}
     auto total = [&]() { int c = 0; for (auto &s : subs) c += s.count; return c; };
     hipEvent_t last_fc = nullptr;
     size_t fc_ring_pos = 0;
@@ -759,8 +773,9 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 launch_fc(h, s.cur, s.count, gsize, nullptr, s.st);
                 if (nsub > 1) { last_fc = h->fc_ring[fc_ring_pos++ % h->fc_ring.size()]; HCHECK(h, hipEventRecord(last_fc, s.st)); }
                 if (prof) { e[2] = ne++; HCHECK(h, hipEventRecord(h->event(e[2]), s.st)); }
+                E.step_counter = prof ? h->launch_units + evs.size() : nullptr;
                 launch_env_step(h, E, s.cur, s.count, gsize, tslimit, s.st);
-                if (prof) { e[3] = ne++; HCHECK(h, hipEventRecord(h->event(e[3]), s.st)); evs.push_back(e); }
+                if (prof) { e[3] = ne++; HCHECK(h, hipEventRecord(h->event(e[3]), s.st)); evs.push_back(e); ev_full.push_back(s.count > h->fc_tail_max); }
                 s.step_counts.push_back(s.count);
                 group_steps += s.count;
             }
@@ -796,12 +811,17 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     P.fc_group_steps = group_steps;
     P.env_steps = 0;
     for (int i = 0; i < n; i++) P.env_steps += lengths[i];
+    P.fc_full_ms = P.fc_full_launches = P.fc_full_units = 0;
     if (prof) {
         HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[0], h->ev_pool[1]));
         P.ref_ms = ms;
-        for (auto &e : evs) {
+        std::vector<int32_t> units(evs.size());
+        if (!evs.empty()) HCHECK(h, hipMemcpy(units.data(), h->launch_units, evs.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < evs.size(); i++) {
+            const auto &e = evs[i];
             HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e[0]], h->ev_pool[e[1]])); P.conv_ms += ms;
             HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e[1]], h->ev_pool[e[2]])); P.fc_ms += ms;
+            if (ev_full[i]) { P.fc_full_ms += ms; P.fc_full_launches += 1; P.fc_full_units += units[i]; }
             HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e[2]], h->ev_pool[e[3]])); P.env_ms += ms;
         }
     }

@@ -699,8 +699,7 @@ __global__ __launch_bounds__(256) void k_bn_stats(FwdArgs A, int member0, int F,
             const int n = i / C, c = i % C;
             const float *p = ym + (size_t)n * NPOS * C + c;
             float s = 0.0f;
-#pragma unroll 9
-            for (int q = 0; q < NPOS; q++) s = s + p[(size_t)q * C];   // loads batch, the adds stay sequential
+            for (int q = 0; q < NPOS; q++) s = s + p[(size_t)q * C];
             bn_part[i] = s;
         }
         __syncthreads();
@@ -717,7 +716,6 @@ __global__ __launch_bounds__(256) void k_bn_stats(FwdArgs A, int member0, int F,
             const float *p = ym + (size_t)n * NPOS * C + c;
             const float mean = mean_s[c];
             float qv = 0.0f;
-#pragma unroll 9
             for (int q = 0; q < NPOS; q++) {
                 float d = p[(size_t)q * C] - mean;
                 qv = __builtin_fmaf(d, d, qv);

@@ -36,7 +36,8 @@ class Profile(C.Structure):
     _fields_ = [("eval_ms", C.c_double), ("fc_ms", C.c_double), ("fc_launches", C.c_int64),
                 ("fc_group_steps", C.c_int64), ("env_steps", C.c_int64), ("conv_ms", C.c_double),
                 ("env_ms", C.c_double), ("ref_ms", C.c_double), ("reduce_ms", C.c_double),
-                ("materialize_ms", C.c_double), ("reserved", C.c_double * 6)]
+                ("materialize_ms", C.c_double), ("fc_full_ms", C.c_double), ("fc_full_launches", C.c_double),
+                ("fc_full_units", C.c_double), ("reserved", C.c_double * 3)]
 
 
 def build(force=False):

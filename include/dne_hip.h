@@ -58,7 +58,11 @@ typedef struct { /* filled by dne_get_profile; times from HIP events on the engi
     double conv_ms, env_ms, ref_ms; /* other stages of the last eval (0 if not profiled) */
     double reduce_ms;     /* last dne_weighted_sum / dne_es_update aggregate kernel */
     double materialize_ms;/* last dne_materialize kernel */
-    double reserved[6];
+    /* the streaming kernel proper (k_fc), without the small-count tail path (k_fc_cols + k_out) */
+    double fc_full_ms;
+    double fc_full_launches;
+    double fc_full_units; /* env-steps (member-steps actually taken) processed by those launches */
+    double reserved[3];
 } dne_profile;
 
 /* ---- lifecycle ------------------------------------------------------------------------------------ */
