@@ -1,0 +1,107 @@
+"""GPU, BASELINE.json full sizes (pop 5000 = 2500 antithetic pairs, the 250M-entry noise table, P = 1 009 058):
+size-independent properties + spot checks against the oracle, where a full oracle run would take hours."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_PAIRS, NACT = 2500, 18
+
+
+@pytest.fixture(scope="module")
+def full(oracle):
+    from dne_hip import _lib, es, policies
+    noise = es.SharedNoiseTable()                                    # es.py:51-61, 250M entries
+    e = _lib.Engine(_lib.KIND_ES, NACT, max_members=2 * N_PAIRS, ref_count=128)
+    noise.attach(e)
+    th = policies.xavier_flat(NACT, 0)
+    e.set_theta(th)
+    ref = oracle.get_ref_batch(seed=0, batch_size=128, nact=NACT)
+    e.set_ref_batch(ref)
+    yield e, noise, th, ref
+    e.close()
+
+
+def test_noise_table_golden(full, golden):
+    _, noise, _, _ = full
+    assert noise.noise.size == 250_000_000
+    assert noise.noise[:8].view(np.uint32).tolist() == [3213555186, 1065308680, 1049682575, 3217083972, 3205766949,
+                                                        1070817862, 3223015094, 3202062960]
+    assert noise.noise[-3:].view(np.uint32).tolist() == [3158718917, 3219242230, 1075127793]
+    if "noise_full_sha256" in golden.files:
+        import hashlib
+        assert hashlib.sha256(noise.noise.tobytes()).digest() == golden["noise_full_sha256"].tobytes()
+
+
+def test_aggregate_properties_full_size(full, oracle):
+    e, noise, th, _ = full
+    P = e.P
+    srs = np.random.RandomState(0)
+    idx = np.array([noise.sample_index(srs, P) for _ in range(N_PAIRS)], np.int64)
+    assert idx[:4].tolist() == [209652396, 130329135, 118924917, 136432832]
+    rets = (10 * np.random.RandomState(1).poisson(20, (N_PAIRS, 2))).astype(np.float32)               # SURVEY 8d aggregate micro-benchmark
+    proc = e.centered_ranks(rets)
+    assert np.array_equal(proc, oracle.centered_ranks(rets.reshape(-1)).reshape(rets.shape))
+    assert proc.min() == -0.5 and proc.max() == 0.5 and abs(float(proc.sum())) < 1e-3
+    w = proc[:, 0] - proc[:, 1]
+    g = e.weighted_sum(idx, w, rets.size)
+    assert g.shape == (P,) and g.dtype == np.float32                                                   # es.py:297
+    # one-hot weights select exactly one slice; homogeneity; antisymmetry; additivity within fp32 round-off
+    onehot = np.zeros(N_PAIRS, np.float32); onehot[1234] = 1.0
+    assert np.array_equal(e.weighted_sum(idx, onehot, 1.0), noise.get(idx[1234], P))
+    assert np.array_equal(e.weighted_sum(idx, -w, rets.size), -g)
+    assert np.array_equal(e.weighted_sum(idx, 2 * w, rets.size), 2 * g)
+    half = w.copy(); half[N_PAIRS // 2:] = 0
+    rest = w - half
+    gs = e.weighted_sum(idx, half, rets.size) + e.weighted_sum(idx, rest, rets.size)
+    assert np.abs(gs - g).max() < 1e-5 * max(1.0, np.abs(g).max())
+    # spot check 4096 parameters against the reference formulation in float64
+    ps = np.random.RandomState(2).randint(0, P, 4096)
+    ref = np.zeros(4096)
+    for i in range(N_PAIRS):
+        ref += float(w[i]) * noise.noise[idx[i] + ps].astype(np.float64)
+    assert np.abs(g[ps] - ref / rets.size).max() < 1e-5
+    # full update vs the oracle's Adam on the same g
+    e.optimizer_reset(); e.set_theta(th)
+    e.es_update(idx, rets, None, "centered_rank", "adam", 0.005, 0.01)
+    opt = oracle.Adam(th, 0.01)
+    _, oth = opt.update(g, 0.005)
+    assert np.array_equal(e.get_theta(), oth)
+    e.set_theta(th)
+
+
+def test_materialize_full_table(full):
+    e, noise, th, _ = full
+    idx = np.array([0, 248_990_942, 125_000_001], np.int64)          # first, last legal and an odd-aligned index
+    out = e.materialize(idx, 0.02)
+    for i, ix in enumerate(idx):
+        v = np.float32(0.02) * noise.get(ix, e.P)
+        assert np.array_equal(out[i, 0], th + v) and np.array_equal(out[i, 1], th - v)
+    assert np.abs((out[:, 0] + out[:, 1]) / 2 - th).max() < 1e-5     # gpu_implementation/es.py:182-183
+    with pytest.raises(Exception):
+        e.materialize(np.array([248_990_943], np.int64), 0.02)        # one past the last legal index
+
+
+def test_population_eval_properties(full, oracle):
+    from dne_hip import es
+    e, noise, th, ref = full
+    L = oracle.layout(oracle.KIND_ES, NACT)
+    tslimit = 40
+    _, idx, seeds = es.generation_inputs(noise.noise.size, e.P, N_PAIRS, 0, 0, 1)
+    ret, sg, ln = e.es_eval(idx, 0.02, tslimit, seeds)
+    assert ret.shape == sg.shape == ln.shape == (N_PAIRS, 2) and ret.dtype == np.float32 and ln.dtype == np.int32
+    assert ln.min() >= 1 and ln.max() <= tslimit
+    assert np.all(ret >= 0) and np.all(np.mod(ret, 10) == 0)         # SynthAtari rewards are multiples of 10
+    assert np.all(sg <= ret / 10 + 1e-6) and np.all((sg > 0) == (ret > 0))
+    ret2, sg2, ln2 = e.es_eval(idx, 0.02, tslimit, seeds)            # idempotent: no hidden state between evaluations
+    assert np.array_equal(ret, ret2) and np.array_equal(sg, sg2) and np.array_equal(ln, ln2)
+    # permutation equivariance: a member's result does not depend on its slot or on which sub-batch stream ran it
+    perm = np.random.RandomState(3).permutation(N_PAIRS)
+    retp, sgp, lnp = e.es_eval(idx[perm], 0.02, tslimit, seeds.reshape(-1, 2)[perm].reshape(-1))
+    assert np.array_equal(retp, ret[perm]) and np.array_equal(lnp, ln[perm]) and np.array_equal(sgp, sg[perm])
+    # spot-check pairs against the oracle
+    for i in (0, 1249, 1250, 2499, 777):
+        oret, osg, oln = oracle.es_eval(L, th, noise.noise, idx[i:i + 1], 0.02, tslimit, ref, seeds[2 * i:2 * i + 2])
+        assert np.array_equal(oret[0], ret[i]) and np.array_equal(oln[0], ln[i]) and np.array_equal(osg[0], sg[i]), i
