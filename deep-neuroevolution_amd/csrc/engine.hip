@@ -603,11 +603,11 @@ static int ref_pass(dne_handle *h, int n) {
     for (int m0 = 0; m0 < n; m0 += h->ref_chunk) {
         const int nc = std::min(h->ref_chunk, n - m0);
         hipLaunchKernelGGL(k_conv1, dim3(nc * F), dim3(256), 0, h->stream, A, (const int *)nullptr, 1, F, m0,
-                           (const uint8_t *)h->stacks, (const uint8_t *)h->ref, h->y1);
+                           (const uint8_t *)h->stacks, (const uint8_t *)h->ref, h->y1, 1);
         hipLaunchKernelGGL((k_bn_stats<16, 441>), dim3(nc), dim3(256), F * 16 * sizeof(float), h->stream, A, m0, F,
                            (const float *)h->y1, 0, h->L.bn1b, h->L.bn1g);
         hipLaunchKernelGGL((k_conv2<true>), dim3(nc * F), dim3(256), 0, h->stream, A, (const int *)nullptr, 1, F, m0,
-                           (const float *)h->y1, h->y2);
+                           (const float *)h->y1, h->y2, 1);
         hipLaunchKernelGGL((k_bn_stats<32, 121>), dim3(nc), dim3(256), F * 32 * sizeof(float), h->stream, A, m0, F,
                            (const float *)h->y2, 32, h->L.bn2b, h->L.bn2g);
         if (F == 16 || F == 32 || F == 64 || F == 128) {   // matrix-core path
@@ -649,12 +649,14 @@ static void launch_forward(dne_handle *h, const int *list, int count, int gsize,
     if (!st) st = h->stream;
     const FwdArgs A = h->fwd(use_done);
     const bool es = h->L.kind == DNE_KIND_ES;
+    const int items = count * gsize;
+    const int s1 = items <= 64 ? 4 : 1, s2 = items <= 128 ? 2 : 1;   // few members left: several workgroups per member
     if (!(h->dbg_skip & 1))
-    hipLaunchKernelGGL(k_conv1, dim3(count * gsize), dim3(256), 0, st, A, list, gsize, 1, 0,
-                       (const uint8_t *)h->stacks, (const uint8_t *)nullptr, h->y1);
+    hipLaunchKernelGGL(k_conv1, dim3(items * s1), dim3(256), 0, st, A, list, gsize, 1, 0,
+                       (const uint8_t *)h->stacks, (const uint8_t *)nullptr, h->y1, s1);
     if (h->dbg_skip & 2) return;
-    if (es) hipLaunchKernelGGL((k_conv2<true>), dim3(count * gsize), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2);
-    else hipLaunchKernelGGL((k_conv2<false>), dim3(count * gsize), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2);
+    if (es) hipLaunchKernelGGL((k_conv2<true>), dim3(items * s2), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2, s2);
+    else hipLaunchKernelGGL((k_conv2<false>), dim3(items * s2), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2, s2);
 }
 
 static void launch_fc(dne_handle *h, const int *list, int count, int gsize, float *logits, hipStream_t st = nullptr) {
@@ -665,7 +667,7 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
 #define FCT(NV, BN)                                                                                                          \
     do {                                                                                                                     \
         hipLaunchKernelGGL((k_fc_cols<NV, BN>), dim3(count * 4), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3);    \
-        hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(64), 0, st, A, list, (const float *)h->y3, h->action, logits); \
+        hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3, h->action, logits); \
     } while (0)
         if (gsize == 2) { if (es) FCT(2, true); else FCT(2, false); }
         else { if (es) FCT(1, true); else FCT(1, false); }
@@ -763,19 +765,21 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
             for (auto &s : subs) {
                 if (s.count == 0) continue;
                 std::array<size_t, 4> e{};
-                if (prof) { e[0] = ne++; HCHECK(h, hipEventRecord(h->event(e[0]), s.st)); }
+                // events only around full-width launches: in the latency-bound tail every event packet is a bubble
+                const bool pe = prof && s.count > h->fc_tail_max;
+                if (pe) { e[0] = ne++; HCHECK(h, hipEventRecord(h->event(e[0]), s.st)); }
                 launch_forward(h, s.cur, s.count, gsize, true, s.st);
                 // the fc kernels of all sub-batches take turns on the HBM pipe: each one waits for the previous
                 // one (on another stream), which keeps the sub-batches in anti-phase -- conv / emulator work of
                 // one sub-batch always runs under the fc stream of the other
                 if (nsub > 1 && last_fc) HCHECK(h, hipStreamWaitEvent(s.st, last_fc, 0));
-                if (prof) { e[1] = ne++; HCHECK(h, hipEventRecord(h->event(e[1]), s.st)); }   // after the wait: brackets fc only
+                if (pe) { e[1] = ne++; HCHECK(h, hipEventRecord(h->event(e[1]), s.st)); }   // after the wait: brackets fc only
                 launch_fc(h, s.cur, s.count, gsize, nullptr, s.st);
                 if (nsub > 1) { last_fc = h->fc_ring[fc_ring_pos++ % h->fc_ring.size()]; HCHECK(h, hipEventRecord(last_fc, s.st)); }
-                if (prof) { e[2] = ne++; HCHECK(h, hipEventRecord(h->event(e[2]), s.st)); }
-                E.step_counter = prof ? h->launch_units + evs.size() : nullptr;
+                if (pe) { e[2] = ne++; HCHECK(h, hipEventRecord(h->event(e[2]), s.st)); }
+                E.step_counter = pe ? h->launch_units + evs.size() : nullptr;
                 launch_env_step(h, E, s.cur, s.count, gsize, tslimit, s.st);
-                if (prof) { e[3] = ne++; HCHECK(h, hipEventRecord(h->event(e[3]), s.st)); evs.push_back(e); ev_full.push_back(s.count > h->fc_tail_max); }
+                if (pe) { e[3] = ne++; HCHECK(h, hipEventRecord(h->event(e[3]), s.st)); evs.push_back(e); ev_full.push_back(1); }
                 s.step_counts.push_back(s.count);
                 group_steps += s.count;
             }

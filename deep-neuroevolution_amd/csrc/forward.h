@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace dne {
 
@@ -77,8 +78,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict__ list, int gsize, int F, int member0,
                                                const uint8_t *__restrict__ stacks, const uint8_t *__restrict__ ref,
-                                               float *__restrict__ y1) {
-    const Item it = decode_item(blockIdx.x, list, gsize, F, member0, stacks, ref, A.done);
+                                               float *__restrict__ y1, int nsplit) {
+    // nsplit = 4 (few members left): four workgroups share one member's 28 position tiles to cut the latency
+    const int part = blockIdx.x % nsplit;
+    const Item it = decode_item(blockIdx.x / nsplit, list, gsize, F, member0, stacks, ref, A.done);
     if (it.skip) return;
     __shared__ float lut[256];
     __shared__ uint32_t img[88 * 88];
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict_
     }
     __syncthreads();
     float *out = y1 + (size_t)it.row * 7056;
-    for (int j = 0; j < 8; j += 2) {
+    for (int j = nsplit == 4 ? 2 * part : 0; j < (nsplit == 4 ? 2 * part + 2 : 8); j += 2) {
         const int tA = wv + 4 * j, tB = wv + 4 * (j + 1);
         const bool hasB = j + 1 < 7;
         const int pA = min(tA * 16 + lp, 440), pB = hasB ? min(tB * 16 + lp, 440) : 0;
@@ -149,8 +152,9 @@ __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict_
 // perturbed weights of 16 output channels) live in 64 VGPRs, A comes from the padded activation image in LDS.
 template <bool HAS_BN>
 __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict__ list, int gsize, int F, int member0,
-                                               const float *__restrict__ y1, float *__restrict__ y2) {
-    const Item it = decode_item(blockIdx.x, list, gsize, F, member0, nullptr, nullptr, A.done);
+                                               const float *__restrict__ y1, float *__restrict__ y2, int nsplit) {
+    const int part = blockIdx.x % nsplit;   // nsplit = 2: two workgroups share one member's position tiles
+    const Item it = decode_item(blockIdx.x / nsplit, list, gsize, F, member0, nullptr, nullptr, A.done);
     if (it.skip) return;
     constexpr int PS = 17;   // LDS pixel stride (16 channels + 1 pad)
     __shared__ float a_s[24 * 24 * PS];
@@ -198,37 +202,43 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
         }
     }
     __syncthreads();
-    int off[4];
-    f32x4 acc[4];
+    auto run = [&](auto ntl_) {
+        constexpr int NTL = decltype(ntl_)::value;                   // position tiles per wave: 4, or 2 when split
+        const int mtb = mt0 + (NTL == 2 ? 2 * part : 0);
+        int off[NTL];
+        f32x4 acc[NTL];
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const int p = min((mt0 + m) * 16 + lp, 120);
-        off[m] = ((p / 11) * 2 * 24 + (p % 11) * 2) * PS + lk;
-        acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+        for (int m = 0; m < NTL; m++) {
+            const int p = min((mtb + m) * 16 + lp, 120);
+            off[m] = ((p / 11) * 2 * 24 + (p % 11) * 2) * PS + lk;
+            acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-    for (int kh = 0; kh < 4; kh++) {
+        for (int kh = 0; kh < 4; kh++) {
 #pragma unroll
-        for (int kw = 0; kw < 4; kw++) {
+            for (int kw = 0; kw < 4; kw++) {
 #pragma unroll
-            for (int c4 = 0; c4 < 4; c4++) {   // k = (kh*4+kw)*16 + c4*4 + (l>>4)
-                const int kk = (kh * 4 + kw) * 4 + c4;
+                for (int c4 = 0; c4 < 4; c4++) {   // k = (kh*4+kw)*16 + c4*4 + (l>>4)
+                    const int kk = (kh * 4 + kw) * 4 + c4;
 #pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const float x = a_s[off[m] + (kh * 24 + kw) * PS + c4 * 4];
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, b[kk], acc[m], 0, 0, 0);
+                    for (int m = 0; m < NTL; m++) {
+                        const float x = a_s[off[m] + (kh * 24 + kw) * PS + c4 * 4];
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, b[kk], acc[m], 0, 0, 0);
+                    }
                 }
             }
         }
-    }
-    float *o = y2 + (size_t)it.row * 3872;
+        float *o = y2 + (size_t)it.row * 3872;
 #pragma unroll
-    for (int m = 0; m < 4; m++)
+        for (int m = 0; m < NTL; m++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {   // D[row = 4*(l>>4) + r][col = l&15]
-            const int pos = (mt0 + m) * 16 + lk * 4 + r;
-            if (pos < 121) o[pos * 32 + nt * 16 + lp] = acc[m][r] + bias;
-        }
+            for (int r = 0; r < 4; r++) {   // D[row = 4*(l>>4) + r][col = l&15]
+                const int pos = (mtb + m) * 16 + lk * 4 + r;
+                if (pos < 121) o[pos * 32 + nt * 16 + lp] = acc[m][r] + bias;
+            }
+    };
+    if (nsplit == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 4>{});
 }
 
 // ------------------------------------------------------------------------- fc (+ out + argmax)
@@ -628,9 +638,9 @@ __global__ __launch_bounds__(256) void k_fc_cols(FwdArgs A, const int *__restric
     }
 }
 
-// bn3 + relu + out layer (256 x nact, k-ordered chain) + first-max argmax from y3, one wave per group
+// bn3 + relu + out layer (256 x nact, k-ordered chain) + first-max argmax from y3, one workgroup per group
 template <int NV, bool HAS_BN>
-__global__ __launch_bounds__(64) void k_out(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y3,
+__global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y3,
                                             int32_t *__restrict__ actions, float *__restrict__ logits_out) {
     __shared__ float a3[NV][256];
     __shared__ float lg[NV][32];
@@ -641,7 +651,7 @@ __global__ __launch_bounds__(64) void k_out(FwdArgs A, const int *__restrict__ l
 #pragma unroll
     for (int v = 0; v < NV; v++) {
         const int m = g * NV + v;
-        for (int j = tid; j < 256; j += 64) {
+        for (int j = tid; j < 256; j += 256) {
             float t = y3[(size_t)m * 256 + j];
             if (HAS_BN) {
                 t = t * A.bn[(size_t)m * 608 + 96 + j];
@@ -650,21 +660,30 @@ __global__ __launch_bounds__(64) void k_out(FwdArgs A, const int *__restrict__ l
             a3[v][j] = t > 0.0f ? t : 0.0f;
         }
     }
+    // the (256 x nact) output weights of every member are staged by the whole wave in a few load batches (the
+    // chain below is latency-bound: 256 dependent fmaf per logit)
+    __shared__ float wo[NV][256 * 32];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        const int m = g * NV + v;
+        const float sc = A.m_scale[m];
+        const float *wb = A.bases + (size_t)A.m_slot[m] * A.base_stride + L.ow;
+        const float *we = A.noise + A.m_off[m] + L.ow;
+#pragma unroll 8
+        for (int i = tid; i < 256 * nact; i += 256) {
+            float pv = sc * we[i];
+            wo[v][i] = wb[i] + pv;
+        }
+    }
     __syncthreads();
     if (tid < NV * nact) {
         const int v = tid / nact, a = tid % nact, m = g * NV + v;
         const float sc = A.m_scale[m];
         const int64_t off = A.m_off[m];
         const float *base = A.bases + (size_t)A.m_slot[m] * A.base_stride;
-        const float *wb = base + L.ow + a;
-        const float *we = A.noise + off + L.ow + a;
         float s = 0.0f;
 #pragma unroll 16
-        for (int k = 0; k < 256; k++) {
-            float pv = sc * we[k * nact];
-            float w = wb[k * nact] + pv;
-            s = __builtin_fmaf(a3[v][k], w, s);
-        }
+        for (int k = 0; k < 256; k++) s = __builtin_fmaf(a3[v][k], wo[v][k * nact + a], s);
         float pv = sc * A.noise[off + L.ob + a];
         const float bias = base[L.ob + a] + pv;
         lg[v][a] = s + bias;

@@ -25,8 +25,8 @@ for rep in range(a.reps):
     n = p["fc_launches"]
     print(json.dumps({"rep": rep, "wall_s": wall, "steps": int(ln.sum()), "launches": n,
                       "per_step_ms": {k: p[k] / n for k in ("conv_ms", "fc_ms", "env_ms")}, "ref_ms": p["ref_ms"],
-                      "fc_GBps_alg": p["env_steps"] * 4064456 / (p["fc_ms"] * 1e-3) / 1e9,
-                      "fc_GBps_stream": p["fc_group_steps"] * 3872 * 256 * 4 / (p["fc_ms"] * 1e-3) / 1e9}))
+                      "fc_GBps_alg": p["fc_full_units"] * 4064456 / (max(p["fc_full_ms"], 1e-9) * 1e-3) / 1e9,
+                      "step_wall_ms": (wall * 1e3 - p["ref_ms"]) / n}))
 t = time.time(); g = e.weighted_sum(idx, np.random.RandomState(0).randn(len(idx)).astype(np.float32), 2 * len(idx), copy_out=False)
 print("weighted_sum ms", e.profile()["reduce_ms"], "GB/s", len(idx) * e.P * 4 / e.profile()["reduce_ms"] / 1e6)
 e.materialize(idx[:256], 0.02, copy_out=False)
