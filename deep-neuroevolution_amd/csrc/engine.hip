@@ -927,6 +927,8 @@ extern "C" int dne_ga_eval(dne_handle *h, const int32_t *co, const int64_t *seed
     if (fresh > h->free_slots.size()) {
         if (grow_bases(h, h->base_cap + (int)(fresh - h->free_slots.size()))) return -1;
     }
+    struct Fresh { const std::vector<int64_t> *chain; int slot, src_slot, src_len; };
+    std::vector<Fresh> fresh_list;
     for (auto &kv : needed) {
         auto it = h->ga_cache.find(kv.first);
         if (it != h->ga_cache.end()) { kv.second = it->second; continue; }
@@ -940,8 +942,40 @@ extern "C" int dne_ga_eval(dne_handle *h, const int32_t *co, const int64_t *seed
             auto jt = h->ga_cache.find(p);
             if (jt != h->ga_cache.end()) { src_slot = jt->second; src_len = (int)p.size(); break; }
         }
-        if (build_chain(h, slot, kv.first.data(), (int)kv.first.size(), sigma, src_slot, src_len)) return -1;
         kv.second = slot;
+        fresh_list.push_back({&kv.first, slot, src_slot, src_len});
+    }
+    {   // genomes with no cached ancestor start as normc(noise[s0]) (ga.py:256-260): one batched launch set for all
+        std::vector<int32_t> rslot; std::vector<int64_t> roff;
+        for (auto &f : fresh_list)
+            if (f.src_slot < 0) {
+                if (check_noise_range(h, (*f.chain)[0], h->L.P)) return -1;
+                rslot.push_back(f.slot); roff.push_back((*f.chain)[0]);
+            }
+        const int nr = (int)rslot.size();
+        if (nr > 0) {
+            if ((size_t)nr > h->scratch_cap) return h->fail("too many fresh genomes");
+            int32_t *d_slot = (int32_t *)h->scratch_f;
+            HCHECK(h, hipMemcpyAsync(d_slot, rslot.data(), nr * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+            HCHECK(h, hipMemcpyAsync(h->scratch_i, roff.data(), nr * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+            const Layout &L = h->L;
+            const size_t st = h->base_stride;
+            hipLaunchKernelGGL(k_copy_noise_batch, dim3((L.P + 255) / 256, nr), dim3(256), 0, h->stream, (const float *)h->noise,
+                               (const int64_t *)h->scratch_i, (const int32_t *)d_slot, st, L.P, h->bases);
+            auto nc = [&](int off, int K, int C, float sd) { hipLaunchKernelGGL(k_normc_batch, dim3((C + 63) / 64, nr), dim3(64), 0, h->stream, h->bases, (const int32_t *)d_slot, st, off, K, C, sd); };
+            auto z = [&](int off, int n2) { hipLaunchKernelGGL(k_zero_batch, dim3((n2 + 63) / 64, nr), dim3(64), 0, h->stream, h->bases, (const int32_t *)d_slot, st, off, n2); };
+            nc(L.c1w, 256, 16, 1.0f); z(L.c1b, 16);
+            nc(L.c2w, 256, 32, 1.0f); z(L.c2b, 32);
+            nc(L.fcw, 3872, 256, 1.0f); z(L.fcb, 256);
+            nc(L.ow, 256, L.nact, 0.1f); z(L.ob, L.nact);
+            HCHECK(h, hipStreamSynchronize(h->stream));   // scratch is reused below
+        }
+    }
+    for (auto &f : fresh_list) {
+        const auto &c = *f.chain;
+        if (f.src_slot < 0) {   // root already holds normc(noise[s0]); apply the remaining mutations in place
+            if (c.size() > 1 && build_chain(h, f.slot, c.data(), (int)c.size(), sigma, f.slot, 1)) return -1;
+        } else if (build_chain(h, f.slot, c.data(), (int)c.size(), sigma, f.src_slot, f.src_len)) return -1;
     }
     HCHECK(h, hipGetLastError());
     HCHECK(h, hipStreamSynchronize(h->stream));

@@ -155,6 +155,29 @@ __global__ __launch_bounds__(64) void k_normc(float *__restrict__ w, int K, int 
     const float sc = std / rt;
     for (int k = 0; k < K; k++) w[(size_t)k * C + c] = w[(size_t)k * C + c] * sc;
 }
+// batched forms for a whole generation of fresh genomes (generation 0 of the GA: every child is its own
+// normc(noise[s0])): blockIdx.y = genome, written into base slot slots[genome]
+__global__ __launch_bounds__(256) void k_copy_noise_batch(const float *__restrict__ noise, const int64_t *__restrict__ offs,
+                                                          const int32_t *__restrict__ slots, size_t stride, int P,
+                                                          float *__restrict__ bases) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < P) bases[(size_t)slots[blockIdx.y] * stride + p] = noise[offs[blockIdx.y] + p];
+}
+__global__ __launch_bounds__(64) void k_normc_batch(float *__restrict__ bases, const int32_t *__restrict__ slots, size_t stride,
+                                                    int off, int K, int C, float std) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    float *w = bases + (size_t)slots[blockIdx.y] * stride + off;
+    float ss = 0.0f;
+    for (int k = 0; k < K; k++) { float x = w[(size_t)k * C + c]; float sq = x * x; ss = ss + sq; }
+    const float rt = sqrtf(ss);
+    const float sc = std / rt;
+    for (int k = 0; k < K; k++) w[(size_t)k * C + c] = w[(size_t)k * C + c] * sc;
+}
+__global__ void k_zero_batch(float *__restrict__ bases, const int32_t *__restrict__ slots, size_t stride, int off, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) bases[(size_t)slots[blockIdx.y] * stride + off + i] = 0.0f;
+}
 __global__ void k_zero(float *__restrict__ w, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) w[i] = 0.0f;
