@@ -172,7 +172,7 @@ struct dne_handle {
     hipStream_t stream = nullptr;
     std::vector<hipStream_t> sub_streams;   // sub-batch streams (sub_streams[0] == stream)
     int dbg_skip = 0;   // DNE_DEBUG_SKIP bitmask (timing experiments only): 1 conv1, 2 conv2, 4 render
-    int nsub = 2, sub_min_groups = 256, fc_grid = 512, fc_tail_max = 96, fc_rb = 4;
+    int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_rb = 4, fc_chain_min = 1 << 30;
     int M = 0, F = 0, ref_chunk = 0;
     size_t base_stride = 0;
     // device memory
@@ -366,13 +366,13 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipSetDevice(cfg->device_id));
     CH(hipStreamCreate(&h->stream));
     h->sub_streams.push_back(h->stream);
-    if (const char *e = getenv("DNE_NSUB")) h->nsub = std::max(1, std::min(8, atoi(e)));
+    if (const char *e = getenv("DNE_NSUB")) h->nsub_fixed = std::max(1, std::min(4, atoi(e)));
     if (const char *e = getenv("DNE_FC_TAIL_MAX")) h->fc_tail_max = std::max(0, atoi(e));
     if (const char *e = getenv("DNE_DEBUG_SKIP")) h->dbg_skip = atoi(e);
+    if (const char *e = getenv("DNE_FC_CHAIN_MIN")) h->fc_chain_min = atoi(e);
     if (const char *e = getenv("DNE_FC_RB")) h->fc_rb = atoi(e);
     if (const char *e = getenv("DNE_FC_GRID")) h->fc_grid = std::max(1, atoi(e));
-    if (const char *e = getenv("DNE_SUB_MIN_GROUPS")) h->sub_min_groups = std::max(1, atoi(e));
-    for (int s = 1; s < h->nsub; s++) { hipStream_t st; CH(hipStreamCreate(&st)); h->sub_streams.push_back(st); }
+    for (int s = 1; s < 4; s++) { hipStream_t st; CH(hipStreamCreate(&st)); h->sub_streams.push_back(st); }
     make_layout(cfg->policy_kind, cfg->n_actions, &h->L);
     h->M = cfg->max_members;
     h->F = cfg->policy_kind == DNE_KIND_ES ? (cfg->ref_count > 0 ? cfg->ref_count : 128) : 0;
@@ -729,25 +729,25 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     hipLaunchKernelGGL(k_iota, dim3((groups + 255) / 256), dim3(256), 0, h->stream, h->list_a, groups);
     HCHECK(h, hipStreamSynchronize(h->stream));
 
-    const int nsub = groups >= 2 * h->sub_min_groups ? std::min(h->nsub, (int)h->sub_streams.size()) : 1;
-    struct Sub { hipStream_t st; int *cur, *nxt; int count; int *count_dev; int host_count; size_t ev0; std::vector<int> step_counts; };
-    std::vector<Sub> subs(nsub);
-    size_t ne = 2;
-    for (int s = 0; s < nsub; s++) {
-        const int lo = (int)((long long)groups * s / nsub), hi = (int)((long long)groups * (s + 1) / nsub);
-        subs[s].st = h->sub_streams[s];
-        subs[s].cur = h->list_a + lo; subs[s].nxt = h->list_b + lo;   // disjoint windows of the two list buffers
-        subs[s].count = hi - lo;
-        subs[s].count_dev = h->count_dev + s;
-        subs[s].ev0 = 0;
-    }
+    // One global list of active groups, compacted every burst of 16 lock-steps.  Within a burst the list is cut
+    // into nsub equal windows, each stepped on its own stream, so that while one window streams its noise slices
+    // (HBM) the others run their MFMA convolutions and emulator frames.  nsub follows the active count:
+    // two free-running streams at full width, three in the mid range (where no single kernel fills the chip),
+    // one when only a handful of episodes are left (measured: tools/kbench.py sweeps).
+    auto pick_nsub = [&](int total) {
+        int k = h->nsub_fixed > 0 ? h->nsub_fixed : (total >= 1900 ? 2 : total >= 200 ? 3 : total >= 48 ? 2 : 1);
+        k = std::min(k, (int)h->sub_streams.size());
+        return std::max(1, std::min(k, total));
+    };
+    int *cur = h->list_a, *nxt = h->list_b;
+    int total = groups;
     EnvArgs E = h->env(bc_mode);
     int t = 0;
-    long long group_steps = 0;
-    std::vector<std::array<size_t, 4>> evs;
-    std::vector<char> ev_full;   // per launch set: did it use the streaming kernel (k_fc) rather than the tail path
+    long long group_steps = 0, launch_sets = 0;
+    std::vector<std::array<size_t, 4>> evs;   // per profiled launch set: event indices {before, after conv, after fc, after env}
+    size_t ne = 2;
     if (prof) {
-        const size_t need = (size_t)nsub * (size_t)tslimit + 64;
+        const size_t need = (size_t)h->sub_streams.size() * (size_t)tslimit + 64;
         if (need > h->launch_units_cap) {
             if (h->launch_units) HCHECK(h, hipFree(h->launch_units));
             HCHECK(h, dalloc(&h->launch_units, need));
@@ -755,48 +755,44 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
         }
         HCHECK(h, hipMemsetAsync(h->launch_units, 0, need * sizeof(int32_t), h->stream));
         HCHECK(h, hipStreamSynchronize(h->stream));
-    }   // per launch set: event indices {before, after conv, after fc, after env}
-    auto total = [&]() { int c = 0; for (auto &s : subs) c += s.count; return c; };
+    }
     hipEvent_t last_fc = nullptr;
     size_t fc_ring_pos = 0;
-    while (total() > 0 && t < tslimit) {
+    while (total > 0 && t < tslimit) {
         const int burst = std::min(16, tslimit - t);
+        const int nsub = pick_nsub(total);
         for (int st = 0; st < burst; st++) {
-            for (auto &s : subs) {
-                if (s.count == 0) continue;
+            for (int s = 0; s < nsub; s++) {
+                const int lo = (int)((long long)total * s / nsub), cnt = (int)((long long)total * (s + 1) / nsub) - lo;
+                if (cnt == 0) continue;
+                hipStream_t sst = h->sub_streams[s];
+                const int *lst = cur + lo;
                 std::array<size_t, 4> e{};
                 // events only around full-width launches: in the latency-bound tail every event packet is a bubble
-                const bool pe = prof && s.count > h->fc_tail_max;
-                if (pe) { e[0] = ne++; HCHECK(h, hipEventRecord(h->event(e[0]), s.st)); }
-                launch_forward(h, s.cur, s.count, gsize, true, s.st);
-                // the fc kernels of all sub-batches take turns on the HBM pipe: each one waits for the previous
-                // one (on another stream), which keeps the sub-batches in anti-phase -- conv / emulator work of
-                // one sub-batch always runs under the fc stream of the other
-                if (nsub > 1 && last_fc) HCHECK(h, hipStreamWaitEvent(s.st, last_fc, 0));
-                if (pe) { e[1] = ne++; HCHECK(h, hipEventRecord(h->event(e[1]), s.st)); }   // after the wait: brackets fc only
-                launch_fc(h, s.cur, s.count, gsize, nullptr, s.st);
-                if (nsub > 1) { last_fc = h->fc_ring[fc_ring_pos++ % h->fc_ring.size()]; HCHECK(h, hipEventRecord(last_fc, s.st)); }
-                if (pe) { e[2] = ne++; HCHECK(h, hipEventRecord(h->event(e[2]), s.st)); }
+                const bool pe = prof && cnt > h->fc_tail_max;
+                if (pe) { e[0] = ne++; HCHECK(h, hipEventRecord(h->event(e[0]), sst)); }
+                launch_forward(h, lst, cnt, gsize, true, sst);
+                // optional: serialise the fc kernels of the windows (anti-phase); off by default, free-running measured faster
+                const bool chain = nsub > 1 && cnt >= h->fc_chain_min;
+                if (chain && last_fc) HCHECK(h, hipStreamWaitEvent(sst, last_fc, 0));
+                if (pe) { e[1] = ne++; HCHECK(h, hipEventRecord(h->event(e[1]), sst)); }   // after the wait: brackets fc only
+                launch_fc(h, lst, cnt, gsize, nullptr, sst);
+                if (chain) { last_fc = h->fc_ring[fc_ring_pos++ % h->fc_ring.size()]; HCHECK(h, hipEventRecord(last_fc, sst)); }
+                if (pe) { e[2] = ne++; HCHECK(h, hipEventRecord(h->event(e[2]), sst)); }
                 E.step_counter = pe ? h->launch_units + evs.size() : nullptr;
-                launch_env_step(h, E, s.cur, s.count, gsize, tslimit, s.st);
-                if (pe) { e[3] = ne++; HCHECK(h, hipEventRecord(h->event(e[3]), s.st)); evs.push_back(e); ev_full.push_back(1); }
-                s.step_counts.push_back(s.count);
-                group_steps += s.count;
+                launch_env_step(h, E, lst, cnt, gsize, tslimit, sst);
+                if (pe) { e[3] = ne++; HCHECK(h, hipEventRecord(h->event(e[3]), sst)); evs.push_back(e); }
+                group_steps += cnt;
+                launch_sets++;
             }
         }
         t += burst;
-        for (auto &s : subs) {
-            if (s.count == 0) continue;
-            hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, s.st, (const int32_t *)h->done, gsize, (const int *)s.cur,
-                               s.count, s.nxt, s.count_dev);
-            HCHECK(h, hipMemcpyAsync(&s.host_count, s.count_dev, sizeof(int), hipMemcpyDeviceToHost, s.st));
-        }
-        for (auto &s : subs) {
-            if (s.count == 0) continue;
-            HCHECK(h, hipStreamSynchronize(s.st));
-            s.count = s.host_count;
-            std::swap(s.cur, s.nxt);
-        }
+        for (int s = 1; s < nsub; s++) HCHECK(h, hipStreamSynchronize(h->sub_streams[s]));
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, (const int32_t *)h->done, gsize, (const int *)cur,
+                           total, nxt, h->count_dev);
+        HCHECK(h, hipMemcpyAsync(&total, h->count_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HCHECK(h, hipStreamSynchronize(h->stream));
+        std::swap(cur, nxt);
     }
     HCHECK(h, hipGetLastError());
     HCHECK(h, hipEventRecord(h->ev_b, h->stream));
@@ -810,8 +806,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     dne_profile &P = h->prof;
     P.eval_ms = ms;
     P.fc_ms = P.conv_ms = P.env_ms = P.ref_ms = 0;
-    P.fc_launches = 0;
-    for (auto &s : subs) P.fc_launches += (int64_t)s.step_counts.size();
+    P.fc_launches = launch_sets;
     P.fc_group_steps = group_steps;
     P.env_steps = 0;
     for (int i = 0; i < n; i++) P.env_steps += lengths[i];
@@ -825,7 +820,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
             const auto &e = evs[i];
             HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e[0]], h->ev_pool[e[1]])); P.conv_ms += ms;
             HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e[1]], h->ev_pool[e[2]])); P.fc_ms += ms;
-            if (ev_full[i]) { P.fc_full_ms += ms; P.fc_full_launches += 1; P.fc_full_units += units[i]; }
+            P.fc_full_ms += ms; P.fc_full_launches += 1; P.fc_full_units += units[i];
             HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e[2]], h->ev_pool[e[3]])); P.env_ms += ms;
         }
     }

@@ -271,14 +271,15 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     if (tid < 210) {
         key = synth_row_class(tid) * 4 + (synth_player_row(s.ram_prev, tid) ? 2 : 0) + (synth_player_row(s.ram_cur, tid) ? 1 : 0);
         if (atomicCAS(&s.slot_of_key[key], -1, -2) == -1) {     // first row of this key claims a slot
-            const int slot = atomicAdd(&s.misc[2], 1);
+            int slot = atomicAdd(&s.misc[2], 1);
+            if (slot >= ENV_MAX_ROWS) slot = ENV_MAX_ROWS - 1;   // unreachable (<= 75 keys by construction); never write out of bounds
             s.rep_y[slot] = tid;
             s.slot_of_key[key] = slot;
         }
     }
     __syncthreads();
     if (tid < 210) s.slot_of_y[tid] = (uint8_t)s.slot_of_key[key];
-    const int nu = s.misc[2];
+    const int nu = min(s.misc[2], ENV_MAX_ROWS);
     const PixState pp = synth_pix_state(s.ram_prev), pc = synth_pix_state(s.ram_cur);
     for (int i = tid; i < nu * 160; i += nthr) {
         const int y = s.rep_y[i / 160], x = i % 160;
