@@ -189,7 +189,9 @@ struct dne_handle {
     int32_t *len = nullptr, *done = nullptr, *action = nullptr, *stepped = nullptr;
     int32_t *launch_units = nullptr; size_t launch_units_cap = 0;
     uint32_t *seeds = nullptr;
-    float *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *y3p = nullptr; size_t rows_cap = 0;
+    float *y1 = nullptr, *y2 = nullptr, *y3 = nullptr;          // step mode: one row per member
+    float *y1r[2] = {nullptr, nullptr}, *y2r[2] = {nullptr, nullptr}, *y3pr[2] = {nullptr, nullptr};   // reference pass scratch, two ways
+    hipEvent_t ev_ref[2] = {nullptr, nullptr};
     int *list_a = nullptr, *list_b = nullptr, *count_dev = nullptr;
     uint8_t *bc = nullptr; size_t bc_bytes = 0;
     float *mat_out = nullptr; size_t mat_cap = 0;
@@ -403,9 +405,14 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(dalloc(&h->logits, M * cfg->n_actions));
     CH(dalloc(&h->len, M)); CH(dalloc(&h->done, M)); CH(dalloc(&h->action, M)); CH(dalloc(&h->seeds, M)); CH(dalloc(&h->stepped, M));
     CH(hipMemset(h->done, 0, M * sizeof(int32_t))); CH(hipMemset(h->len, 0, M * sizeof(int32_t)));
-    h->rows_cap = std::max<size_t>(M, (size_t)h->ref_chunk * std::max(h->F, 1));
-    CH(dalloc(&h->y1, h->rows_cap * 7056)); CH(dalloc(&h->y2, h->rows_cap * 3872)); CH(dalloc(&h->y3, h->rows_cap * 256));
-    if (h->F) CH(dalloc(&h->y3p, (size_t)h->ref_chunk * 4 * h->F * 256));
+    CH(dalloc(&h->y1, M * 7056)); CH(dalloc(&h->y2, M * 3872)); CH(dalloc(&h->y3, M * 256));
+    if (h->F) {
+        const size_t rr = (size_t)h->ref_chunk * h->F;
+        for (int w = 0; w < 2; w++) {
+            CH(dalloc(&h->y1r[w], rr * 7056)); CH(dalloc(&h->y2r[w], rr * 3872)); CH(dalloc(&h->y3pr[w], rr * 4 * 256));
+            CH(hipEventCreateWithFlags(&h->ev_ref[w], hipEventDisableTiming));
+        }
+    }
     CH(dalloc(&h->list_a, M)); CH(dalloc(&h->list_b, M)); CH(dalloc(&h->count_dev, 8));
     if (cfg->record_bc) {
         h->bc_bytes = cfg->policy_kind == DNE_KIND_ES ? M * (size_t)std::max(cfg->bc_max_steps, 1) * 128 : M * 128;
@@ -428,12 +435,13 @@ extern "C" void dne_destroy(dne_handle *h) {
     hipDeviceSynchronize();
     void *ptrs[] = {h->noise, h->bases, h->opt_m, h->opt_v, h->g, h->partial, h->ref, h->m_slot, h->m_off, h->m_scale,
                     h->bn, h->ram_prev, h->ram_cur, h->stacks, h->tables, h->ret, h->sign, h->step_reward, h->logits,
-                    h->len, h->done, h->action, h->seeds, h->stepped, h->launch_units, h->y1, h->y2, h->y3, h->y3p, h->list_a, h->list_b, h->count_dev,
+                    h->len, h->done, h->action, h->seeds, h->stepped, h->launch_units, h->y1, h->y2, h->y3, h->y1r[0], h->y1r[1], h->y2r[0], h->y2r[1], h->y3pr[0], h->y3pr[1], h->list_a, h->list_b, h->count_dev,
                     h->bc, h->mat_out, h->scratch_f, h->scratch_i};
     for (void *p : ptrs)
         if (p) hipFree(p);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     for (hipEvent_t e : h->fc_ring) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_ref) if (e) hipEventDestroy(e);
     if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->ev_b) hipEventDestroy(h->ev_b);
     for (size_t s = 1; s < h->sub_streams.size(); s++) hipStreamDestroy(h->sub_streams[s]);
@@ -600,30 +608,44 @@ static int ref_pass(dne_handle *h, int n) {
     if (!h->ref_set) return h->fail("reference batch not set (dne_set_ref_batch)");
     const int F = h->F;
     const FwdArgs A = h->fwd(false);
-    for (int m0 = 0; m0 < n; m0 += h->ref_chunk) {
-        const int nc = std::min(h->ref_chunk, n - m0);
-        hipLaunchKernelGGL(k_conv1, dim3(nc * F), dim3(256), 0, h->stream, A, (const int *)nullptr, 1, F, m0,
-                           (const uint8_t *)h->stacks, (const uint8_t *)h->ref, h->y1, 1);
-        hipLaunchKernelGGL((k_bn_stats<16, 441>), dim3(nc), dim3(256), F * 16 * sizeof(float), h->stream, A, m0, F,
-                           (const float *)h->y1, 0, h->L.bn1b, h->L.bn1g);
-        hipLaunchKernelGGL((k_conv2<true>), dim3(nc * F), dim3(256), 0, h->stream, A, (const int *)nullptr, 1, F, m0,
-                           (const float *)h->y1, h->y2, 1);
-        hipLaunchKernelGGL((k_bn_stats<32, 121>), dim3(nc), dim3(256), F * 32 * sizeof(float), h->stream, A, m0, F,
-                           (const float *)h->y2, 32, h->L.bn2b, h->L.bn2g);
+    // chunks alternate between two streams with their own scratch: the statistics kernels (one workgroup per
+    // member, latency-bound) of one chunk run under the MFMA convolutions of the next
+    const int nways = n > h->ref_chunk ? 2 : 1;
+    if (nways > 1) {
+        HCHECK(h, hipEventRecord(h->ev_ref[0], h->stream));
+        HCHECK(h, hipStreamWaitEvent(h->sub_streams[1], h->ev_ref[0], 0));
+    }
+    int c = 0;
+    for (int m0 = 0; m0 < n; m0 += h->ref_chunk, c++) {
+        const int nc = std::min(h->ref_chunk, n - m0), w = c % nways;
+        hipStream_t st = h->sub_streams[w];
+        float *y1 = h->y1r[w], *y2 = h->y2r[w], *y3p = h->y3pr[w];
+        hipLaunchKernelGGL(k_conv1, dim3(nc * F), dim3(256), 0, st, A, (const int *)nullptr, 1, F, m0,
+                           (const uint8_t *)h->stacks, (const uint8_t *)h->ref, y1, 1);
+        hipLaunchKernelGGL((k_bn_stats<16, 441>), dim3(nc), dim3(256), F * 16 * sizeof(float), st, A, m0, F,
+                           (const float *)y1, 0, h->L.bn1b, h->L.bn1g);
+        hipLaunchKernelGGL((k_conv2<true>), dim3(nc * F), dim3(256), 0, st, A, (const int *)nullptr, 1, F, m0,
+                           (const float *)y1, y2, 1);
+        hipLaunchKernelGGL((k_bn_stats<32, 121>), dim3(nc), dim3(256), F * 32 * sizeof(float), st, A, m0, F,
+                           (const float *)y2, 32, h->L.bn2b, h->L.bn2g);
         if (F == 16 || F == 32 || F == 64 || F == 128) {   // matrix-core path
             const int grid = (nc + 7) / 8 * 8 * 16;
-#define FCREF(MT) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid), dim3(256), 0, h->stream, A, nc, m0, (const float *)h->y2, h->y3p)
+#define FCREF(MT) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid), dim3(256), 0, st, A, nc, m0, (const float *)y2, y3p)
             if (F == 16) FCREF(1); else if (F == 32) FCREF(2); else if (F == 64) FCREF(4); else FCREF(8);
 #undef FCREF
-            hipLaunchKernelGGL(k_bn3_partials, dim3(nc), dim3(256), 0, h->stream, A, m0, F, (const float *)h->y3p);
+            hipLaunchKernelGGL(k_bn3_partials, dim3(nc), dim3(256), 0, st, A, m0, F, (const float *)y3p);
         } else {
-            const int nfg = F / 8;
-            hipLaunchKernelGGL((k_fc<8, true, true, 4>), dim3((nc + 7) / 8 * 8 * nfg), dim3(256), 0, h->stream, A,
-                               (const int *)nullptr, nc, F, m0, (const float *)h->y2, h->y3, (int32_t *)nullptr,
+            const int nfg = F / 8;   // generic path: y3 rows live in the partial buffer of this way
+            hipLaunchKernelGGL((k_fc<8, true, true, 4>), dim3((nc + 7) / 8 * 8 * nfg), dim3(256), 0, st, A,
+                               (const int *)nullptr, nc, F, m0, (const float *)y2, y3p, (int32_t *)nullptr,
                                (float *)nullptr);
-            hipLaunchKernelGGL((k_bn_stats<256, 1>), dim3(nc), dim3(256), 0, h->stream, A, m0, F, (const float *)h->y3,
+            hipLaunchKernelGGL((k_bn_stats<256, 1>), dim3(nc), dim3(256), 0, st, A, m0, F, (const float *)y3p,
                                96, h->L.bn3b, h->L.bn3g);
         }
+    }
+    if (nways > 1) {
+        HCHECK(h, hipEventRecord(h->ev_ref[1], h->sub_streams[1]));
+        HCHECK(h, hipStreamWaitEvent(h->stream, h->ev_ref[1], 0));
     }
     HCHECK(h, hipGetLastError());
     return 0;
