@@ -207,9 +207,14 @@ def main():
                 "traffic": _pmc_traffic(units_per_launch),
                 "algorithmic_bytes_per_unit": ALG_BYTES_PER_ENV_STEP, "unit_def": "one env-step of one member",
                 "units_per_launch": units_per_launch, "avg_launch_ms": avg_ms, "launches": int(fc_launches),
-                "note": "antithetic pairs share one read of their noise slice, so HBM traffic per unit is below the "
-                        "algorithmic figure (see profiles/ for FETCH_SIZE)",
+                "note": "antithetic pairs share one read of their noise slice, so the HBM traffic per unit (traffic, from "
+                        "the rocprofv3 FETCH_SIZE/WRITE_SIZE passes in profiles/) is about half the algorithmic figure and "
+                        "frac may exceed 1; traffic_rate is what the memory system actually delivers to this kernel",
             }
+            tr = out["roofline"]["traffic"]
+            if tr:
+                out["roofline"]["traffic_rate"] = {"value": tr / (avg_ms * 1e-3) / 1e9, "unit": "GB/s",
+                                                   "frac_of_peak": tr / (avg_ms * 1e-3) / HBM_PEAK}
             out["stage_ms_per_generation"] = {k: v / args.steps for k, v in stage.items()}
             out["stage_ms_per_generation"]["fc_ms"] = fc_all_ms / args.steps
             out["stage_ms_per_generation"]["fc_streaming_kernel_ms"] = fc_ms / args.steps
