@@ -387,3 +387,59 @@ def test_ref_pass_full_reference_batch(hip, oracle, small_noise):
         thi = th + np.float32(scale[i]) * small_noise[off[i]:off[i] + L.P]
         assert np.array_equal(bn[i], O.es_ref_pass(L, thi, ref)), i
     e.close()
+
+
+def test_nses_driver_on_device(hip, oracle, small_noise, tmp_path):
+    """dne_hip.nses master/worker over the real engine (NSR-ES, 2 meta-population members, 2 iterations): the novelty
+    shipped in signreturns equals the oracle's novelty of the same rollouts against the same archive."""
+    import threading
+    from dne_hip import dist, es, nses
+    dist.reset_brokers()
+    tsl = 24
+    exp = {"config": {"calc_obstat_prob": 0.0, "episodes_per_batch": 8, "eval_prob": 0.0, "l2coeff": 0.005,
+                      "noise_stdev": 0.02, "snapshot_freq": 0, "timesteps_per_batch": 10,
+                      "return_proc_mode": "centered_sign_rank", "episode_cutoff_mode": tsl},
+           "env_id": "FrostbiteNoFrameskip-v4", "algo_type": "nsr",
+           "novelty_search": {"k": 2, "population_size": 2, "num_rollouts": 1, "selection_method": "round_robin"},
+           "optimizer": {"args": {"stepsize": 0.01}, "type": "adam"}, "policy": {"args": {}, "type": "ESAtariPolicy"}}
+    noise = es.SharedNoiseTable(count=small_noise.size)
+    mk = lambda: hip.Engine(hip.KIND_ES, NACT, max_members=8, ref_count=NREF, record_bc=True, bc_max_steps=tsl)
+    me, we = mk(), mk()
+    cfg = {"unix_socket_path": "/tmp/gpu_ns.sock"}
+    out, pushed = {}, []
+    orig_push = dist.WorkerClient.push_result
+
+    def spy(self, task_id, result):
+        pushed.append((task_id, result, self.get_archive()))
+        return orig_push(self, task_id, result)
+
+    dist.WorkerClient.push_result = spy
+    try:
+        tm = threading.Thread(target=lambda: out.update(r=nses.run_master(cfg, str(tmp_path), exp, engine=me, noise=noise, max_iters=2)), daemon=True)
+        tm.start()
+        nses.run_worker(cfg, cfg, noise, engine=we, max_tasks=2, seed=9)
+        tm.join(timeout=120)
+    finally:
+        dist.WorkerClient.push_result = orig_push
+    assert not tm.is_alive()
+    theta_dict, archive = out["r"]
+    assert len(archive) == 4 and all(a.shape[1] == 128 and a.dtype == np.uint8 for a in archive)
+    # re-derive the first task's novelty with the oracle
+    task_id, res, arch = pushed[0]
+    L = oracle.layout(oracle.KIND_ES, NACT)
+    from dne_hip import policies
+    th = policies.xavier_flat(NACT, 0)
+    ref = me.env_observation  # noqa: F841  (reference batch lives on the device; rebuild it the same way)
+    env = policies.HipAtariEnv(me, seed=0)
+    refb = np.rint(np.stack(es.get_ref_batch(env, NREF, np.random.RandomState(0))) * 255.0).astype(np.uint8)
+    rs = np.random.RandomState(9); rs.randint(2 ** 31)
+    idx = np.array([noise.sample_index(rs, L.P) for _ in range(4)], np.int64)
+    seeds = rs.randint(0, 2 ** 32, size=8, dtype=np.uint64).astype(np.uint32)
+    assert np.array_equal(res.noise_inds_n, idx)
+    for i in range(4):
+        for s in range(2):
+            thp = oracle.perturb(th, small_noise, idx[i], 0.02, 1 if s == 0 else -1)
+            r, _, l, bc = oracle.rollout(L, thp, refb, seeds[2 * i + s], tsl, want_bc=True)
+            assert r == res.returns_n2[i, s] and l == res.lengths_n2[i, s]
+            assert np.float32(oracle.novelty(arch, bc, 2)) == res.signreturns_n2[i, s]
+    me.close(); we.close()
