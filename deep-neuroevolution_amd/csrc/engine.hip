@@ -172,7 +172,8 @@ struct dne_handle {
     hipStream_t stream = nullptr;
     std::vector<hipStream_t> sub_streams;   // sub-batch streams (sub_streams[0] == stream)
     int dbg_skip = 0;   // DNE_DEBUG_SKIP bitmask (timing experiments only): 1 conv1, 2 conv2, 4 render
-    int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_rb = 4, fc_chain_min = 1 << 30;
+    int render_threads = 256;
+    int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_quad_max = 24, fc_rb = 4, fc_chain_min = 1 << 30;
     int M = 0, F = 0, ref_chunk = 0;
     size_t base_stride = 0;
     // device memory
@@ -189,7 +190,7 @@ struct dne_handle {
     int32_t *len = nullptr, *done = nullptr, *action = nullptr, *stepped = nullptr;
     int32_t *launch_units = nullptr; size_t launch_units_cap = 0;
     uint32_t *seeds = nullptr;
-    float *y1 = nullptr, *y2 = nullptr, *y3 = nullptr;          // step mode: one row per member
+    float *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *y3t = nullptr;   // step mode: one row per member (y3t: 4 k-slice partials)
     float *y1r[2] = {nullptr, nullptr}, *y2r[2] = {nullptr, nullptr}, *y3pr[2] = {nullptr, nullptr};   // reference pass scratch, two ways
     hipEvent_t ev_ref[2] = {nullptr, nullptr};
     int *list_a = nullptr, *list_b = nullptr, *count_dev = nullptr;
@@ -369,8 +370,10 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipStreamCreate(&h->stream));
     h->sub_streams.push_back(h->stream);
     if (const char *e = getenv("DNE_NSUB")) h->nsub_fixed = std::max(1, std::min(4, atoi(e)));
+    if (const char *e = getenv("DNE_FC_QUAD_MAX")) h->fc_quad_max = atoi(e);
     if (const char *e = getenv("DNE_FC_TAIL_MAX")) h->fc_tail_max = std::max(0, atoi(e));
     if (const char *e = getenv("DNE_DEBUG_SKIP")) h->dbg_skip = atoi(e);
+    if (const char *e = getenv("DNE_RENDER_THREADS")) h->render_threads = atoi(e);
     if (const char *e = getenv("DNE_FC_CHAIN_MIN")) h->fc_chain_min = atoi(e);
     if (const char *e = getenv("DNE_FC_RB")) h->fc_rb = atoi(e);
     if (const char *e = getenv("DNE_FC_GRID")) h->fc_grid = std::max(1, atoi(e));
@@ -405,7 +408,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(dalloc(&h->logits, M * cfg->n_actions));
     CH(dalloc(&h->len, M)); CH(dalloc(&h->done, M)); CH(dalloc(&h->action, M)); CH(dalloc(&h->seeds, M)); CH(dalloc(&h->stepped, M));
     CH(hipMemset(h->done, 0, M * sizeof(int32_t))); CH(hipMemset(h->len, 0, M * sizeof(int32_t)));
-    CH(dalloc(&h->y1, M * 7056)); CH(dalloc(&h->y2, M * 3872)); CH(dalloc(&h->y3, M * 256));
+    CH(dalloc(&h->y1, M * 7056)); CH(dalloc(&h->y2, M * 3872)); CH(dalloc(&h->y3, M * 256)); CH(dalloc(&h->y3t, M * 4 * 256));
     if (h->F) {
         const size_t rr = (size_t)h->ref_chunk * h->F;
         for (int w = 0; w < 2; w++) {
@@ -435,7 +438,7 @@ extern "C" void dne_destroy(dne_handle *h) {
     hipDeviceSynchronize();
     void *ptrs[] = {h->noise, h->bases, h->opt_m, h->opt_v, h->g, h->partial, h->ref, h->m_slot, h->m_off, h->m_scale,
                     h->bn, h->ram_prev, h->ram_cur, h->stacks, h->tables, h->ret, h->sign, h->step_reward, h->logits,
-                    h->len, h->done, h->action, h->seeds, h->stepped, h->launch_units, h->y1, h->y2, h->y3, h->y1r[0], h->y1r[1], h->y2r[0], h->y2r[1], h->y3pr[0], h->y3pr[1], h->list_a, h->list_b, h->count_dev,
+                    h->len, h->done, h->action, h->seeds, h->stepped, h->launch_units, h->y1, h->y2, h->y3, h->y3t, h->y1r[0], h->y1r[1], h->y2r[0], h->y2r[1], h->y3pr[0], h->y3pr[1], h->list_a, h->list_b, h->count_dev,
                     h->bc, h->mat_out, h->scratch_f, h->scratch_i};
     for (void *p : ptrs)
         if (p) hipFree(p);
@@ -536,7 +539,7 @@ static void launch_env_step(dne_handle *h, const EnvArgs &E, const int *list, in
     const int items = count * gsize;
     hipLaunchKernelGGL(k_env_logic, dim3((items + 63) / 64), dim3(64), 0, st, E, list, gsize, items, tslimit);
     if (h->dbg_skip & 4) return;
-    hipLaunchKernelGGL(k_env_render, dim3(items), dim3(items <= 192 ? 1024 : 256), 0, st, E, list, gsize, 0);
+    hipLaunchKernelGGL(k_env_render, dim3(items), dim3(items <= 192 ? 1024 : h->render_threads), 0, st, E, list, gsize, 0);
 }
 
 // ------------------------------------------------------------------------------- env ABI
@@ -688,8 +691,9 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
     if (count <= h->fc_tail_max) {   // latency-bound regime: 4 workgroups per group + a separate output-layer kernel
 #define FCT(NV, BN)                                                                                                          \
     do {                                                                                                                     \
-        hipLaunchKernelGGL((k_fc_cols<NV, BN>), dim3(count * 4), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3);    \
-        hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3, h->action, logits); \
+        if (count <= h->fc_quad_max) hipLaunchKernelGGL((k_fc_quad<NV, BN>), dim3(count * 64), dim3(64), 0, st, A, list, (const float *)h->y2, h->y3t); \
+        else hipLaunchKernelGGL((k_fc_cols<NV, BN>), dim3(count * 4), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
+        hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->y3, h->action, logits); \
     } while (0)
         if (gsize == 2) { if (es) FCT(2, true); else FCT(2, false); }
         else { if (es) FCT(1, true); else FCT(1, false); }

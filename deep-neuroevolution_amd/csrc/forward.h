@@ -561,16 +561,111 @@ __global__ __launch_bounds__(256) void k_bn3_partials(FwdArgs A, int member0, in
 }
 
 // ------------------------------------------------------------ fc for small active counts (the tail)
-// When only a few episodes are still running, a lock-step is latency-bound: one workgroup per pair would
-// stream 4 MB through four waves.  Here each pair gets 4 workgroups (one per 64-column quarter), every lane
-// owns ONE output column (4-byte loads, 256 B per wave-row) and keeps 2 x 44 rows in flight, so a slice is 22
-// dependent batches instead of 121.  Same 4 k-slices, same chain order, same combine -> same bits.
-// The 256 x nact output layer + argmax needs all four quarters and runs in k_out.
+// When only a few episodes are still running a lock-step is latency-bound, and what limits one wave streaming its
+// k-slice is the issue rate of its load instructions (~40 cycles each), not bytes.  So a wave covers 4 ROWS x 16
+// columns per load: lanes 4c..4c+3 (a DPP quad) hold four consecutive rows of column c, and the fp32 chain of that
+// column runs around the quad -- step j: lane j = fma(x[4g+j], w[row 4g+j], value from lane j-1) -- one
+// v_mov_dpp quad_perm + one v_fma per row.  Same 4 k-slices, same row order, same bits; 4x fewer load
+// instructions per slice.  One single-wave workgroup per (group, 16-column group, k-slice): 64 CUs per pair.
+// The ((s0+s1)+(s2+s3)) + bias combine, bn3, the 256 x nact output layer and the argmax run in k_out.
+__device__ __forceinline__ float quad_from_prev(float v) {   // lane r of every quad receives lane (r-1)&3's value
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x93, 0xf, 0xf, true));
+}
+
+template <int NV, bool HAS_BN>
+__global__ __launch_bounds__(64) void k_fc_quad(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
+                                                float *__restrict__ y3t /*[member][4 slices][256]*/) {
+    __shared__ __attribute__((aligned(16))) float xs[NV][968];
+    const int lane = threadIdx.x, rg = lane & 3, cl = lane >> 2;
+    const Layout &L = A.L;
+    const int item = blockIdx.x >> 6, cg = (blockIdx.x >> 2) & 15, sl = blockIdx.x & 3;
+    const int g = list ? list[item] : item;
+    int member[NV];
+    float scale[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) { member[v] = g * NV + v; scale[v] = A.m_scale[member[v]]; }
+    const int64_t off = A.m_off[member[0]];
+    const float *base = A.bases + (size_t)A.m_slot[member[0]] * A.base_stride;
+    const int col = cg * 16 + cl;
+    const int kbeg = 968 * sl;
+    const float *eps = A.noise + off + L.fcw + (size_t)(kbeg + rg) * 256 + col;
+    const float *th = base + L.fcw + (size_t)(kbeg + rg) * 256 + col;
+    constexpr int GB = 22, NBT = 242 / GB;   // 242 four-row groups per slice, 22 per batch, next batch in flight
+    float e_cur[GB], t_cur[GB], e_nxt[GB], t_nxt[GB];
+#pragma unroll
+    for (int i = 0; i < GB; i++) { e_cur[i] = eps[(size_t)(4 * i) * 256]; t_cur[i] = th[(size_t)(4 * i) * 256]; }
+    {   // activations of this slice: all 16 loads per vector are issued together, then bn2 + relu into LDS
+        float yv[NV][16], s2[NV], h2[NV];
+        const int ch = (kbeg + lane) & 31;   // 968 = 8 (mod 32) and the stride is 64: one bn2 channel per lane
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            s2[v] = HAS_BN ? A.bn[(size_t)member[v] * 608 + 32 + ch] : 1.0f;
+            h2[v] = HAS_BN ? A.bn[(size_t)member[v] * 608 + 64 + ch] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int i = lane + 64 * j;
+                yv[v][j] = i < 968 ? y2[(size_t)member[v] * 3872 + kbeg + i] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int i = lane + 64 * j;
+                if (i < 968) {
+                    float t = yv[v][j];
+                    if (HAS_BN) {
+                        t = t * s2[v];
+                        t = t + h2[v];
+                    }
+                    xs[v][i] = t > 0.0f ? t : 0.0f;
+                }
+            }
+    }
+    __syncthreads();
+    float acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) acc[v] = 0.0f;
+    for (int bt = 0; bt < NBT; bt++) {
+        if (bt + 1 < NBT) {
+#pragma unroll
+            for (int i = 0; i < GB; i++) {
+                e_nxt[i] = eps[(size_t)(4 * ((bt + 1) * GB + i)) * 256];
+                t_nxt[i] = th[(size_t)(4 * ((bt + 1) * GB + i)) * 256];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the chain below (hipcc otherwise sinks the loads)
+#pragma unroll
+        for (int i = 0; i < GB; i++) {
+            float w[NV];
+            f4a x4[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                float pv = scale[v] * e_cur[i];
+                w[v] = t_cur[i] + pv;                                        // this lane's row 4g + rg
+                x4[v] = *(const f4a *)&xs[v][4 * (bt * GB + i)];             // activations of rows 4g .. 4g+3 (broadcast)
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int v = 0; v < NV; v++) acc[v] = __builtin_fmaf(x4[v][j], w[v], quad_from_prev(acc[v]));   // meaningful in lane rg == j
+        }
+#pragma unroll
+        for (int i = 0; i < GB; i++) { e_cur[i] = e_nxt[i]; t_cur[i] = t_nxt[i]; }
+    }
+    if (rg == 3) {   // after the last row (4g + 3) the chain value sits in lane 3 of the quad
+#pragma unroll
+        for (int v = 0; v < NV; v++) y3t[((size_t)member[v] * 4 + sl) * 256 + col] = acc[v];
+    }
+}
+
+// Middle of the tail (a few dozen active groups): 4 workgroups per group (one per 64-column quarter), wave = k-slice,
+// lane = ONE output column with 2 x 44 rows in flight.  Fewer, fatter workgroups than k_fc_quad -- faster once the
+// quad kernel's 64 workgroups per group no longer fit the chip at once.  Same partial-sum output.
 template <int NV, bool HAS_BN>
 __global__ __launch_bounds__(256) void k_fc_cols(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
-                                                 float *__restrict__ y3) {
+                                                 float *__restrict__ y3t /*[member][4 slices][256]*/) {
     __shared__ float xs[4][NV][968];
-    __shared__ float part[4][NV][64];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const Layout &L = A.L;
     const int item = blockIdx.x >> 2, cq = blockIdx.x & 3;
@@ -589,17 +684,34 @@ __global__ __launch_bounds__(256) void k_fc_cols(FwdArgs A, const int *__restric
     float e_cur[RB], t_cur[RB], e_nxt[RB], t_nxt[RB];
 #pragma unroll
     for (int i = 0; i < RB; i++) { e_cur[i] = eps[(size_t)i * 256]; t_cur[i] = th[(size_t)i * 256]; }
+    {
+        float yv[NV][16], s2[NV], h2[NV];
+        const int ch = (kbeg + lane) & 31;
 #pragma unroll
-    for (int v = 0; v < NV; v++)
-        for (int i = lane; i < 968; i += 64) {
-            float t = y2[(size_t)member[v] * 3872 + kbeg + i];
-            if (HAS_BN) {
-                const int ch = (kbeg + i) & 31;
-                t = t * A.bn[(size_t)member[v] * 608 + 32 + ch];
-                t = t + A.bn[(size_t)member[v] * 608 + 64 + ch];
+        for (int v = 0; v < NV; v++) {
+            s2[v] = HAS_BN ? A.bn[(size_t)member[v] * 608 + 32 + ch] : 1.0f;
+            h2[v] = HAS_BN ? A.bn[(size_t)member[v] * 608 + 64 + ch] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int i = lane + 64 * j;
+                yv[v][j] = i < 968 ? y2[(size_t)member[v] * 3872 + kbeg + i] : 0.0f;
             }
-            xs[wv][v][i] = t > 0.0f ? t : 0.0f;
         }
+#pragma unroll
+        for (int v = 0; v < NV; v++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int i = lane + 64 * j;
+                if (i < 968) {
+                    float t = yv[v][j];
+                    if (HAS_BN) {
+                        t = t * s2[v];
+                        t = t + h2[v];
+                    }
+                    xs[wv][v][i] = t > 0.0f ? t : 0.0f;
+                }
+            }
+    }
     __syncthreads();
     float acc[NV];
 #pragma unroll
@@ -625,23 +737,14 @@ __global__ __launch_bounds__(256) void k_fc_cols(FwdArgs A, const int *__restric
         for (int i = 0; i < RB; i++) { e_cur[i] = e_nxt[i]; t_cur[i] = t_nxt[i]; }
     }
 #pragma unroll
-    for (int v = 0; v < NV; v++) part[wv][v][lane] = acc[v];
-    __syncthreads();
-    if (tid < NV * 64) {
-        const int v = tid >> 6, j = cq * 64 + (tid & 63);
-        const float s01 = part[0][v][tid & 63] + part[1][v][tid & 63];
-        const float s23 = part[2][v][tid & 63] + part[3][v][tid & 63];
-        float s = s01 + s23;
-        float pv = scale[v] * A.noise[off + L.fcb + j];
-        const float bias = base[L.fcb + j] + pv;
-        y3[(size_t)member[v] * 256 + j] = s + bias;
-    }
+    for (int v = 0; v < NV; v++) y3t[((size_t)member[v] * 4 + wv) * 256 + col] = acc[v];
 }
 
 // bn3 + relu + out layer (256 x nact, k-ordered chain) + first-max argmax from y3, one workgroup per group
 template <int NV, bool HAS_BN>
-__global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y3,
-                                            int32_t *__restrict__ actions, float *__restrict__ logits_out) {
+__global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y3t,
+                                            float *__restrict__ y3, int32_t *__restrict__ actions,
+                                            float *__restrict__ logits_out) {
     __shared__ float a3[NV][256];
     __shared__ float lg[NV][32];
     const int tid = threadIdx.x;
@@ -652,7 +755,14 @@ __global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ 
     for (int v = 0; v < NV; v++) {
         const int m = g * NV + v;
         for (int j = tid; j < 256; j += 256) {
-            float t = y3[(size_t)m * 256 + j];
+            const float *p = y3t + (size_t)m * 4 * 256 + j;
+            const float s01 = p[0] + p[256];
+            const float s23 = p[512] + p[768];
+            float t = s01 + s23;
+            float pvb = A.m_scale[m] * A.noise[A.m_off[m] + L.fcb + j];
+            const float fb = (A.bases + (size_t)A.m_slot[m] * A.base_stride)[L.fcb + j] + pvb;
+            t = t + fb;
+            y3[(size_t)m * 256 + j] = t;
             if (HAS_BN) {
                 t = t * A.bn[(size_t)m * 608 + 96 + j];
                 t = t + A.bn[(size_t)m * 608 + 352 + j];
