@@ -148,11 +148,8 @@ def es_generation(engine, noise_len, config, n_pairs, generation, tslimit, optim
     mine, idx, seeds = generation_inputs(noise_len, P, n_pairs, generation, rank, world)
     ret, sg, ln = engine.es_eval(idx, config.noise_stdev, tslimit, seeds)
     rec = allgather_records(pack_records(idx, ret, ln, sg), n_pairs, rank, world, device)
-    a = optimizer['args']
     ratio = engine.es_update(rec['noise_idx'], rec['ret'], rec['aux'], config.return_proc_mode, optimizer['type'],
-                             config.l2coeff, a['stepsize'],
-                             a.get('beta1', 0.9) if optimizer['type'] == 'adam' else a.get('momentum', 0.9),
-                             a.get('beta2', 0.999), a.get('epsilon', 1e-08))
+                             config.l2coeff, *optimizer_args(optimizer))
     return rec, ratio
 
 
@@ -174,102 +171,126 @@ def setup(exp, engine=None, n_pairs=None, device_id=0):
     return config, env, policy
 
 
+class Batch:
+    """What the master keeps of one generation: the Results that belong to the current task, eval episodes,
+    and the bookkeeping counters the reference logs (es.py:226-277)."""
+
+    def __init__(self):
+        self.results, self.eval_rets, self.eval_lens, self.worker_ids = [], [], [], []
+        self.skipped = self.episodes = self.timesteps = 0
+        self.all_episodes = self.all_timesteps = 0   # including stale tasks and eval jobs (EpisodesSoFar / TimestepsSoFar)
+
+    def cat(self, field):
+        return np.concatenate([getattr(r, field) for r in self.results])
+
+    @property
+    def skipped_frac(self):
+        return self.skipped / max(self.skipped + len(self.results), 1)
+
+
+def collect_batch(master, config, task_id, check_pairs=True):
+    """Pop Results until both episodes_per_batch and timesteps_per_batch are met (es.py:230-265): results of
+    older tasks are counted but dropped, eval jobs are kept apart, shapes/dtypes asserted like the reference."""
+    b = Batch()
+    while b.episodes < config.episodes_per_batch or b.timesteps < config.timesteps_per_batch:
+        tid, res = master.pop_result()
+        assert isinstance(tid, int) and isinstance(res, Result)
+        assert (res.eval_return is None) == (res.eval_length is None)
+        b.worker_ids.append(res.worker_id)
+        if res.eval_length is not None:                   # an evaluation episode of the unperturbed theta
+            b.all_episodes += 1
+            b.all_timesteps += res.eval_length
+            if tid == task_id:
+                b.eval_rets.append(res.eval_return)
+                b.eval_lens.append(res.eval_length)
+            continue
+        if check_pairs:                                   # es.py:246-248
+            assert res.noise_inds_n.ndim == 1
+            assert res.returns_n2.shape == res.lengths_n2.shape == (len(res.noise_inds_n), 2)
+        assert res.returns_n2.dtype == np.float32
+        if tid != task_id:
+            b.skipped += 1
+            continue
+        n_eps, n_steps = res.lengths_n2.size, int(res.lengths_n2.sum())
+        b.results.append(res)
+        b.episodes += n_eps
+        b.timesteps += n_steps
+        b.all_episodes += n_eps
+        b.all_timesteps += n_steps
+    return b
+
+
+def optimizer_args(opt):
+    """(stepsize, beta1-or-momentum, beta2, epsilon) from the experiment's optimizer dict (optimizers.py:24,36)."""
+    a = opt['args']
+    first = a.get('beta1', 0.9) if opt['type'] == 'adam' else a.get('momentum', 0.9)
+    return a['stepsize'], first, a.get('beta2', 0.999), a.get('epsilon', 1e-08)
+
+
+def log_generation(tlogger, rows):
+    for k, v in rows:
+        tlogger.record_tabular(k, v)
+    tlogger.dump_tabular()
+
+
 def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_iters=None, seed=0):
-    """es.py:141-353.  Same loop: declare task -> pop results until episodes_per_batch and timesteps_per_batch
-    are met -> process returns -> aggregate -> optimizer step, with the reduce running on the device
-    (dne_es_update).  max_iters (extension) lets tests stop the otherwise endless loop."""
+    """es.py:141-353.  Same protocol: declare a task -> collect Results -> process returns -> aggregate ->
+    optimizer step, with the reduce running on the device (dne_es_update).  max_iters (extension) lets tests
+    stop the otherwise endless loop."""
     from . import tabular_logger as tlogger
     logger.info('run_master: {}'.format(locals()))
     tlogger.start(log_dir)
     config, env, policy = setup(exp, engine=engine)
     engine = policy.engine
     master = MasterClient(master_redis_cfg)
-    if policy.get_trainable_flat().any() == False:  # noqa: E712  fresh policy: reference relies on TF's initialiser
-        policy.initialize(seed) if hasattr(policy, 'initialize') else None
+    if not policy.get_trainable_flat().any() and hasattr(policy, 'initialize'):
+        policy.initialize(seed)                           # the reference relies on TF's (unseeded) initialiser
     noise = noise if noise is not None else SharedNoiseTable()
     noise.attach(engine)
     engine.optimizer_reset()
     opt = exp['optimizer']
-    if policy.needs_ref_batch:
-        ref_batch = get_ref_batch(env, batch_size=engine.ref_count, random_stream=np.random.RandomState(seed))
-        policy.set_ref_batch(ref_batch)
-    tslimit, incr_tslimit_threshold, tslimit_incr_ratio, tslimit_max, adaptive_tslimit = parse_cutoff(config.episode_cutoff_mode)
+    if policy.needs_ref_batch:                            # es.py:160-162
+        policy.set_ref_batch(get_ref_batch(env, batch_size=engine.ref_count, random_stream=np.random.RandomState(seed)))
+    tslimit, grow_thresh, grow_ratio, tslimit_max, adaptive = parse_cutoff(config.episode_cutoff_mode)
     episodes_so_far = timesteps_so_far = 0
     tstart = time.time()
     master.declare_experiment(exp)
     it = 0
     while max_iters is None or it < max_iters:
         it += 1
-        step_tstart = time.time()
+        t0 = time.time()
         theta = policy.get_trainable_flat()
         assert theta.dtype == np.float32
-        curr_task_id = master.declare_task(Task(
-            params=theta, ob_mean=None, ob_std=None,
-            ref_batch=policy.ref_batch if policy.needs_ref_batch else None, timestep_limit=tslimit))
-        tlogger.log('********** Iteration {} **********'.format(curr_task_id))
-        curr_task_results, eval_rets, eval_lens, worker_ids = [], [], [], []
-        num_results_skipped = num_episodes_popped = num_timesteps_popped = 0
-        while num_episodes_popped < config.episodes_per_batch or num_timesteps_popped < config.timesteps_per_batch:
-            task_id, result = master.pop_result()
-            assert isinstance(task_id, int) and isinstance(result, Result)
-            assert (result.eval_return is None) == (result.eval_length is None)
-            worker_ids.append(result.worker_id)
-            if result.eval_length is not None:
-                episodes_so_far += 1
-                timesteps_so_far += result.eval_length
-                if task_id == curr_task_id:
-                    eval_rets.append(result.eval_return)
-                    eval_lens.append(result.eval_length)
-            else:
-                assert (result.noise_inds_n.ndim == 1 and
-                        result.returns_n2.shape == result.lengths_n2.shape == (len(result.noise_inds_n), 2))
-                assert result.returns_n2.dtype == np.float32
-                if task_id == curr_task_id:
-                    episodes_so_far += result.lengths_n2.size
-                    timesteps_so_far += result.lengths_n2.sum()
-                    curr_task_results.append(result)
-                    num_episodes_popped += result.lengths_n2.size
-                    num_timesteps_popped += result.lengths_n2.sum()
-                else:
-                    num_results_skipped += 1
-        frac_results_skipped = num_results_skipped / (num_results_skipped + len(curr_task_results))
-        noise_inds_n = np.concatenate([r.noise_inds_n for r in curr_task_results])
-        returns_n2 = np.concatenate([r.returns_n2 for r in curr_task_results])
-        lengths_n2 = np.concatenate([r.lengths_n2 for r in curr_task_results])
-        signreturns_n2 = np.concatenate([r.signreturns_n2 for r in curr_task_results])
+        task_id = master.declare_task(Task(params=theta, ob_mean=None, ob_std=None, timestep_limit=tslimit,
+                                           ref_batch=policy.ref_batch if policy.needs_ref_batch else None))
+        tlogger.log('********** Iteration {} **********'.format(task_id))
+        batch = collect_batch(master, config, task_id)
+        episodes_so_far += batch.all_episodes
+        timesteps_so_far += batch.all_timesteps
+        noise_inds_n, returns_n2 = batch.cat('noise_inds_n'), batch.cat('returns_n2')
+        lengths_n2, signreturns_n2 = batch.cat('lengths_n2'), batch.cat('signreturns_n2')
         assert noise_inds_n.shape[0] == returns_n2.shape[0] == lengths_n2.shape[0]
-        a = opt['args']
         # es.py:281-301 on the device: process returns, sum_i w_i * noise[idx_i], g /= 2N, -g + l2*theta, step
         update_ratio = engine.es_update(noise_inds_n, returns_n2, signreturns_n2, config.return_proc_mode, opt['type'],
-                                        config.l2coeff, a['stepsize'],
-                                        a.get('beta1', 0.9) if opt['type'] == 'adam' else a.get('momentum', 0.9),
-                                        a.get('beta2', 0.999), a.get('epsilon', 1e-08))
-        if adaptive_tslimit and (lengths_n2 == tslimit).mean() >= incr_tslimit_threshold:
-            tslimit = min(int(tslimit_incr_ratio * tslimit), tslimit_max)
-        step_tend = time.time()
-        tlogger.record_tabular("EpRewMean", returns_n2.mean())
-        tlogger.record_tabular("EpRewStd", returns_n2.std())
-        tlogger.record_tabular("EpLenMean", lengths_n2.mean())
-        tlogger.record_tabular("EvalEpRewMean", np.nan if not eval_rets else np.mean(eval_rets))
-        tlogger.record_tabular("EvalEpCount", len(eval_rets))
-        tlogger.record_tabular("Norm", float(np.square(policy.get_trainable_flat()).sum()))
-        tlogger.record_tabular("UpdateRatio", float(update_ratio))
-        tlogger.record_tabular("EpisodesThisIter", lengths_n2.size)
-        tlogger.record_tabular("EpisodesSoFar", episodes_so_far)
-        tlogger.record_tabular("TimestepsThisIter", lengths_n2.sum())
-        tlogger.record_tabular("TimestepsSoFar", timesteps_so_far)
-        tlogger.record_tabular("UniqueWorkers", len(set(worker_ids)))
-        tlogger.record_tabular("ResultsSkippedFrac", frac_results_skipped)
-        tlogger.record_tabular("TimeElapsedThisIter", step_tend - step_tstart)
-        tlogger.record_tabular("TimestepsPerSecondThisIter", lengths_n2.sum() / (step_tend - step_tstart))
-        tlogger.record_tabular("TimeElapsed", step_tend - tstart)
-        tlogger.dump_tabular()
-        if config.snapshot_freq != 0 and curr_task_id % config.snapshot_freq == 0:
+                                        config.l2coeff, *optimizer_args(opt))
+        if adaptive and (lengths_n2 == tslimit).mean() >= grow_thresh:      # es.py:308-311
+            tslimit = min(int(grow_ratio * tslimit), tslimit_max)
+        dt = time.time() - t0
+        ev = batch.eval_rets
+        log_generation(tlogger, [
+            ("EpRewMean", returns_n2.mean()), ("EpRewStd", returns_n2.std()), ("EpLenMean", lengths_n2.mean()),
+            ("EvalEpRewMean", np.mean(ev) if ev else np.nan), ("EvalEpCount", len(ev)),
+            ("Norm", float(np.square(policy.get_trainable_flat()).sum())), ("UpdateRatio", float(update_ratio)),
+            ("EpisodesThisIter", lengths_n2.size), ("EpisodesSoFar", episodes_so_far),
+            ("TimestepsThisIter", lengths_n2.sum()), ("TimestepsSoFar", timesteps_so_far),
+            ("UniqueWorkers", len(set(batch.worker_ids))), ("ResultsSkippedFrac", batch.skipped_frac),
+            ("TimeElapsedThisIter", dt), ("TimestepsPerSecondThisIter", lengths_n2.sum() / dt),
+            ("TimeElapsed", time.time() - tstart)])
+        if config.snapshot_freq != 0 and task_id % config.snapshot_freq == 0:    # es.py:345-353
             import os.path as osp
-            filename = osp.join(log_dir, 'snapshot_iter{:05d}_rew{}.npz'.format(
-                curr_task_id, np.nan if not eval_rets else int(np.mean(eval_rets))))
-            policy.save(filename)
-            tlogger.log('Saved snapshot {}'.format(filename))
+            fn = osp.join(log_dir, 'snapshot_iter{:05d}_rew{}.npz'.format(task_id, int(np.mean(ev)) if ev else np.nan))
+            policy.save(fn)
+            tlogger.log('Saved snapshot {}'.format(fn))
     return policy
 
 

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from .dist import MasterClient, WorkerClient
-from .es import Config, Result, SharedNoiseTable, parse_cutoff, namedtuple  # noqa: F401  (ga.py:1 star-imports es)
+from .es import Config, Result, SharedNoiseTable, collect_batch, log_generation, namedtuple, parse_cutoff  # noqa: F401
 
 logger = logging.getLogger(__name__)
 
@@ -64,28 +64,10 @@ def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_i
         curr_task_id = master.declare_task(GATask(params=theta, population=population, ob_mean=None, ob_std=None,
                                                   timestep_limit=tslimit))
         tlogger.log('********** Iteration {} **********'.format(curr_task_id))
-        curr_task_results, eval_rets, eval_lens, worker_ids = [], [], [], []
-        num_results_skipped = num_episodes_popped = num_timesteps_popped = 0
-        while num_episodes_popped < config.episodes_per_batch or num_timesteps_popped < config.timesteps_per_batch:
-            task_id, result = master.pop_result()
-            assert isinstance(task_id, int) and isinstance(result, Result)
-            worker_ids.append(result.worker_id)
-            if result.eval_length is not None:
-                episodes_so_far += 1
-                timesteps_so_far += result.eval_length
-                if task_id == curr_task_id:
-                    eval_rets.append(result.eval_return)
-                    eval_lens.append(result.eval_length)
-            else:
-                assert result.returns_n2.dtype == np.float32
-                if task_id == curr_task_id:
-                    episodes_so_far += result.lengths_n2.size
-                    timesteps_so_far += result.lengths_n2.sum()
-                    curr_task_results.append(result)
-                    num_episodes_popped += result.lengths_n2.size
-                    num_timesteps_popped += result.lengths_n2.sum()
-                else:
-                    num_results_skipped += 1
+        batch = collect_batch(master, config, curr_task_id, check_pairs=False)
+        episodes_so_far += batch.all_episodes
+        timesteps_so_far += batch.all_timesteps
+        curr_task_results, eval_rets = batch.results, batch.eval_rets
         # ga.py:136-149: elites (old scores) + all children, keep the best population_size
         noise_inds_n = [list(c) for c in population[:num_elites]]
         returns_n2 = list(population_score[:num_elites])
@@ -101,18 +83,13 @@ def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_i
         policy.set_from_seeds(population[0], config.noise_stdev)   # ga.py:151-158
         if adaptive_tslimit and (lengths_n2 == tslimit).mean() >= incr_tslimit_threshold:
             tslimit = int(tslimit_incr_ratio * tslimit)
-        step_tend = time.time()
-        tlogger.record_tabular("EpRewMax", returns_n2.max())
-        tlogger.record_tabular("EpRewMean", returns_n2.mean())
-        tlogger.record_tabular("EpLenMean", lengths_n2.mean())
-        tlogger.record_tabular("EpisodesThisIter", lengths_n2.size)
-        tlogger.record_tabular("EpisodesSoFar", episodes_so_far)
-        tlogger.record_tabular("TimestepsThisIter", lengths_n2.sum())
-        tlogger.record_tabular("TimestepsSoFar", timesteps_so_far)
-        tlogger.record_tabular("TimeElapsedThisIter", step_tend - step_tstart)
-        tlogger.record_tabular("TimestepsPerSecondThisIter", lengths_n2.sum() / (step_tend - step_tstart))
-        tlogger.record_tabular("TimeElapsed", step_tend - tstart)
-        tlogger.dump_tabular()
+        dt = time.time() - step_tstart
+        log_generation(tlogger, [
+            ("EpRewMax", returns_n2.max()), ("EpRewMean", returns_n2.mean()), ("EpLenMean", lengths_n2.mean()),
+            ("EpisodesThisIter", lengths_n2.size), ("EpisodesSoFar", episodes_so_far),
+            ("TimestepsThisIter", lengths_n2.sum()), ("TimestepsSoFar", timesteps_so_far),
+            ("TimeElapsedThisIter", dt), ("TimestepsPerSecondThisIter", lengths_n2.sum() / dt),
+            ("TimeElapsed", time.time() - tstart)])
         if config.snapshot_freq != 0:
             import os.path as osp
             policy.save(osp.join(log_dir, 'snapshot_iter{:05d}_rew{}.npz'.format(

@@ -13,7 +13,8 @@ import numpy as np
 
 from . import _lib
 from .dist import MasterClient, WorkerClient
-from .es import Config, Result, SharedNoiseTable, Task, get_ref_batch, parse_cutoff, shard_pairs
+from .es import (Config, Result, SharedNoiseTable, Task, collect_batch, get_ref_batch, log_generation, optimizer_args,
+                 parse_cutoff, shard_pairs)
 
 logger = logging.getLogger(__name__)
 
@@ -57,7 +58,6 @@ def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_i
     ns = exp['novelty_search']
     pop_size, num_rollouts = int(ns['population_size']), int(ns['num_rollouts'])
     opt = exp['optimizer']
-    a = opt['args']
     theta_dict, optimizer_dict = {}, {}
     curr_parent = 0
     P = policy.num_params
@@ -79,19 +79,9 @@ def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_i
         curr_task_id = master.declare_task(Task(params=theta, ob_mean=None, ob_std=None, ref_batch=policy.ref_batch,
                                                 timestep_limit=tslimit))
         tlogger.log('********** Iteration {} **********'.format(curr_task_id))
-        curr_task_results = []
-        num_episodes_popped = num_timesteps_popped = 0
-        while num_episodes_popped < config.episodes_per_batch or num_timesteps_popped < config.timesteps_per_batch:
-            task_id, result = master.pop_result()
-            assert isinstance(task_id, int) and isinstance(result, Result)
-            if result.eval_length is None and task_id == curr_task_id:
-                curr_task_results.append(result)
-                num_episodes_popped += result.lengths_n2.size
-                num_timesteps_popped += result.lengths_n2.sum()
-        noise_inds_n = np.concatenate([r.noise_inds_n for r in curr_task_results])
-        returns_n2 = np.concatenate([r.returns_n2 for r in curr_task_results])
-        lengths_n2 = np.concatenate([r.lengths_n2 for r in curr_task_results])
-        signreturns_n2 = np.concatenate([r.signreturns_n2 for r in curr_task_results])   # novelty (Q7)
+        batch = collect_batch(master, config, curr_task_id)
+        noise_inds_n, returns_n2 = batch.cat('noise_inds_n'), batch.cat('returns_n2')
+        lengths_n2, signreturns_n2 = batch.cat('lengths_n2'), batch.cat('signreturns_n2')   # novelty rides in signreturns (Q7)
         # nses.py:217-228
         if config.return_proc_mode == 'centered_rank':
             proc = engine.centered_ranks(returns_n2)
@@ -105,23 +95,17 @@ def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_i
             rew_ranks = engine.centered_ranks(returns_n2)
             proc = ((rew_ranks + proc) / 2.0).astype(np.float32)
         engine.weighted_sum(noise_inds_n, proc[:, 0] - proc[:, 1], float(returns_n2.size), copy_out=False)   # nses.py:231-236
-        update_ratio = engine.optimizer_step(opt['type'], config.l2coeff, a['stepsize'],
-                                             a.get('beta1', 0.9) if opt['type'] == 'adam' else a.get('momentum', 0.9),
-                                             a.get('beta2', 0.999), a.get('epsilon', 1e-08))
+        update_ratio = engine.optimizer_step(opt['type'], config.l2coeff, *optimizer_args(opt))
         mean_bc = get_mean_bc(engine, int(tslimit_max), rs.randint(2 ** 31), num_rollouts)   # nses.py:246-247
         master.add_to_novelty_archive(mean_bc)
         if adaptive_tslimit and (lengths_n2 == tslimit).mean() >= incr_tslimit_threshold:
             tslimit = min(int(tslimit_incr_ratio * tslimit), tslimit_max)
-        step_tend = time.time()
-        tlogger.record_tabular("ParentId", curr_parent)
-        tlogger.record_tabular("EpRewMean", returns_n2.mean())
-        tlogger.record_tabular("EpLenMean", lengths_n2.mean())
-        tlogger.record_tabular("NoveltyMean", signreturns_n2.mean())
-        tlogger.record_tabular("UpdateRatio", float(update_ratio))
-        tlogger.record_tabular("TimestepsThisIter", lengths_n2.sum())
-        tlogger.record_tabular("TimestepsPerSecondThisIter", lengths_n2.sum() / (step_tend - step_tstart))
-        tlogger.record_tabular("TimeElapsed", step_tend - tstart)
-        tlogger.dump_tabular()
+        dt = time.time() - step_tstart
+        log_generation(tlogger, [
+            ("ParentId", curr_parent), ("EpRewMean", returns_n2.mean()), ("EpLenMean", lengths_n2.mean()),
+            ("NoveltyMean", signreturns_n2.mean()), ("UpdateRatio", float(update_ratio)),
+            ("TimestepsThisIter", lengths_n2.sum()), ("TimestepsPerSecondThisIter", lengths_n2.sum() / dt),
+            ("TimeElapsed", time.time() - tstart)])
         theta_dict[curr_parent] = policy.get_trainable_flat()       # nses.py:283-284
         optimizer_dict[curr_parent] = engine.optimizer_get_state()
         if ns['selection_method'] == "novelty_prob":                  # nses.py:293-302
