@@ -743,7 +743,9 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     const bool prof = h->cfg.profile_events != 0;
     // record_bc engines always record (the trajectories feed dne_novelty_batch on the device); bc_out only controls the download
     const int bc_mode = h->bc ? (h->L.kind == DNE_KIND_ES ? 1 : 2) : 0;
-    if (bc_mode == 1) HCHECK(h, hipMemsetAsync(h->bc, 0, (size_t)n * h->cfg.bc_max_steps * 128, h->stream));
+    // rows past an episode's length are never read on the device (dne_novelty_batch takes the lengths); zero them only
+    // when the whole buffer is about to be downloaded
+    if (bc_mode == 1 && bc_out) HCHECK(h, hipMemsetAsync(h->bc, 0, (size_t)n * h->cfg.bc_max_steps * 128, h->stream));
     if (bc_mode == 2) HCHECK(h, hipMemsetAsync(h->bc, 0, (size_t)n * 128, h->stream));
     HCHECK(h, hipEventRecord(h->ev_a, h->stream));
     HCHECK(h, hipMemcpyAsync(h->seeds, env_seed, n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
