@@ -1,0 +1,120 @@
+"""GPU: edge cases -- smallest and ragged inputs, limits, ties, refusals (the reference has no tests; these follow the
+runtime asserts it does carry: es.py:196,246-248,297; ga.py:148-149)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+NACT, NREF = 18, 16
+
+
+@pytest.fixture(scope="module")
+def eng(small_noise, oracle):
+    from dne_hip import _lib
+    es = _lib.Engine(_lib.KIND_ES, NACT, max_members=9, ref_count=NREF, record_bc=True, bc_max_steps=12)
+    ga = _lib.Engine(_lib.KIND_GA, NACT, max_members=9)
+    for e in (es, ga):
+        e.noise_upload(small_noise)
+    ref = oracle.get_ref_batch(seed=0, batch_size=NREF, nact=NACT)
+    es.set_ref_batch(ref)
+    es.set_theta(oracle.es_init_theta(oracle.layout(0, NACT), 0))
+    yield es, ga, ref
+    es.close(); ga.close()
+
+
+def test_single_pair_and_single_step(eng, oracle, small_noise):
+    es, _, ref = eng
+    L = oracle.layout(0, NACT)
+    th = es.get_theta()
+    idx = np.array([3_000_000 - 1 - 58], np.int64)          # close to the end of the 4M-entry table
+    idx[0] = small_noise.size - L.P                           # last legal index (es.py:66-67: randint(0, len - dim + 1))
+    seeds = np.array([4294967295, 0], np.uint32)              # extreme seeds (noop counts 1 + seed % 30)
+    for tsl in (1, 2, 12):
+        ret, sg, ln = es.es_eval(idx, 0.02, tsl, seeds)
+        oret, osg, oln = oracle.es_eval(L, th, small_noise, idx, 0.02, tsl, ref, seeds)
+        assert np.array_equal(ret, oret) and np.array_equal(ln, oln) and np.array_equal(sg, osg)
+        assert ln.max() <= tsl
+    # odd member counts through the generic API (groups of one)
+    for n in (1, 3):
+        es.set_members(np.zeros(n, np.int32), np.full(n, 1234, np.int64), np.linspace(-0.02, 0.02, n).astype(np.float32))
+        r, s, l = es.eval_members(n, 5, np.arange(n, dtype=np.uint32))
+        assert r.shape == (n,) and l.max() <= 5
+
+
+def test_refusals(eng, small_noise):
+    from dne_hip import _lib
+    es, ga, _ = eng
+    P = es.P
+    with pytest.raises(_lib.DneError):                         # more pairs than max_members allows
+        es.es_eval(np.zeros(5, np.int64), 0.02, 3, np.zeros(10, np.uint32))
+    with pytest.raises(_lib.DneError):                         # one past the last legal noise index
+        es.es_eval(np.array([small_noise.size - P + 1], np.int64), 0.02, 3, np.zeros(2, np.uint32))
+    with pytest.raises(_lib.DneError):
+        es.es_eval(np.array([-1], np.int64), 0.02, 3, np.zeros(2, np.uint32))
+    with pytest.raises(_lib.DneError):                         # non-positive timestep limit
+        es.es_eval(np.array([0], np.int64), 0.02, 0, np.zeros(2, np.uint32))
+    with pytest.raises(_lib.DneError):                         # GA entry point on an ES engine and vice versa
+        es.ga_eval([[1]], 0.005, 3, np.zeros(1, np.uint32))
+    with pytest.raises(_lib.DneError):
+        ga.es_eval(np.array([0], np.int64), 0.02, 3, np.zeros(2, np.uint32))
+    with pytest.raises(_lib.DneError):
+        ga.set_ref_batch(np.zeros((NREF, 84, 84, 4), np.uint8))
+    with pytest.raises(_lib.DneError):                         # wrong reference-batch size
+        es.set_ref_batch(np.zeros((NREF + 16, 84, 84, 4), np.uint8))
+    with pytest.raises(_lib.DneError):
+        es.centered_ranks(np.zeros(1, np.float32))            # es.py:83 divides by size - 1
+    with pytest.raises(_lib.DneError):
+        es.ga_select(np.zeros(3, np.float32), 4)
+    with pytest.raises(_lib.DneError):                         # BCs requested from an engine without record_bc
+        ga2 = None
+        from dne_hip import _lib as L2
+        e2 = L2.Engine(L2.KIND_ES, NACT, max_members=2, ref_count=NREF)
+        try:
+            e2.noise_upload(small_noise); e2.set_ref_batch(np.zeros((NREF, 84, 84, 4), np.uint8))
+            e2.es_eval(np.array([0], np.int64), 0.02, 3, np.zeros(2, np.uint32), want_bc=True)
+        finally:
+            e2.close()
+
+
+def test_reduce_edges(eng, oracle, small_noise):
+    es, _, _ = eng
+    P = es.P
+    assert np.array_equal(es.centered_ranks(np.array([5.0, 5.0], np.float32)), np.array([-0.5, 0.5], np.float32))
+    x = np.array([[np.inf, -np.inf], [0.0, -0.0], [1e-45, 3.4e38]], np.float32)   # infinities, signed zero, denormal, max
+    assert np.array_equal(es.centered_ranks(x), oracle.centered_ranks(x.reshape(-1)).reshape(x.shape))
+    g = es.weighted_sum(np.array([7], np.int64), np.array([2.5], np.float32), 1.0)
+    assert np.array_equal(g, np.float32(2.5) * small_noise[7:7 + P])
+    g0 = es.weighted_sum(np.array([7, 9], np.int64), np.zeros(2, np.float32), 4.0)
+    assert not g0.any()
+    scores = np.array([10, 30, 30, 10, 30], np.float32)       # ties at and above the cut
+    assert es.ga_select(scores, 1).tolist() == [1] and es.ga_select(scores, 4).tolist() == [1, 2, 4, 0]
+    assert es.ga_select(scores, 5).tolist() == [1, 2, 4, 0, 3]
+    assert es.ga_select(np.array([3.0], np.float32), 1).tolist() == [0]
+
+
+def test_ga_ragged_chains_and_elite_reuse(eng, oracle, small_noise):
+    _, ga, _ = eng
+    L = oracle.layout(1, NACT)
+    hi = small_noise.size - L.P
+    chains = [[5], [5, 77], [5, 77, 1999], [hi], [hi, 0, hi, 0, hi, 0, hi], [123456, 5]]   # lengths 1..7, shared prefixes
+    seeds = np.arange(len(chains), dtype=np.uint32) * 7919
+    ret, sg, ln = ga.ga_eval(chains, 0.005, 9, seeds)
+    for i, c in enumerate(chains):
+        th = oracle.ga_rebuild(L, small_noise, c, 0.005)
+        assert (ret[i], sg[i], ln[i]) == oracle.rollout(L, th, None, seeds[i], 9)[:3], c
+    # same chains again: everything is served from the parent cache, results identical
+    ret2, sg2, ln2 = ga.ga_eval(chains, 0.005, 9, seeds)
+    assert np.array_equal(ret, ret2) and np.array_equal(ln, ln2)
+    with pytest.raises(Exception):
+        ga.ga_eval([[]], 0.005, 3, np.zeros(1, np.uint32))
+
+
+def test_novelty_length_cases(eng, oracle):
+    es, _, _ = eng
+    rs = np.random.RandomState(0)
+    bc = rs.randint(0, 256, (9, 128)).astype(np.uint8)
+    arch = [rs.randint(0, 256, (n, 128)).astype(np.uint8) for n in (1, 9, 8, 10, 300)]   # shorter, equal, longer (nses.py:12-20)
+    arch.append(bc.copy())                                                                  # identical trajectory: distance 0
+    for k in (1, 3, 6, 50):                                                                 # k larger than the archive too
+        assert es.novelty(arch, bc, k) == oracle.novelty(arch, bc, k)
+    assert es.novelty([bc.copy()], bc, 1) == 0.0
+    assert es.novelty(arch, bc[:1], 2) == oracle.novelty(arch, bc[:1], 2)                   # single-row BC
