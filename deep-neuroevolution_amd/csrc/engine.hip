@@ -420,6 +420,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     if (cfg->record_bc) {
         h->bc_bytes = cfg->policy_kind == DNE_KIND_ES ? M * (size_t)std::max(cfg->bc_max_steps, 1) * 128 : M * 128;
         CH(dalloc(&h->bc, h->bc_bytes));
+        CH(hipMemset(h->bc, 0, h->bc_bytes));   // the emulator writes the RAM_LIVE bytes of a row; the other bytes of the 128 stay zero for good
     }
     h->scratch_cap = std::max<size_t>(4 * M + 64, 65536);
     CH(dalloc(&h->scratch_f, h->scratch_cap)); CH(dalloc(&h->scratch_i, h->scratch_cap));
@@ -691,7 +692,7 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
     if (count <= h->fc_tail_max) {   // latency-bound regime: 4 workgroups per group + a separate output-layer kernel
 #define FCT(NV, BN)                                                                                                          \
     do {                                                                                                                     \
-        if (count <= h->fc_quad_max) hipLaunchKernelGGL((k_fc_quad<NV, BN>), dim3(count * 64), dim3(64), 0, st, A, list, (const float *)h->y2, h->y3t); \
+        if (count <= h->fc_quad_max) hipLaunchKernelGGL((k_fc_quad<NV, BN>), dim3(count * 64), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
         else hipLaunchKernelGGL((k_fc_cols<NV, BN>), dim3(count * 4), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
         hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->y3, h->action, logits); \
     } while (0)

@@ -573,10 +573,15 @@ __device__ __forceinline__ float quad_from_prev(float v) {   // lane r of every 
 }
 
 template <int NV, bool HAS_BN>
-__global__ __launch_bounds__(64) void k_fc_quad(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
-                                                float *__restrict__ y3t /*[member][4 slices][256]*/) {
+__global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
+                                                 float *__restrict__ y3t /*[member][4 slices][256]*/) {
+    // One workgroup per (group, 16-column block, k-slice).  Its four waves split the slice's 242 four-row groups
+    // 61/61/60/60: every wave has ALL of its rows in flight at once (4x the bytes in flight of a one-wave block --
+    // this regime is pure load latency), perturbs them in registers, and then the waves run their parts of the
+    // ordered chain one after the other, handing the per-lane chain value over through LDS.
     __shared__ __attribute__((aligned(16))) float xs[NV][968];
-    const int lane = threadIdx.x, rg = lane & 3, cl = lane >> 2;
+    __shared__ float hand[NV][64];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, rg = lane & 3, cl = lane >> 2;
     const Layout &L = A.L;
     const int item = blockIdx.x >> 6, cg = (blockIdx.x >> 2) & 15, sl = blockIdx.x & 3;
     const int g = list ? list[item] : item;
@@ -588,74 +593,85 @@ __global__ __launch_bounds__(64) void k_fc_quad(FwdArgs A, const int *__restrict
     const float *base = A.bases + (size_t)A.m_slot[member[0]] * A.base_stride;
     const int col = cg * 16 + cl;
     const int kbeg = 968 * sl;
-    const float *eps = A.noise + off + L.fcw + (size_t)(kbeg + rg) * 256 + col;
-    const float *th = base + L.fcw + (size_t)(kbeg + rg) * 256 + col;
-    constexpr int GB = 22, NBT = 242 / GB;   // 242 four-row groups per slice, 22 per batch, next batch in flight
-    float e_cur[GB], t_cur[GB], e_nxt[GB], t_nxt[GB];
+    constexpr int GW = 61;                                   // groups per wave (the last two waves use 60)
+    const int g0 = wv * 60 + (wv < 2 ? wv : 2), ng = wv < 2 ? 61 : 60;
+    const float *eps = A.noise + off + L.fcw + (size_t)(kbeg + 4 * g0 + rg) * 256 + col;
+    const float *th = base + L.fcw + (size_t)(kbeg + 4 * g0 + rg) * 256 + col;
+    float e[GW], t[GW];
 #pragma unroll
-    for (int i = 0; i < GB; i++) { e_cur[i] = eps[(size_t)(4 * i) * 256]; t_cur[i] = th[(size_t)(4 * i) * 256]; }
-    {   // activations of this slice: all 16 loads per vector are issued together, then bn2 + relu into LDS
-        float yv[NV][16], s2[NV], h2[NV];
-        const int ch = (kbeg + lane) & 31;   // 968 = 8 (mod 32) and the stride is 64: one bn2 channel per lane
+    for (int i = 0; i < GW; i++) {
+        const int ii = i < ng ? i : ng - 1;                  // wave-uniform clamp: the 61st load of a 60-group wave is a repeat
+        e[i] = eps[(size_t)(4 * ii) * 256];
+        t[i] = th[(size_t)(4 * ii) * 256];
+    }
+    {   // activations of this slice (bn2 + relu) into LDS, 256 threads
+        const int ch0 = kbeg & 31;
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-            s2[v] = HAS_BN ? A.bn[(size_t)member[v] * 608 + 32 + ch] : 1.0f;
-            h2[v] = HAS_BN ? A.bn[(size_t)member[v] * 608 + 64 + ch] : 0.0f;
+            float yv[4];
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int i = lane + 64 * j;
-                yv[v][j] = i < 968 ? y2[(size_t)member[v] * 3872 + kbeg + i] : 0.0f;
+            for (int j = 0; j < 4; j++) {
+                const int i = tid + 256 * j;
+                yv[j] = i < 968 ? y2[(size_t)member[v] * 3872 + kbeg + i] : 0.0f;
             }
-        }
 #pragma unroll
-        for (int v = 0; v < NV; v++)
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int i = lane + 64 * j;
+            for (int j = 0; j < 4; j++) {
+                const int i = tid + 256 * j;
                 if (i < 968) {
-                    float t = yv[v][j];
+                    float x = yv[j];
                     if (HAS_BN) {
-                        t = t * s2[v];
-                        t = t + h2[v];
+                        const int ch = (ch0 + i) & 31;
+                        x = x * A.bn[(size_t)member[v] * 608 + 32 + ch];
+                        x = x + A.bn[(size_t)member[v] * 608 + 64 + ch];
                     }
-                    xs[v][i] = t > 0.0f ? t : 0.0f;
+                    xs[v][i] = x > 0.0f ? x : 0.0f;
                 }
             }
+        }
+    }
+    // perturbed weights in place: e[] <- the first member's weight, t[] <- the second's
+#pragma unroll
+    for (int i = 0; i < GW; i++) {
+        const float ee = e[i], tt = t[i];
+        float pv = scale[0] * ee;
+        e[i] = tt + pv;
+        if (NV == 2) {
+            float pw = scale[NV - 1] * ee;
+            t[i] = tt + pw;
+        }
     }
     __syncthreads();
     float acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) acc[v] = 0.0f;
-    for (int bt = 0; bt < NBT; bt++) {
-        if (bt + 1 < NBT) {
+    for (int p = 0; p < 4; p++) {
+        if (wv == p) {
+            if (p > 0) {
 #pragma unroll
-            for (int i = 0; i < GB; i++) {
-                e_nxt[i] = eps[(size_t)(4 * ((bt + 1) * GB + i)) * 256];
-                t_nxt[i] = th[(size_t)(4 * ((bt + 1) * GB + i)) * 256];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the chain below (hipcc otherwise sinks the loads)
-#pragma unroll
-        for (int i = 0; i < GB; i++) {
-            float w[NV];
-            f4a x4[NV];
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                float pv = scale[v] * e_cur[i];
-                w[v] = t_cur[i] + pv;                                        // this lane's row 4g + rg
-                x4[v] = *(const f4a *)&xs[v][4 * (bt * GB + i)];             // activations of rows 4g .. 4g+3 (broadcast)
+                for (int v = 0; v < NV; v++) acc[v] = hand[v][lane];
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int i = 0; i < GW; i++) {
+                if (i < ng) {
+                    f4a x4[NV];
 #pragma unroll
-                for (int v = 0; v < NV; v++) acc[v] = __builtin_fmaf(x4[v][j], w[v], quad_from_prev(acc[v]));   // meaningful in lane rg == j
+                    for (int v = 0; v < NV; v++) x4[v] = *(const f4a *)&xs[v][4 * (g0 + i)];   // rows 4g .. 4g+3 (broadcast)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int v = 0; v < NV; v++)
+                            acc[v] = __builtin_fmaf(x4[v][j], v == 0 ? e[i] : t[i], quad_from_prev(acc[v]));   // meaningful in lane rg == j
+                }
+            }
+            if (p < 3) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) hand[v][lane] = acc[v];
+            } else if (rg == 3) {   // after the last row (4g + 3) the chain value sits in lane 3 of the quad
+#pragma unroll
+                for (int v = 0; v < NV; v++) y3t[((size_t)member[v] * 4 + sl) * 256 + col] = acc[v];
+            }
         }
-#pragma unroll
-        for (int i = 0; i < GB; i++) { e_cur[i] = e_nxt[i]; t_cur[i] = t_nxt[i]; }
-    }
-    if (rg == 3) {   // after the last row (4g + 3) the chain value sits in lane 3 of the quad
-#pragma unroll
-        for (int v = 0; v < NV; v++) y3t[((size_t)member[v] * 4 + sl) * 256 + col] = acc[v];
+        if (p < 3) __syncthreads();
     }
 }
 

@@ -118,3 +118,24 @@ def test_novelty_length_cases(eng, oracle):
         assert es.novelty(arch, bc, k) == oracle.novelty(arch, bc, k)
     assert es.novelty([bc.copy()], bc, 1) == 0.0
     assert es.novelty(arch, bc[:1], 2) == oracle.novelty(arch, bc[:1], 2)                   # single-row BC
+
+
+def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
+    """trajectories kept on the device (no download, no clearing): rows past an episode's length hold the previous
+    run's data and must not influence novelty; bytes past the emulator's live RAM stay zero"""
+    es, _, ref = eng
+    L = oracle.layout(0, NACT)
+    th = es.get_theta()
+    idx = np.array([100, 2000, 30000], np.int64)
+    seeds = np.arange(6, dtype=np.uint32) + 11
+    _, _, ln_long, bc_long = es.es_eval(idx, 0.02, 12, seeds, want_bc=True)        # fills all 12 rows
+    assert ln_long.max() == 12 and bc_long.reshape(6, 12, 128)[:, :, 40:].max() == 0
+    ret, sg, ln = es.es_eval(idx[::-1].copy(), 0.02, 5, seeds[::-1].copy())        # shorter, different members, stays on the device
+    rs = np.random.RandomState(1)
+    arch = [rs.randint(0, 256, (n, 128)).astype(np.uint8) for n in (3, 5, 12)]
+    nov = es.novelty_batch(arch, ln.reshape(-1), 2)
+    for i in range(3):
+        for s in range(2):
+            thp = oracle.perturb(th, small_noise, idx[::-1][i], 0.02, 1 if s == 0 else -1)
+            r, _, l, bc = oracle.rollout(L, thp, ref, seeds[::-1][2 * i + s], 5, want_bc=True)
+            assert l == ln[i, s] and nov[2 * i + s] == oracle.novelty(arch, bc, 2)
