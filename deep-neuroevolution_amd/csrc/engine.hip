@@ -86,18 +86,12 @@ __global__ __launch_bounds__(64) void k_env_reset_logic(EnvArgs E, const uint32_
     E.ret[m] = 0.0f; E.sign[m] = 0.0f; E.step_reward[m] = 0.0f; E.len[m] = 0; E.done[m] = 0; E.stepped[m] = 1;
 }
 
-__global__ __launch_bounds__(64) void k_env_logic(EnvArgs E, const int *__restrict__ list, int gsize, int n_items, int tslimit) {
-    __shared__ __attribute__((aligned(16))) uint8_t rows[64][2][RAM_STRIDE];
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= n_items) return;
-    const int g = list ? list[b / gsize] : b / gsize;
-    const int m = g * gsize + b % gsize;
-    if (E.done[m]) { E.stepped[m] = 0; return; }
-    uint8_t *prev = rows[threadIdx.x][0], *cur = rows[threadIdx.x][1];
+// one wrapped step of member m (atari_wrappers.py:88-107 skip-4 + the episode bookkeeping of policies.py:399-425);
+// prev / cur are the member's RAM rows in LDS, already loaded; the caller is a single lane
+__device__ __forceinline__ void env_member_step(const EnvArgs &E, int m, uint8_t *prev, uint8_t *cur, int action, int tslimit) {
     uint32_t *gp = (uint32_t *)(E.ram_prev + (size_t)m * 128), *gc = (uint32_t *)(E.ram_cur + (size_t)m * 128);
-    for (int j = 0; j < RAM_LIVE / 4; j++) { ((uint32_t *)prev)[j] = gp[j]; ((uint32_t *)cur)[j] = gc[j]; }
     int over;
-    const int r = skip4(prev, cur, E.action[m], &over);
+    const int r = skip4(prev, cur, action, &over);
     for (int j = 0; j < RAM_LIVE / 4; j++) { gp[j] = ((const uint32_t *)prev)[j]; gc[j] = ((const uint32_t *)cur)[j]; }
     const int t = E.len[m];
     if (E.bc_mode == 1 && t < E.bc_max_steps) {     // policies.py:410,418 RAM after every step
@@ -117,6 +111,19 @@ __global__ __launch_bounds__(64) void k_env_logic(EnvArgs E, const int *__restri
     if (over || t + 1 >= tslimit) E.done[m] = 1;             // policies.py:401,424-425
 }
 
+__global__ __launch_bounds__(64) void k_env_logic(EnvArgs E, const int *__restrict__ list, int gsize, int n_items, int tslimit) {
+    __shared__ __attribute__((aligned(16))) uint8_t rows[64][2][RAM_STRIDE];
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= n_items) return;
+    const int g = list ? list[b / gsize] : b / gsize;
+    const int m = g * gsize + b % gsize;
+    if (E.done[m]) { E.stepped[m] = 0; return; }
+    uint8_t *prev = rows[threadIdx.x][0], *cur = rows[threadIdx.x][1];
+    const uint32_t *gp = (const uint32_t *)(E.ram_prev + (size_t)m * 128), *gc = (const uint32_t *)(E.ram_cur + (size_t)m * 128);
+    for (int j = 0; j < RAM_LIVE / 4; j++) { ((uint32_t *)prev)[j] = gp[j]; ((uint32_t *)cur)[j] = gc[j]; }
+    env_member_step(E, m, prev, cur, E.action[m], tslimit);
+}
+
 // max over the last two raw frames + WarpFrame + FrameStack for every member stepped by the logic kernel
 __global__ __launch_bounds__(1024) void k_env_render(EnvArgs E, const int *__restrict__ list, int gsize, int fill) {
     __shared__ __attribute__((aligned(16))) EnvLds s;
@@ -131,6 +138,75 @@ __global__ __launch_bounds__(1024) void k_env_render(EnvArgs E, const int *__res
     }
     __syncthreads();
     synth_observe(s, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), fill != 0);
+}
+
+// Tail of a generation (a few dozen members left, every kernel boundary is a visible bubble): one workgroup per
+// member finishes the policy's forward pass from the fc partial sums (k_out's arithmetic: ((s0+s1)+(s2+s3)) + bias,
+// bn3, relu, the 256 x nact output layer as ordered fmaf chains, first-maximum argmax), steps the emulator with the
+// chosen action on one lane, and renders the new observation -- k_out + k_env_logic + k_env_render in one launch.
+template <bool HAS_BN>
+__global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const int *__restrict__ list, int gsize, int tslimit,
+                                                     const float *__restrict__ y3t, float *__restrict__ y3,
+                                                     int32_t *__restrict__ actions) {
+    __shared__ __attribute__((aligned(16))) EnvLds s;
+    __shared__ float a3[256];
+    __shared__ float lg[32];
+    __shared__ float wo[256 * 32];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int g = list ? list[b / gsize] : b / gsize;
+    const int m = g * gsize + b % gsize;
+    if (E.done[m]) { if (tid == 0) E.stepped[m] = 0; return; }
+    const Layout &L = A.L;
+    const int nact = L.nact;
+    const float sc = A.m_scale[m];
+    const int64_t off = A.m_off[m];
+    const float *base = A.bases + (size_t)A.m_slot[m] * A.base_stride;
+    if (tid < 64) {
+        s.ram_prev[tid] = E.ram_prev[(size_t)m * 128 + tid];
+        s.ram_cur[tid] = E.ram_cur[(size_t)m * 128 + tid];
+    }
+    if (tid < 256) {
+        const float *p = y3t + (size_t)m * 4 * 256 + tid;
+        const float s01 = p[0] + p[256];
+        const float s23 = p[512] + p[768];
+        float t = s01 + s23;
+        float pvb = sc * A.noise[off + L.fcb + tid];
+        const float fb = base[L.fcb + tid] + pvb;
+        t = t + fb;
+        y3[(size_t)m * 256 + tid] = t;
+        if (HAS_BN) {
+            t = t * A.bn[(size_t)m * 608 + 96 + tid];
+            t = t + A.bn[(size_t)m * 608 + 352 + tid];
+        }
+        a3[tid] = t > 0.0f ? t : 0.0f;
+    }
+    {
+        const float *wb = base + L.ow, *we = A.noise + off + L.ow;
+        for (int i = tid; i < 256 * nact; i += 1024) {
+            float pv = sc * we[i];
+            wo[i] = wb[i] + pv;
+        }
+    }
+    synth_load_tables(s, E.T);
+    __syncthreads();
+    if (tid < nact) {
+        float acc = 0.0f;
+#pragma unroll 16
+        for (int k = 0; k < 256; k++) acc = __builtin_fmaf(a3[k], wo[k * nact + tid], acc);
+        float pv = sc * A.noise[off + L.ob + tid];
+        const float bias = base[L.ob + tid] + pv;
+        lg[tid] = acc + bias;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int best = 0;
+        for (int a = 1; a < nact; a++)
+            if (lg[a] > lg[best]) best = a;   // tf.argmax: first maximum
+        actions[m] = best;
+        env_member_step(E, m, s.ram_prev, s.ram_cur, best, tslimit);
+    }
+    __syncthreads();
+    synth_observe(s, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), false);
 }
 
 // order-preserving compaction of the active-group list
@@ -173,6 +249,7 @@ struct dne_handle {
     std::vector<hipStream_t> sub_streams;   // sub-batch streams (sub_streams[0] == stream)
     int dbg_skip = 0;   // DNE_DEBUG_SKIP bitmask (timing experiments only): 1 conv1, 2 conv2, 4 render
     int render_threads = 256;
+    int tail_fused_max = 32;         // up to this many active groups k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
     int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_quad_max = 24, fc_rb = 4, fc_chain_min = 1 << 30;
     int M = 0, F = 0, ref_chunk = 0;
     size_t base_stride = 0;
@@ -374,6 +451,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     if (const char *e = getenv("DNE_FC_TAIL_MAX")) h->fc_tail_max = std::max(0, atoi(e));
     if (const char *e = getenv("DNE_DEBUG_SKIP")) h->dbg_skip = atoi(e);
     if (const char *e = getenv("DNE_RENDER_THREADS")) h->render_threads = atoi(e);
+    if (const char *e = getenv("DNE_TAIL_FUSED_MAX")) h->tail_fused_max = atoi(e);
     if (const char *e = getenv("DNE_FC_CHAIN_MIN")) h->fc_chain_min = atoi(e);
     if (const char *e = getenv("DNE_FC_RB")) h->fc_rb = atoi(e);
     if (const char *e = getenv("DNE_FC_GRID")) h->fc_grid = std::max(1, atoi(e));
@@ -685,7 +763,8 @@ static void launch_forward(dne_handle *h, const int *list, int count, int gsize,
     else hipLaunchKernelGGL((k_conv2<false>), dim3(items * s2), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2, s2);
 }
 
-static void launch_fc(dne_handle *h, const int *list, int count, int gsize, float *logits, hipStream_t st = nullptr) {
+static void launch_fc(dne_handle *h, const int *list, int count, int gsize, float *logits, hipStream_t st = nullptr,
+                      bool out_fused = false /* tail only: the caller runs k_tail_step instead of k_out */) {
     if (!st) st = h->stream;
     const FwdArgs A = h->fwd(false);
     const bool es = h->L.kind == DNE_KIND_ES;
@@ -694,7 +773,7 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
     do {                                                                                                                     \
         if (count <= h->fc_quad_max) hipLaunchKernelGGL((k_fc_quad<NV, BN>), dim3(count * 64), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
         else hipLaunchKernelGGL((k_fc_cols<NV, BN>), dim3(count * 4), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
-        hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->y3, h->action, logits); \
+        if (!out_fused) hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->y3, h->action, logits); \
     } while (0)
         if (gsize == 2) { if (es) FCT(2, true); else FCT(2, false); }
         else { if (es) FCT(1, true); else FCT(1, false); }
@@ -805,11 +884,16 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 const bool chain = nsub > 1 && cnt >= h->fc_chain_min;
                 if (chain && last_fc) HCHECK(h, hipStreamWaitEvent(sst, last_fc, 0));
                 if (pe) { e[1] = ne++; HCHECK(h, hipEventRecord(h->event(e[1]), sst)); }   // after the wait: brackets fc only
-                launch_fc(h, lst, cnt, gsize, nullptr, sst);
+                const bool tail = cnt <= std::min(h->tail_fused_max, h->fc_tail_max);
+                launch_fc(h, lst, cnt, gsize, nullptr, sst, tail);
                 if (chain) { last_fc = h->fc_ring[fc_ring_pos++ % h->fc_ring.size()]; HCHECK(h, hipEventRecord(last_fc, sst)); }
                 if (pe) { e[2] = ne++; HCHECK(h, hipEventRecord(h->event(e[2]), sst)); }
                 E.step_counter = pe ? h->launch_units + evs.size() : nullptr;
-                launch_env_step(h, E, lst, cnt, gsize, tslimit, sst);
+                if (tail) {
+                    const FwdArgs A = h->fwd(false);
+                    if (h->L.kind == DNE_KIND_ES) hipLaunchKernelGGL(k_tail_step<true>, dim3(cnt * gsize), dim3(1024), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
+                    else hipLaunchKernelGGL(k_tail_step<false>, dim3(cnt * gsize), dim3(1024), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
+                } else launch_env_step(h, E, lst, cnt, gsize, tslimit, sst);
                 if (pe) { e[3] = ne++; HCHECK(h, hipEventRecord(h->event(e[3]), sst)); evs.push_back(e); }
                 group_steps += cnt;
                 launch_sets++;

@@ -264,6 +264,16 @@ __device__ inline void synth_load_tables(EnvLds &s, const ResizeLds *__restrict_
 // synth_load_tables and after ram_prev / ram_cur are in LDS.
 __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bool fill) {
     const int tid = threadIdx.x, nthr = blockDim.x;   // 256 threads normally, 1024 when few members remain
+    constexpr int VP = 7;
+    uint32_t old[VP] = {};
+    const bool pre = !fill && nthr * VP >= 84 * 84;
+    if (pre) {
+#pragma unroll
+        for (int j = 0; j < VP; j++) {
+            const int i = tid + j * nthr;
+            old[j] = i < 84 * 84 ? stack[i] : 0u;
+        }
+    }
     if (tid < 192) s.slot_of_key[tid] = -1;
     if (tid == 0) s.misc[2] = 0;
     __syncthreads();
@@ -296,16 +306,31 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
         s.tmp[i] = (float)acc;
     }
     __syncthreads();
-    for (int i = tid; i < 84 * 84; i += nthr) {   // vertical pass + u8 truncation + stack shift
-        const int yy = i / 84, xx = i % 84;
-        const uint8_t *sl = s.slot_of_y + s.R.ymin[yy];
-        const double *k = s.R.kv + yy * 7;
-        double acc = 0.0;
+    // vertical pass + u8 truncation + stack shift.  The old stack words are fetched VP at a time (all of them before
+    // the first barrier when the workgroup covers the stack in one go) so that the global-load latency is paid once
+    // per chunk, not once per pixel.
+    for (int base = 0; base < 84 * 84; base += nthr * VP) {
+        if (!pre && !fill) {
 #pragma unroll
-        for (int t = 0; t < 7; t++) acc = acc + (double)s.tmp[sl[t] * 84 + xx] * k[t];
-        const uint32_t pix = (uint32_t)(uint8_t)(float)acc;
-        uint32_t *p = stack + i;
-        *p = fill ? pix * 0x01010101u : ((*p >> 8) | (pix << 24));
+            for (int j = 0; j < VP; j++) {
+                const int i = base + tid + j * nthr;
+                old[j] = i < 84 * 84 ? stack[i] : 0u;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VP; j++) {
+            const int i = base + tid + j * nthr;
+            if (i < 84 * 84) {
+                const int yy = i / 84, xx = i % 84;
+                const uint8_t *sl = s.slot_of_y + s.R.ymin[yy];
+                const double *k = s.R.kv + yy * 7;
+                double acc = 0.0;
+#pragma unroll
+                for (int t = 0; t < 7; t++) acc = acc + (double)s.tmp[sl[t] * 84 + xx] * k[t];
+                const uint32_t pix = (uint32_t)(uint8_t)(float)acc;
+                stack[i] = fill ? pix * 0x01010101u : ((old[j] >> 8) | (pix << 24));
+            }
+        }
     }
 }
 

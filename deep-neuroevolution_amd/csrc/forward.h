@@ -568,8 +568,9 @@ __global__ __launch_bounds__(256) void k_bn3_partials(FwdArgs A, int member0, in
 // v_mov_dpp quad_perm + one v_fma per row.  Same 4 k-slices, same row order, same bits; 4x fewer load
 // instructions per slice.  One single-wave workgroup per (group, 16-column group, k-slice): 64 CUs per pair.
 // The ((s0+s1)+(s2+s3)) + bias combine, bn3, the 256 x nact output layer and the argmax run in k_out.
-__device__ __forceinline__ float quad_from_prev(float v) {   // lane r of every quad receives lane (r-1)&3's value
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x93, 0xf, 0xf, true));
+template <int J>
+__device__ __forceinline__ float quad_bcast(float v) {   // every lane of a quad receives lane J's value (folds into v_fmac_f32_dpp)
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), J * 0x55, 0xf, 0xf, true));
 }
 
 template <int NV, bool HAS_BN>
@@ -578,7 +579,9 @@ __global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restric
     // One workgroup per (group, 16-column block, k-slice).  Its four waves split the slice's 242 four-row groups
     // 61/61/60/60: every wave has ALL of its rows in flight at once (4x the bytes in flight of a one-wave block --
     // this regime is pure load latency), perturbs them in registers, and then the waves run their parts of the
-    // ordered chain one after the other, handing the per-lane chain value over through LDS.
+    // ordered chain one after the other, handing the chain value over through LDS.  Lane (rg, cl) loads row 4g + rg of
+    // column cl; the chain takes row j's weight from lane j of the quad with a DPP operand, so all four lanes of a quad
+    // carry the same value.
     __shared__ __attribute__((aligned(16))) float xs[NV][968];
     __shared__ float hand[NV][64];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, rg = lane & 3, cl = lane >> 2;
@@ -650,23 +653,38 @@ __global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restric
 #pragma unroll
                 for (int v = 0; v < NV; v++) acc[v] = hand[v][lane];
             }
+            f4a xn[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) xn[v] = *(const f4a *)&xs[v][4 * g0];   // rows 4g .. 4g+3 (broadcast), one group ahead
 #pragma unroll
             for (int i = 0; i < GW; i++) {
                 if (i < ng) {
                     f4a x4[NV];
 #pragma unroll
-                    for (int v = 0; v < NV; v++) x4[v] = *(const f4a *)&xs[v][4 * (g0 + i)];   // rows 4g .. 4g+3 (broadcast)
+                    for (int v = 0; v < NV; v++) {
+                        x4[v] = xn[v];
+                        xn[v] = *(const f4a *)&xs[v][4 * (g0 + (i + 1 < GW ? i + 1 : i))];
+                    }
+                    // row 4g + j's weight sits in lane j of the quad and enters the fused multiply-add as a DPP operand
+                    // (v_fmac_f32 = the same single-rounding fma); all four lanes carry the same chain value.  s_nop:
+                    // the two wait states a DPP read needs after a VALU write of its source register.
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-#pragma unroll
-                        for (int v = 0; v < NV; v++)
-                            acc[v] = __builtin_fmaf(x4[v][j], v == 0 ? e[i] : t[i], quad_from_prev(acc[v]));   // meaningful in lane rg == j
+                    for (int v = 0; v < NV; v++) {
+                        const float w = v == 0 ? e[i] : t[i];
+                        asm("s_nop 1\n\t"
+                            "v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                            "v_fmac_f32_dpp %0, %1, %3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                            "v_fmac_f32_dpp %0, %1, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                            "v_fmac_f32_dpp %0, %1, %5 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+                            : "+v"(acc[v])
+                            : "v"(w), "v"(x4[v][0]), "v"(x4[v][1]), "v"(x4[v][2]), "v"(x4[v][3]));
+                    }
                 }
             }
             if (p < 3) {
 #pragma unroll
                 for (int v = 0; v < NV; v++) hand[v][lane] = acc[v];
-            } else if (rg == 3) {   // after the last row (4g + 3) the chain value sits in lane 3 of the quad
+            } else if (rg == 0) {
 #pragma unroll
                 for (int v = 0; v < NV; v++) y3t[((size_t)member[v] * 4 + sl) * 256 + col] = acc[v];
             }
