@@ -207,6 +207,73 @@ __device__ __forceinline__ int synth_pixel(const PixState &p, int x, int y) {
     return (yo & 8) ? 15 : 5;
 }
 
+// the state is the same in every lane: move it to scalar registers
+__device__ __forceinline__ PixState synth_pix_uniform(const PixState &q) {
+    PixState p;
+    p.px = __builtin_amdgcn_readfirstlane(q.px); p.py = __builtin_amdgcn_readfirstlane(q.py);
+    p.temp2 = __builtin_amdgcn_readfirstlane(q.temp2); p.lives10 = __builtin_amdgcn_readfirstlane(q.lives10);
+    p.score = __builtin_amdgcn_readfirstlane(q.score); p.igloo = __builtin_amdgcn_readfirstlane(q.igloo);
+    p.sky = __builtin_amdgcn_readfirstlane(q.sky);
+    p.off4 = __builtin_amdgcn_readfirstlane(q.off4); p.vis4 = __builtin_amdgcn_readfirstlane(q.vis4);
+    p.hzx4 = __builtin_amdgcn_readfirstlane(q.hzx4); p.hza4 = __builtin_amdgcn_readfirstlane(q.hza4);
+    p.blink = __builtin_amdgcn_readfirstlane((int)q.blink) != 0;
+    return p;
+}
+
+// One screen row of one frame as the renderer paints it: background, one periodic pattern, one span above it, the
+// player sprite on top.  Every row class of synth_pixel fits this shape.  All values are wave-uniform and are kept
+// as separate scalars (a struct here ends up in scratch memory: the colour selects turn into indexed loads).
+//   pattern: rel = (x - p_off) mod 160 hits when rel < p_len, rel % p_period < p_width and bit rel / p_period of p_mask
+//            is set (p_recip = ceil(65536 / p_period));  span: [r_lo, r_lo + r_len);  sprite: 8 pixels from s_px, wrapping
+#define DNE_ROW_FIELDS(pre)                                                                                               \
+    int pre##bg, pre##p_off, pre##p_len, pre##p_period, pre##p_recip, pre##p_width, pre##p_col, pre##r_lo, pre##r_len,    \
+        pre##r_col, pre##s_on, pre##s_px;                                                                                 \
+    uint32_t pre##p_mask
+#define DNE_ROW_ARGS(pre)                                                                                                 \
+    pre##bg, pre##p_off, pre##p_len, pre##p_period, pre##p_recip, pre##p_width, pre##p_col, pre##p_mask, pre##r_lo,       \
+        pre##r_len, pre##r_col, pre##s_on, pre##s_px
+
+__device__ __forceinline__ void synth_row_desc(const PixState &p, int y, int &bg, int &p_off, int &p_len, int &p_period,
+                                               int &p_recip, int &p_width, int &p_col, uint32_t &p_mask, int &r_lo, int &r_len,
+                                               int &r_col, int &s_on, int &s_px) {
+    // straight-line selects on the scalar unit
+    const bool hud = y >= 8 && y < 16, sco = y >= 16 && y < 20, sky = y >= 20 && y < 64, shore = y >= 64 && y < 80;
+    const bool wat = y >= 80 && y < 208;
+    const int yw = wat ? y - 80 : 0, r8 = (yw >> 5) * 8, yo = yw & 31;
+    const bool floe = wat && yo >= 16 && yo < 28;
+    const bool haz = wat && yo >= 4 && yo < 12 && ((p.hza4 >> r8) & 255u) != 0u;
+    const bool igl = sky && y >= 40, door = igl && y >= 52 && p.igloo >= 16;
+    int nb = p.igloo - ((63 - (igl ? y : 63)) / 6) * 4;
+    nb = nb < 0 ? 0 : nb > 4 ? 4 : nb;
+    s_on = (!p.blink && (unsigned)(y - p.py) < 16u) ? 1 : 0;
+    s_px = p.px;
+    bg = (hud || sco) ? 1 : sky ? p.sky : shore ? 4 : wat ? ((yo & 8) ? 15 : 5) : 0;
+    p_off = hud ? 120 : sco ? 8 : sky ? 112 : (int)((p.off4 >> r8) & 255u);
+    p_len = hud ? p.lives10 : sco ? 128 : igl ? 32 : floe ? 160 : 0;
+    p_period = hud ? 10 : wat ? 40 : 8;
+    p_recip = hud ? 6554 : wat ? 1639 : 8192;
+    p_width = (hud || sco) ? 6 : sky ? 8 : 32;
+    p_col = hud ? 12 : sco ? 14 : sky ? 10 : (((p.vis4 >> r8) & 255u) ? 7 : 6);
+    p_mask = sco ? (uint32_t)p.score : sky ? (1u << nb) - 1u : 0xffffffffu;
+    r_lo = hud ? 8 : sky ? 124 : (int)((p.hzx4 >> r8) & 255u) - 5;
+    r_len = hud ? p.temp2 - 8 : door ? 8 : haz ? 11 : 0;
+    r_col = hud ? 11 : sky ? 13 : 9;
+}
+
+__device__ __forceinline__ int synth_row_pixel(int x, int bg, int p_off, int p_len, int p_period, int p_recip, int p_width,
+                                               int p_col, uint32_t p_mask, int r_lo, int r_len, int r_col, int s_on, int s_px) {
+    int rel = x - p_off;
+    rel += rel < 0 ? 160 : 0;
+    const int cell = (rel * p_recip) >> 16;              // rel / p_period for 0 <= rel < 160 and the periods 8, 10, 40
+    const int rem = rel - cell * p_period;
+    const bool hit = (rel < p_len) & (rem < p_width) & (((p_mask >> cell) & 1u) != 0u);
+    int c = hit ? p_col : bg;
+    c = (unsigned)(x - r_lo) < (unsigned)r_len ? r_col : c;
+    int sx = x - s_px;
+    sx += sx < 0 ? 160 : 0;
+    return ((s_on != 0) & (sx < 8)) ? 8 : c;
+}
+
 // Screen rows fall into 45 static classes (HUD bands, sky, igloo block rows, shore, 4-row strips of the
 // water) inside which every row has identical pixels, except where the 16-row player sprite of the
 // previous / current frame overlaps.  Only one representative row per (class, player-in-prev,
@@ -290,10 +357,21 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     __syncthreads();
     if (tid < 210) s.slot_of_y[tid] = (uint8_t)s.slot_of_key[key];
     const int nu = min(s.misc[2], ENV_MAX_ROWS);
-    const PixState pp = synth_pix_state(s.ram_prev), pc = synth_pix_state(s.ram_cur);
-    for (int i = tid; i < nu * 160; i += nthr) {
-        const int y = s.rep_y[i / 160], x = i % 160;
-        s.img[i] = (uint8_t)((synth_pixel(pp, x, y) << 4) | synth_pixel(pc, x, y));
+    // one wave per unique row: the row number and the RAM-derived state are wave-uniform, so each row of each frame is
+    // first reduced (on the scalar unit) to a background colour + one periodic pattern + one span + the player sprite,
+    // and the per-pixel work is a short branch-free select chain
+    const PixState pp = synth_pix_uniform(synth_pix_state(s.ram_prev)), pc = synth_pix_uniform(synth_pix_state(s.ram_cur));
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6, lane = tid & 63;
+    for (int u = wave; u < nu; u += nwave) {
+        const int y = __builtin_amdgcn_readfirstlane(s.rep_y[u]);
+        DNE_ROW_FIELDS(a_);
+        DNE_ROW_FIELDS(b_);
+        synth_row_desc(pp, y, DNE_ROW_ARGS(a_));
+        synth_row_desc(pc, y, DNE_ROW_ARGS(b_));
+        uint8_t *row = s.img + u * 160;
+        row[lane] = (uint8_t)((synth_row_pixel(lane, DNE_ROW_ARGS(a_)) << 4) | synth_row_pixel(lane, DNE_ROW_ARGS(b_)));
+        row[lane + 64] = (uint8_t)((synth_row_pixel(lane + 64, DNE_ROW_ARGS(a_)) << 4) | synth_row_pixel(lane + 64, DNE_ROW_ARGS(b_)));
+        if (lane < 32) row[lane + 128] = (uint8_t)((synth_row_pixel(lane + 128, DNE_ROW_ARGS(a_)) << 4) | synth_row_pixel(lane + 128, DNE_ROW_ARGS(b_)));
     }
     __syncthreads();
     for (int i = tid; i < nu * 84; i += nthr) {   // horizontal pass over the unique rows
