@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/dne_hip.h"
@@ -125,9 +126,9 @@ __global__ __launch_bounds__(64) void k_env_logic(EnvArgs E, const int *__restri
 }
 
 // max over the last two raw frames + WarpFrame + FrameStack for every member stepped by the logic kernel
-__global__ __launch_bounds__(1024) void k_env_render(EnvArgs E, const int *__restrict__ list, int gsize, int fill) {
+__global__ __launch_bounds__(1024) void k_env_render(EnvArgs E, const int *__restrict__ list, int gsize, int fill, int nbands) {
     __shared__ __attribute__((aligned(16))) EnvLds s;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x / nbands, band = blockIdx.x % nbands, tid = threadIdx.x;
     const int g = list ? list[b / gsize] : b / gsize;
     const int m = g * gsize + b % gsize;
     if (!E.stepped[m]) return;
@@ -137,18 +138,20 @@ __global__ __launch_bounds__(1024) void k_env_render(EnvArgs E, const int *__res
         s.ram_cur[tid] = E.ram_cur[(size_t)m * 128 + tid];
     }
     __syncthreads();
-    synth_observe(s, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), fill != 0);
+    synth_observe(s, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), fill != 0, band, nbands);
 }
 
 // Tail of a generation (a few dozen members left, every kernel boundary is a visible bubble): one workgroup per
 // member finishes the policy's forward pass from the fc partial sums (k_out's arithmetic: ((s0+s1)+(s2+s3)) + bias,
 // bn3, relu, the 256 x nact output layer as ordered fmaf chains, first-maximum argmax), steps the emulator with the
 // chosen action on one lane, and renders the new observation -- k_out + k_env_logic + k_env_render in one launch.
-template <bool HAS_BN>
+struct RamLds { uint8_t ram_prev[128], ram_cur[128]; };
+
+template <bool HAS_BN, bool RENDER>
 __global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const int *__restrict__ list, int gsize, int tslimit,
                                                      const float *__restrict__ y3t, float *__restrict__ y3,
                                                      int32_t *__restrict__ actions) {
-    __shared__ __attribute__((aligned(16))) EnvLds s;
+    __shared__ __attribute__((aligned(16))) std::conditional_t<RENDER, EnvLds, RamLds> s;
     __shared__ float a3[256];
     __shared__ float lg[32];
     __shared__ float wo[256 * 32];
@@ -182,12 +185,12 @@ __global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const 
     }
     {
         const float *wb = base + L.ow, *we = A.noise + off + L.ow;
-        for (int i = tid; i < 256 * nact; i += 1024) {
+        for (int i = tid; i < 256 * nact; i += blockDim.x) {
             float pv = sc * we[i];
             wo[i] = wb[i] + pv;
         }
     }
-    synth_load_tables(s, E.T);
+    if constexpr (RENDER) synth_load_tables(s, E.T);
     __syncthreads();
     if (tid < nact) {
         float acc = 0.0f;
@@ -205,8 +208,10 @@ __global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const 
         actions[m] = best;
         env_member_step(E, m, s.ram_prev, s.ram_cur, best, tslimit);
     }
-    __syncthreads();
-    synth_observe(s, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), false);
+    if constexpr (RENDER) {
+        __syncthreads();
+        synth_observe(s, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), false);
+    }
 }
 
 // order-preserving compaction of the active-group list
@@ -249,6 +254,7 @@ struct dne_handle {
     std::vector<hipStream_t> sub_streams;   // sub-batch streams (sub_streams[0] == stream)
     int dbg_skip = 0;   // DNE_DEBUG_SKIP bitmask (timing experiments only): 1 conv1, 2 conv2, 4 render
     int render_threads = 256;
+    int render_bands = 4, band_threads = 512;   // tail: workgroups per frame (DNE_RENDER_BANDS, 1 = render inside k_tail_step) and their size
     int tail_fused_max = 32;         // up to this many active groups k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
     int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_quad_max = 24, fc_rb = 4, fc_chain_min = 1 << 30;
     int M = 0, F = 0, ref_chunk = 0;
@@ -452,6 +458,8 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     if (const char *e = getenv("DNE_DEBUG_SKIP")) h->dbg_skip = atoi(e);
     if (const char *e = getenv("DNE_RENDER_THREADS")) h->render_threads = atoi(e);
     if (const char *e = getenv("DNE_TAIL_FUSED_MAX")) h->tail_fused_max = atoi(e);
+    if (const char *e = getenv("DNE_RENDER_BANDS")) h->render_bands = std::max(1, std::min(12, atoi(e)));
+    if (const char *e = getenv("DNE_BAND_THREADS")) h->band_threads = atoi(e);
     if (const char *e = getenv("DNE_FC_CHAIN_MIN")) h->fc_chain_min = atoi(e);
     if (const char *e = getenv("DNE_FC_RB")) h->fc_rb = atoi(e);
     if (const char *e = getenv("DNE_FC_GRID")) h->fc_grid = std::max(1, atoi(e));
@@ -609,7 +617,7 @@ extern "C" int dne_materialize(dne_handle *h, const int64_t *idx, int n, float s
 static void launch_env_reset(dne_handle *h, int n) {
     const EnvArgs E = h->env(0);
     hipLaunchKernelGGL(k_env_reset_logic, dim3((n + 63) / 64), dim3(64), 0, h->stream, E, (const uint32_t *)h->seeds, n);
-    hipLaunchKernelGGL(k_env_render, dim3(n), dim3(256), 0, h->stream, E, (const int *)nullptr, 1, 1);   // FrameStack reset: 4 copies
+    hipLaunchKernelGGL(k_env_render, dim3(n), dim3(256), 0, h->stream, E, (const int *)nullptr, 1, 1, 1);   // FrameStack reset: 4 copies
 }
 
 static void launch_env_step(dne_handle *h, const EnvArgs &E, const int *list, int count, int gsize, int tslimit,
@@ -618,7 +626,7 @@ static void launch_env_step(dne_handle *h, const EnvArgs &E, const int *list, in
     const int items = count * gsize;
     hipLaunchKernelGGL(k_env_logic, dim3((items + 63) / 64), dim3(64), 0, st, E, list, gsize, items, tslimit);
     if (h->dbg_skip & 4) return;
-    hipLaunchKernelGGL(k_env_render, dim3(items), dim3(items <= 192 ? 1024 : h->render_threads), 0, st, E, list, gsize, 0);
+    hipLaunchKernelGGL(k_env_render, dim3(items), dim3(items <= 192 ? 1024 : h->render_threads), 0, st, E, list, gsize, 0, 1);
 }
 
 // ------------------------------------------------------------------------------- env ABI
@@ -891,8 +899,14 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 E.step_counter = pe ? h->launch_units + evs.size() : nullptr;
                 if (tail) {
                     const FwdArgs A = h->fwd(false);
-                    if (h->L.kind == DNE_KIND_ES) hipLaunchKernelGGL(k_tail_step<true>, dim3(cnt * gsize), dim3(1024), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
-                    else hipLaunchKernelGGL(k_tail_step<false>, dim3(cnt * gsize), dim3(1024), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
+                    const int items = cnt * gsize, nb = h->render_bands;
+#define TS(BN, R, THR) hipLaunchKernelGGL((k_tail_step<BN, R>), dim3(items), dim3(THR), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action)
+                    const bool es = h->L.kind == DNE_KIND_ES;
+                    if (nb > 1 && items * nb <= 512) {   // few members left: policy head + emulator, then each frame over nb workgroups
+                        if (es) TS(true, false, 256); else TS(false, false, 256);
+                        hipLaunchKernelGGL(k_env_render, dim3(items * nb), dim3(h->band_threads), 0, sst, E, lst, gsize, 0, nb);
+                    } else if (es) TS(true, true, 1024); else TS(false, true, 1024);
+#undef TS
                 } else launch_env_step(h, E, lst, cnt, gsize, tslimit, sst);
                 if (pe) { e[3] = ne++; HCHECK(h, hipEventRecord(h->event(e[3]), sst)); evs.push_back(e); }
                 group_steps += cnt;

@@ -329,23 +329,29 @@ __device__ inline void synth_load_tables(EnvLds &s, const ResizeLds *__restrict_
 // Render + warp max(prev, cur) and either shift it into the stack (fill == false) or fill all four
 // channels with it (fill == true, FrameStack reset).  Called by the whole workgroup (>= 256 threads) after
 // synth_load_tables and after ram_prev / ram_cur are in LDS.
-__device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bool fill) {
+__device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bool fill, int band = 0, int nbands = 1) {
+    // A workgroup produces output rows [yy0, yy1) of the 84 (all of them when nbands == 1; in the tail of a generation a
+    // member's frame is split over several workgroups = several CUs).  It needs screen rows [ylo, yhi) only.
     const int tid = threadIdx.x, nthr = blockDim.x;   // 256 threads normally, 1024 when few members remain
+    const int yy0 = band * 84 / nbands, yy1 = (band + 1) * 84 / nbands;
+    const int ylo = s.R.ymin[yy0], yhi = s.R.ymin[yy1 - 1] + 7;
+    const int out0 = yy0 * 84, nout = (yy1 - yy0) * 84;
     constexpr int VP = 7;
     uint32_t old[VP] = {};
-    const bool pre = !fill && nthr * VP >= 84 * 84;
+    const bool pre = !fill && nthr * VP >= nout;
     if (pre) {
 #pragma unroll
         for (int j = 0; j < VP; j++) {
             const int i = tid + j * nthr;
-            old[j] = i < 84 * 84 ? stack[i] : 0u;
+            old[j] = i < nout ? stack[out0 + i] : 0u;
         }
     }
     if (tid < 192) s.slot_of_key[tid] = -1;
     if (tid == 0) s.misc[2] = 0;
     __syncthreads();
     int key = 0;
-    if (tid < 210) {
+    const bool myrow = tid >= ylo && tid < yhi;
+    if (myrow) {
         key = synth_row_class(tid) * 4 + (synth_player_row(s.ram_prev, tid) ? 2 : 0) + (synth_player_row(s.ram_cur, tid) ? 1 : 0);
         if (atomicCAS(&s.slot_of_key[key], -1, -2) == -1) {     // first row of this key claims a slot
             int slot = atomicAdd(&s.misc[2], 1);
@@ -355,7 +361,7 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
         }
     }
     __syncthreads();
-    if (tid < 210) s.slot_of_y[tid] = (uint8_t)s.slot_of_key[key];
+    if (myrow) s.slot_of_y[tid] = (uint8_t)s.slot_of_key[key];
     const int nu = min(s.misc[2], ENV_MAX_ROWS);
     // one wave per unique row: the row number and the RAM-derived state are wave-uniform, so each row of each frame is
     // first reduced (on the scalar unit) to a background colour + one periodic pattern + one span + the player sprite,
@@ -387,26 +393,26 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     // vertical pass + u8 truncation + stack shift.  The old stack words are fetched VP at a time (all of them before
     // the first barrier when the workgroup covers the stack in one go) so that the global-load latency is paid once
     // per chunk, not once per pixel.
-    for (int base = 0; base < 84 * 84; base += nthr * VP) {
+    for (int base = 0; base < nout; base += nthr * VP) {
         if (!pre && !fill) {
 #pragma unroll
             for (int j = 0; j < VP; j++) {
                 const int i = base + tid + j * nthr;
-                old[j] = i < 84 * 84 ? stack[i] : 0u;
+                old[j] = i < nout ? stack[out0 + i] : 0u;
             }
         }
 #pragma unroll
         for (int j = 0; j < VP; j++) {
             const int i = base + tid + j * nthr;
-            if (i < 84 * 84) {
-                const int yy = i / 84, xx = i % 84;
+            if (i < nout) {
+                const int yy = yy0 + i / 84, xx = i % 84;
                 const uint8_t *sl = s.slot_of_y + s.R.ymin[yy];
                 const double *k = s.R.kv + yy * 7;
                 double acc = 0.0;
 #pragma unroll
                 for (int t = 0; t < 7; t++) acc = acc + (double)s.tmp[sl[t] * 84 + xx] * k[t];
                 const uint32_t pix = (uint32_t)(uint8_t)(float)acc;
-                stack[i] = fill ? pix * 0x01010101u : ((old[j] >> 8) | (pix << 24));
+                stack[out0 + i] = fill ? pix * 0x01010101u : ((old[j] >> 8) | (pix << 24));
             }
         }
     }
