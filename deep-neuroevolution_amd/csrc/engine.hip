@@ -45,63 +45,79 @@ struct EnvArgs {
     int bc_max_steps;
 };
 
-// The emulator state is 40 live bytes per member (RAM bytes 40..127 stay zero).  The per-frame logic is
-// branchy scalar code, so it runs one member per lane (64 members per workgroup, RAM rows staged in LDS at
-// an 11-dword stride = conflict-free); the pixel work runs in a separate kernel with one workgroup per member.
-constexpr int RAM_STRIDE = 44;
-
-__device__ __forceinline__ void ram_copy(uint8_t *dst, const uint8_t *src) {
-    for (int j = 0; j < RAM_LIVE / 4; j++) ((uint32_t *)dst)[j] = ((const uint32_t *)src)[j];
+// The emulator state is 40 live bytes per member (RAM bytes 40..127 stay zero).  The per-frame logic is branchy
+// scalar code: it runs one member per lane on a register-resident copy of the state (struct Emu); the pixel work
+// runs with one or more workgroups per member.
+__device__ __forceinline__ Emu ram_load(const uint8_t *row) {
+    uint32_t w[RAM_LIVE / 4];
+#pragma unroll
+    for (int j = 0; j < RAM_LIVE / 4; j++) w[j] = ((const uint32_t *)row)[j];
+    return emu_unpack(w);
+}
+__device__ __forceinline__ void ram_store(const Emu &e, uint8_t *row) {
+    uint32_t w[RAM_LIVE / 4];
+    emu_pack(e, w);
+#pragma unroll
+    for (int j = 0; j < RAM_LIVE / 4; j++) ((uint32_t *)row)[j] = w[j];
 }
 
-// atari_wrappers.py:95-107: repeat the action 4 raw frames, sum rewards, stop at game over
-__device__ inline int skip4(uint8_t *prev, uint8_t *cur, int action, int *over) {
+// MaxAndSkipEnv (atari_wrappers.py:88-107): 4 raw frames, rewards summed, early stop on game over;
+// prev / cur are the RAM before / after the last executed frame.
+__device__ inline int skip4(Emu &prev, Emu &cur, int action, int *over) {
     int tot = 0;
     *over = 0;
     for (int i = 0; i < 4; i++) {
-        ram_copy(prev, cur);
-        tot += synth_frame(cur, action);
-        if (cur[RM_OVER]) { *over = 1; break; }
+        prev = cur;
+        tot += emu_frame(cur, action);
+        if (cur.over) { *over = 1; break; }
     }
     return tot;
 }
 
 __global__ __launch_bounds__(64) void k_env_reset_logic(EnvArgs E, const uint32_t *__restrict__ seeds, int n) {
-    __shared__ __attribute__((aligned(16))) uint8_t rows[64][2][RAM_STRIDE];
     const int m = blockIdx.x * 64 + threadIdx.x;
     if (m >= n) return;
-    uint8_t *prev = rows[threadIdx.x][0], *cur = rows[threadIdx.x][1];
     const uint32_t seed = seeds[m];
-    synth_reset(cur, seed);                          // env.reset()
-    ram_copy(prev, cur);
+    Emu cur = emu_reset(seed), prev = cur;            // env.reset()
     const int noops = 1 + (int)(seed % 30u);         // atari_wrappers.py:18-31 (count fixed by the seed)
-    for (int i = 0; i < noops; i++) { ram_copy(prev, cur); synth_frame(cur, 0); }
+    for (int i = 0; i < noops; i++) { prev = cur; emu_frame(cur, 0); }
     int over;
     skip4(prev, cur, 1, &over);                      // atari_wrappers.py:40-48 FIRE then action 2
     skip4(prev, cur, 2, &over);
     uint32_t *gp = (uint32_t *)(E.ram_prev + (size_t)m * 128), *gc = (uint32_t *)(E.ram_cur + (size_t)m * 128);
-    for (int j = 0; j < 32; j++) {
-        gp[j] = j < RAM_LIVE / 4 ? ((const uint32_t *)prev)[j] : 0u;
-        gc[j] = j < RAM_LIVE / 4 ? ((const uint32_t *)cur)[j] : 0u;
-    }
+    for (int j = RAM_LIVE / 4; j < 32; j++) { gp[j] = 0u; gc[j] = 0u; }
+    ram_store(prev, (uint8_t *)gp);
+    ram_store(cur, (uint8_t *)gc);
     E.ret[m] = 0.0f; E.sign[m] = 0.0f; E.step_reward[m] = 0.0f; E.len[m] = 0; E.done[m] = 0; E.stepped[m] = 1;
 }
 
 // one wrapped step of member m (atari_wrappers.py:88-107 skip-4 + the episode bookkeeping of policies.py:399-425);
-// prev / cur are the member's RAM rows in LDS, already loaded; the caller is a single lane
-__device__ __forceinline__ void env_member_step(const EnvArgs &E, int m, uint8_t *prev, uint8_t *cur, int action, int tslimit) {
-    uint32_t *gp = (uint32_t *)(E.ram_prev + (size_t)m * 128), *gc = (uint32_t *)(E.ram_cur + (size_t)m * 128);
+// the caller is a single lane.  lds_prev / lds_cur (optional): LDS copies of the RAM rows for a renderer in the same kernel.
+__device__ __forceinline__ void env_member_step(const EnvArgs &E, int m, int action, int tslimit, uint8_t *lds_prev = nullptr,
+                                                uint8_t *lds_cur = nullptr) {
+    uint8_t *gp = E.ram_prev + (size_t)m * 128, *gc = E.ram_cur + (size_t)m * 128;
+    Emu cur = ram_load(gc), prev = cur;               // skip4 overwrites prev before its first use
     int over;
     const int r = skip4(prev, cur, action, &over);
-    for (int j = 0; j < RAM_LIVE / 4; j++) { gp[j] = ((const uint32_t *)prev)[j]; gc[j] = ((const uint32_t *)cur)[j]; }
+    uint32_t wp[RAM_LIVE / 4], wc[RAM_LIVE / 4];
+    emu_pack(prev, wp);
+    emu_pack(cur, wc);
+#pragma unroll
+    for (int j = 0; j < RAM_LIVE / 4; j++) { ((uint32_t *)gp)[j] = wp[j]; ((uint32_t *)gc)[j] = wc[j]; }
+    if (lds_prev) {
+#pragma unroll
+        for (int j = 0; j < RAM_LIVE / 4; j++) { ((uint32_t *)lds_prev)[j] = wp[j]; ((uint32_t *)lds_cur)[j] = wc[j]; }
+    }
     const int t = E.len[m];
     if (E.bc_mode == 1 && t < E.bc_max_steps) {     // policies.py:410,418 RAM after every step
         uint32_t *d = (uint32_t *)(E.bc + ((size_t)m * E.bc_max_steps + t) * 128);
-        for (int j = 0; j < RAM_LIVE / 4; j++) d[j] = ((const uint32_t *)cur)[j];
+#pragma unroll
+        for (int j = 0; j < RAM_LIVE / 4; j++) d[j] = wc[j];
     }
     if (E.bc_mode == 2) {                           // policies.py:510 final RAM
         uint32_t *d = (uint32_t *)(E.bc + (size_t)m * 128);
-        for (int j = 0; j < RAM_LIVE / 4; j++) d[j] = ((const uint32_t *)cur)[j];
+#pragma unroll
+        for (int j = 0; j < RAM_LIVE / 4; j++) d[j] = wc[j];
     }
     E.ret[m] += (float)r;                                    // es.py:425 rews.sum()
     E.sign[m] += (float)((r > 0) - (r < 0));                 // es.py:423 np.sign(rews).sum()
@@ -113,16 +129,12 @@ __device__ __forceinline__ void env_member_step(const EnvArgs &E, int m, uint8_t
 }
 
 __global__ __launch_bounds__(64) void k_env_logic(EnvArgs E, const int *__restrict__ list, int gsize, int n_items, int tslimit) {
-    __shared__ __attribute__((aligned(16))) uint8_t rows[64][2][RAM_STRIDE];
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n_items) return;
     const int g = list ? list[b / gsize] : b / gsize;
     const int m = g * gsize + b % gsize;
     if (E.done[m]) { E.stepped[m] = 0; return; }
-    uint8_t *prev = rows[threadIdx.x][0], *cur = rows[threadIdx.x][1];
-    const uint32_t *gp = (const uint32_t *)(E.ram_prev + (size_t)m * 128), *gc = (const uint32_t *)(E.ram_cur + (size_t)m * 128);
-    for (int j = 0; j < RAM_LIVE / 4; j++) { ((uint32_t *)prev)[j] = gp[j]; ((uint32_t *)cur)[j] = gc[j]; }
-    env_member_step(E, m, prev, cur, E.action[m], tslimit);
+    env_member_step(E, m, E.action[m], tslimit);
 }
 
 // max over the last two raw frames + WarpFrame + FrameStack for every member stepped by the logic kernel
@@ -152,9 +164,10 @@ __global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const 
                                                      const float *__restrict__ y3t, float *__restrict__ y3,
                                                      int32_t *__restrict__ actions) {
     __shared__ __attribute__((aligned(16))) std::conditional_t<RENDER, EnvLds, RamLds> s;
-    __shared__ float a3[256];
+    constexpr int WS = 260;                              // row stride of the transposed output weights (16-byte aligned, spreads banks)
+    __shared__ __attribute__((aligned(16))) float a3[256];
     __shared__ float lg[32];
-    __shared__ float wo[256 * 32];
+    __shared__ __attribute__((aligned(16))) float wo[32 * WS];   // [action][k]
     const int b = blockIdx.x, tid = threadIdx.x;
     const int g = list ? list[b / gsize] : b / gsize;
     const int m = g * gsize + b % gsize;
@@ -185,17 +198,24 @@ __global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const 
     }
     {
         const float *wb = base + L.ow, *we = A.noise + off + L.ow;
-        for (int i = tid; i < 256 * nact; i += blockDim.x) {
+        for (int i = tid; i < 256 * nact; i += blockDim.x) {   // the flat layout is [k][action]; every logit's column becomes an LDS row
             float pv = sc * we[i];
-            wo[i] = wb[i] + pv;
+            wo[(i % nact) * WS + i / nact] = wb[i] + pv;
         }
     }
     if constexpr (RENDER) synth_load_tables(s, E.T);
     __syncthreads();
     if (tid < nact) {
         float acc = 0.0f;
-#pragma unroll 16
-        for (int k = 0; k < 256; k++) acc = __builtin_fmaf(a3[k], wo[k * nact + tid], acc);
+        const f32x4 *wr = (const f32x4 *)&wo[tid * WS], *ar = (const f32x4 *)a3;
+#pragma unroll 8
+        for (int k4 = 0; k4 < 64; k4++) {
+            const f32x4 w = wr[k4], x = ar[k4];
+            acc = __builtin_fmaf(x[0], w[0], acc);
+            acc = __builtin_fmaf(x[1], w[1], acc);
+            acc = __builtin_fmaf(x[2], w[2], acc);
+            acc = __builtin_fmaf(x[3], w[3], acc);
+        }
         float pv = sc * A.noise[off + L.ob + tid];
         const float bias = base[L.ob + tid] + pv;
         lg[tid] = acc + bias;
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const 
         for (int a = 1; a < nact; a++)
             if (lg[a] > lg[best]) best = a;   // tf.argmax: first maximum
         actions[m] = best;
-        env_member_step(E, m, s.ram_prev, s.ram_cur, best, tslimit);
+        env_member_step(E, m, best, tslimit, RENDER ? s.ram_prev : nullptr, RENDER ? s.ram_cur : nullptr);
     }
     if constexpr (RENDER) {
         __syncthreads();

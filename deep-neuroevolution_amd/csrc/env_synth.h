@@ -7,7 +7,7 @@
 // The emulator itself is the SynthAtari fixture specified in DESIGN.md (ALE and ROMs are not available);
 // this file is an independent implementation of that written spec (the CPU oracle is another one).
 //
-// One workgroup (256 threads) per member.  Lane 0 advances the 128-byte RAM; the whole group then renders
+// One lane advances a member's emulator state in registers (struct Emu); a workgroup per member then renders
 // max(frame_prev, frame_cur) as a byte image of colour pairs in LDS, runs PIL's two separable passes
 // (double accumulation, float32 intermediate, horizontal first) band by band, and shifts the new u8
 // frame into the member's [84][84][4] stack with one dword read-modify-write per pixel.
@@ -26,46 +26,91 @@ enum : int {
 
 constexpr int RAM_LIVE = 40;   // highest used RAM byte is RM_TICK = 39
 
-__device__ __forceinline__ uint32_t ram_rand(uint8_t *ram) {
-    uint32_t s = ram[RM_RNG] | (ram[RM_RNG + 1] << 8) | (ram[RM_RNG + 2] << 16) | ((uint32_t)ram[RM_RNG + 3] << 24);
-    s = s * 1664525u + 1013904223u;
-    ram[RM_RNG] = s & 255; ram[RM_RNG + 1] = (s >> 8) & 255; ram[RM_RNG + 2] = (s >> 16) & 255; ram[RM_RNG + 3] = s >> 24;
-    return s >> 16;
+// The emulator state lives in registers while a member is stepped: the per-row fields (floe offset, visited flag,
+// hazard x / active, direction) packed four bytes to a dword and selected with a shift, everything else as scalars.
+// emu_unpack / emu_pack convert from / to the first 10 dwords of the 128-byte RAM (DESIGN.md "SynthAtari" map).
+struct Emu {
+    uint32_t rng, off4, vis4, hzx4, hza4, dir4;
+    int fc, px, prow, lives, over, temp, cool, igloo, level, score, freeze, lasta, tick;
+};
+
+__device__ __forceinline__ uint32_t emu_b4(uint32_t w, int r) { return (w >> (8 * r)) & 255u; }
+__device__ __forceinline__ uint32_t emu_set4(uint32_t w, int r, uint32_t v) {
+    const int sh = 8 * r;
+    return (w & ~(255u << sh)) | ((v & 255u) << sh);
 }
 
-__device__ inline void synth_reset(uint8_t *ram, uint32_t seed) {
-    for (int i = 0; i < RAM_LIVE; i++) ram[i] = 0;   // bytes RAM_LIVE..127 of the 128-byte RAM are always zero
-    uint32_t s = seed ^ 0x9E3779B9u;
-    ram[RM_RNG] = s & 255; ram[RM_RNG + 1] = (s >> 8) & 255; ram[RM_RNG + 2] = (s >> 16) & 255; ram[RM_RNG + 3] = s >> 24;
-    ram[RM_PX] = 76; ram[RM_LIVES] = 3; ram[RM_TEMP] = 45;
-    for (int r = 0; r < 4; r++) { ram[RM_OFF + r] = ram_rand(ram) % 160u; ram[RM_DIR + r] = r & 1; }
-    for (int r = 0; r < 4; r++) ram[RM_HZX + r] = ram_rand(ram) % 160u;
+__device__ __forceinline__ Emu emu_unpack(const uint32_t *w) {
+    Emu e;
+    e.fc = w[0] & 0xffffu;
+    e.rng = (w[0] >> 16) | (w[1] << 16);
+    e.px = (w[1] >> 16) & 255u; e.prow = w[1] >> 24;
+    e.lives = w[2] & 255u; e.over = (w[2] >> 8) & 255u; e.temp = (w[2] >> 16) & 255u; e.cool = w[2] >> 24;
+    e.off4 = w[3]; e.vis4 = w[4];
+    e.igloo = w[5] & 255u; e.level = (w[5] >> 8) & 255u;
+    e.score = (w[5] >> 16) | ((w[6] & 255u) << 16);
+    e.freeze = (w[6] >> 8) & 255u;
+    e.hzx4 = (w[6] >> 16) | (w[7] << 16);
+    e.hza4 = (w[7] >> 16) | (w[8] << 16);
+    e.dir4 = (w[8] >> 16) | (w[9] << 16);
+    e.lasta = (w[9] >> 16) & 255u; e.tick = w[9] >> 24;
+    return e;
 }
 
-__device__ __forceinline__ bool synth_on_floe(const uint8_t *ram, int px, int r) {
-    int rel = (px + 164 - ram[RM_OFF + r]) % 160;
+__device__ __forceinline__ void emu_pack(const Emu &e, uint32_t *w) {
+    w[0] = (uint32_t)e.fc | (e.rng << 16);
+    w[1] = (e.rng >> 16) | ((uint32_t)e.px << 16) | ((uint32_t)e.prow << 24);
+    w[2] = (uint32_t)e.lives | ((uint32_t)e.over << 8) | ((uint32_t)e.temp << 16) | ((uint32_t)e.cool << 24);
+    w[3] = e.off4; w[4] = e.vis4;
+    w[5] = (uint32_t)e.igloo | ((uint32_t)e.level << 8) | (((uint32_t)e.score & 0xffffu) << 16);
+    w[6] = ((uint32_t)e.score >> 16) | ((uint32_t)e.freeze << 8) | (e.hzx4 << 16);
+    w[7] = (e.hzx4 >> 16) | (e.hza4 << 16);
+    w[8] = (e.hza4 >> 16) | (e.dir4 << 16);
+    w[9] = (e.dir4 >> 16) | ((uint32_t)e.lasta << 16) | ((uint32_t)e.tick << 24);
+}
+
+__device__ __forceinline__ uint32_t emu_rand(Emu &e) {
+    e.rng = e.rng * 1664525u + 1013904223u;
+    return e.rng >> 16;
+}
+
+__device__ __forceinline__ Emu emu_reset(uint32_t seed) {
+    Emu e{};
+    e.rng = seed ^ 0x9E3779B9u;
+    e.px = 76; e.lives = 3; e.temp = 45;
+#pragma unroll
+    for (int r = 0; r < 4; r++) { e.off4 = emu_set4(e.off4, r, emu_rand(e) % 160u); e.dir4 = emu_set4(e.dir4, r, r & 1); }
+#pragma unroll
+    for (int r = 0; r < 4; r++) e.hzx4 = emu_set4(e.hzx4, r, emu_rand(e) % 160u);
+    return e;
+}
+
+__device__ __forceinline__ bool emu_on_floe(const Emu &e, int px, int r) {
+    const int rel = (px + 164 - (int)emu_b4(e.off4, r)) % 160;
     return (rel % 40) < 32;
 }
 
 // one raw emulator frame; returns the integer reward
-__device__ inline int synth_frame(uint8_t *ram, int a) {
-    if (ram[RM_OVER]) return 0;
-    int fc = ((ram[RM_FC] | (ram[RM_FC + 1] << 8)) + 1) & 0xffff;
-    ram[RM_FC] = fc & 255; ram[RM_FC + 1] = fc >> 8;
-    ram[RM_LASTA] = a;
-    int level = ram[RM_LEVEL];
+__device__ inline int emu_frame(Emu &e, int a) {
+    if (e.over) return 0;
+    e.fc = (e.fc + 1) & 0xffff;
+    const int fc = e.fc;
+    e.lasta = a;
+    int level = e.level;
     const int speed = level >= 3 ? 2 : 1;
     int reward = 0;
+#pragma unroll
     for (int r = 0; r < 4; r++) {
-        int o = ram[RM_OFF + r];
-        ram[RM_OFF + r] = ram[RM_DIR + r] ? (o + 160 - speed) % 160 : (o + speed) % 160;
+        const int o = emu_b4(e.off4, r);
+        e.off4 = emu_set4(e.off4, r, emu_b4(e.dir4, r) ? (o + 160 - speed) % 160 : (o + speed) % 160);
     }
+#pragma unroll
     for (int r = 0; r < 4; r++) {
-        if (ram[RM_HZA + r]) {
-            int x = ram[RM_HZX + r];
-            ram[RM_HZX + r] = ram[RM_DIR + r] ? (x + 1) % 160 : (x + 159) % 160;
+        if (emu_b4(e.hza4, r)) {
+            const int x = emu_b4(e.hzx4, r);
+            e.hzx4 = emu_set4(e.hzx4, r, emu_b4(e.dir4, r) ? (x + 1) % 160 : (x + 159) % 160);
         } else if ((fc & 63) == 16 * r) {
-            if ((ram_rand(ram) & 3u) == 0u) { ram[RM_HZA + r] = 1; ram[RM_HZX + r] = ram[RM_DIR + r] ? 0 : 159; }
+            if ((emu_rand(e) & 3u) == 0u) { e.hza4 = emu_set4(e.hza4, r, 1); e.hzx4 = emu_set4(e.hzx4, r, emu_b4(e.dir4, r) ? 0 : 159); }
         }
     }
     // ALE action set: NOOP FIRE UP RIGHT LEFT DOWN UR UL DR DL UF RF LF DF URF ULF DRF DLF
@@ -73,72 +118,67 @@ __device__ inline int synth_frame(uint8_t *ram, int a) {
     const int dy = (0x0C4C4 >> a) & 1 ? -1 : ((0x32320 >> a) & 1 ? 1 : 0);   // UP-ish / DOWN-ish
     const bool fire = a == 1 || a >= 10;
     bool died = false;
-    if (ram[RM_FREEZE] > 0) {
-        ram[RM_FREEZE]--;
+    if (e.freeze > 0) {
+        e.freeze--;
     } else {
-        int px = ram[RM_PX], prow = ram[RM_PROW];
-        if (prow > 0) px = (px + (ram[RM_DIR + prow - 1] ? -speed : speed) + 2 * dx + 160) % 160;   // ice rows wrap
+        int px = e.px, prow = e.prow;
+        if (prow > 0) px = (px + (emu_b4(e.dir4, prow - 1) ? -speed : speed) + 2 * dx + 160) % 160;   // ice rows wrap
         else { px += 2 * dx; px = px < 8 ? 8 : (px > 144 ? 144 : px); }
-        if (ram[RM_COOL] > 0) {
-            ram[RM_COOL]--;
+        if (e.cool > 0) {
+            e.cool--;
         } else if (dy != 0) {
-            int tgt = prow + dy;
+            const int tgt = prow + dy;
             if (tgt < 0) {
-                if (ram[RM_IGLOO] >= 16 && px >= 104) {   // enter the finished igloo: level complete
-                    reward += 10 * ram[RM_TEMP] + 100;
+                if (e.igloo >= 16 && px >= 104) {   // enter the finished igloo: level complete
+                    reward += 10 * e.temp + 100;
                     if (level < 255) level++;
-                    ram[RM_LEVEL] = level; ram[RM_IGLOO] = 0; ram[RM_TEMP] = 45; ram[RM_TICK] = 0;
-                    for (int r = 0; r < 4; r++) { ram[RM_VIS + r] = 0; ram[RM_HZA + r] = 0; }
-                    prow = 0; px = 76; ram[RM_FREEZE] = 64;
+                    e.level = level; e.igloo = 0; e.temp = 45; e.tick = 0;
+                    e.vis4 = 0; e.hza4 = 0;
+                    prow = 0; px = 76; e.freeze = 64;
                 }
             } else if (tgt <= 4) {
                 prow = tgt;
-                ram[RM_COOL] = 12;
+                e.cool = 12;
                 if (prow == 0) px = px < 8 ? 8 : (px > 144 ? 144 : px);
                 if (prow > 0) {
-                    int r = prow - 1;
-                    if (synth_on_floe(ram, px, r)) {
-                        if (!ram[RM_VIS + r]) {
-                            ram[RM_VIS + r] = 1;
+                    const int r = prow - 1;
+                    if (emu_on_floe(e, px, r)) {
+                        if (!emu_b4(e.vis4, r)) {
+                            e.vis4 = emu_set4(e.vis4, r, 1);
                             reward += 10;
-                            if (ram[RM_IGLOO] < 16) ram[RM_IGLOO]++;
-                            if (ram[RM_VIS] & ram[RM_VIS + 1] & ram[RM_VIS + 2] & ram[RM_VIS + 3])
-                                ram[RM_VIS] = ram[RM_VIS + 1] = ram[RM_VIS + 2] = ram[RM_VIS + 3] = 0;
+                            if (e.igloo < 16) e.igloo++;
+                            if (e.vis4 & (e.vis4 >> 8) & (e.vis4 >> 16) & (e.vis4 >> 24) & 255u) e.vis4 = 0;
                         }
                     } else {
                         died = true;
                     }
                 }
             }
-        } else if (fire && prow > 0 && ram[RM_IGLOO] > 0) {
-            ram[RM_DIR + prow - 1] ^= 1; ram[RM_IGLOO]--; ram[RM_COOL] = 12;
+        } else if (fire && prow > 0 && e.igloo > 0) {
+            e.dir4 ^= 1u << (8 * (prow - 1)); e.igloo--; e.cool = 12;
         }
         if (!died && prow > 0) {
-            int r = prow - 1;
-            if (!synth_on_floe(ram, px, r)) died = true;
-            else if (ram[RM_HZA + r]) {
-                int d = px + 4 - (int)ram[RM_HZX + r];
+            const int r = prow - 1;
+            if (!emu_on_floe(e, px, r)) died = true;
+            else if (emu_b4(e.hza4, r)) {
+                const int d = px + 4 - (int)emu_b4(e.hzx4, r);
                 if ((d < 0 ? -d : d) < 8) died = true;
             }
         }
-        ram[RM_PX] = px; ram[RM_PROW] = prow;
+        e.px = px; e.prow = prow;
     }
-    if (++ram[RM_TICK] >= 48) {
-        ram[RM_TICK] = 0;
-        if (ram[RM_TEMP] > 0) ram[RM_TEMP]--;
-        if (ram[RM_TEMP] == 0) died = true;
+    if (++e.tick >= 48) {
+        e.tick = 0;
+        if (e.temp > 0) e.temp--;
+        if (e.temp == 0) died = true;
     }
     if (died) {
-        if (ram[RM_LIVES] == 0) ram[RM_OVER] = 1; else ram[RM_LIVES]--;
-        ram[RM_PROW] = 0; ram[RM_PX] = 76; ram[RM_FREEZE] = 128; ram[RM_COOL] = 0;
-        ram[RM_HZA] = ram[RM_HZA + 1] = ram[RM_HZA + 2] = ram[RM_HZA + 3] = 0;
-        if (ram[RM_TEMP] == 0) ram[RM_TEMP] = 45;
+        if (e.lives == 0) e.over = 1; else e.lives--;
+        e.prow = 0; e.px = 76; e.freeze = 128; e.cool = 0;
+        e.hza4 = 0;
+        if (e.temp == 0) e.temp = 45;
     }
-    if (reward) {
-        uint32_t sc = ram[RM_SCORE] | (ram[RM_SCORE + 1] << 8) | (ram[RM_SCORE + 2] << 16);
-        sc = (sc + reward / 10) & 0xffffffu;
-        ram[RM_SCORE] = sc & 255; ram[RM_SCORE + 1] = (sc >> 8) & 255; ram[RM_SCORE + 2] = sc >> 16;
-    }
+    if (reward) e.score = (e.score + reward / 10) & 0xffffff;
     return reward;
 }
 
