@@ -600,6 +600,20 @@ __global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restric
     const int g0 = wv * 60 + (wv < 2 ? wv : 2), ng = wv < 2 ? 61 : 60;
     const float *eps = A.noise + off + L.fcw + (size_t)(kbeg + 4 * g0 + rg) * 256 + col;
     const float *th = base + L.fcw + (size_t)(kbeg + 4 * g0 + rg) * 256 + col;
+    // The activation loads are issued first and consumed after the weight loads are in flight: loads return in
+    // order, so the barrier below waits for (at most) the first weight rows, not for all of them.
+    float yv[NV][4], s2[NV][4], h2[NV][4];
+#pragma unroll
+    for (int v = 0; v < NV; v++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = tid + 256 * j, ch = (kbeg + i) & 31;
+            const bool in = i < 968;
+            yv[v][j] = in ? y2[(size_t)member[v] * 3872 + kbeg + i] : 0.0f;
+            s2[v][j] = HAS_BN && in ? A.bn[(size_t)member[v] * 608 + 32 + ch] : 1.0f;
+            h2[v][j] = HAS_BN && in ? A.bn[(size_t)member[v] * 608 + 64 + ch] : 0.0f;
+        }
+    __builtin_amdgcn_sched_barrier(0);
     float e[GW], t[GW];
 #pragma unroll
     for (int i = 0; i < GW; i++) {
@@ -607,31 +621,22 @@ __global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restric
         e[i] = eps[(size_t)(4 * ii) * 256];
         t[i] = th[(size_t)(4 * ii) * 256];
     }
-    {   // activations of this slice (bn2 + relu) into LDS, 256 threads
-        const int ch0 = kbeg & 31;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int v = 0; v < NV; v++) {
-            float yv[4];
+    for (int v = 0; v < NV; v++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int i = tid + 256 * j;
-                yv[j] = i < 968 ? y2[(size_t)member[v] * 3872 + kbeg + i] : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int i = tid + 256 * j;
-                if (i < 968) {
-                    float x = yv[j];
-                    if (HAS_BN) {
-                        const int ch = (ch0 + i) & 31;
-                        x = x * A.bn[(size_t)member[v] * 608 + 32 + ch];
-                        x = x + A.bn[(size_t)member[v] * 608 + 64 + ch];
-                    }
-                    xs[v][i] = x > 0.0f ? x : 0.0f;
+        for (int j = 0; j < 4; j++) {
+            const int i = tid + 256 * j;
+            if (i < 968) {
+                float x = yv[v][j];
+                if (HAS_BN) {
+                    x = x * s2[v][j];
+                    x = x + h2[v][j];
                 }
+                xs[v][i] = x > 0.0f ? x : 0.0f;
             }
         }
-    }
+    __syncthreads();
     // perturbed weights in place: e[] <- the first member's weight, t[] <- the second's
 #pragma unroll
     for (int i = 0; i < GW; i++) {
@@ -643,7 +648,6 @@ __global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restric
             t[i] = tt + pw;
         }
     }
-    __syncthreads();
     float acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) acc[v] = 0.0f;
@@ -668,16 +672,27 @@ __global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restric
                     // row 4g + j's weight sits in lane j of the quad and enters the fused multiply-add as a DPP operand
                     // (v_fmac_f32 = the same single-rounding fma); all four lanes carry the same chain value.  s_nop:
                     // the two wait states a DPP read needs after a VALU write of its source register.
-#pragma unroll
-                    for (int v = 0; v < NV; v++) {
-                        const float w = v == 0 ? e[i] : t[i];
+                    if constexpr (NV == 2) {   // the two members' chains interleaved: a dependent v_fmac issues every ~8 cycles
+                        asm("s_nop 1\n\t"
+                            "v_fmac_f32_dpp %0, %2, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                            "v_fmac_f32_dpp %1, %3, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                            "v_fmac_f32_dpp %0, %2, %5 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                            "v_fmac_f32_dpp %1, %3, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                            "v_fmac_f32_dpp %0, %2, %6 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                            "v_fmac_f32_dpp %1, %3, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                            "v_fmac_f32_dpp %0, %2, %7 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                            "v_fmac_f32_dpp %1, %3, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+                            : "+v"(acc[0]), "+v"(acc[NV - 1])
+                            : "v"(e[i]), "v"(t[i]), "v"(x4[0][0]), "v"(x4[0][1]), "v"(x4[0][2]), "v"(x4[0][3]),
+                              "v"(x4[NV - 1][0]), "v"(x4[NV - 1][1]), "v"(x4[NV - 1][2]), "v"(x4[NV - 1][3]));
+                    } else {
                         asm("s_nop 1\n\t"
                             "v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
                             "v_fmac_f32_dpp %0, %1, %3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
                             "v_fmac_f32_dpp %0, %1, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
                             "v_fmac_f32_dpp %0, %1, %5 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
-                            : "+v"(acc[v])
-                            : "v"(w), "v"(x4[v][0]), "v"(x4[v][1]), "v"(x4[v][2]), "v"(x4[v][3]));
+                            : "+v"(acc[0])
+                            : "v"(e[i]), "v"(x4[0][0]), "v"(x4[0][1]), "v"(x4[0][2]), "v"(x4[0][3]));
                     }
                 }
             }
