@@ -274,6 +274,10 @@ struct dne_handle {
     std::vector<hipStream_t> sub_streams;   // sub-batch streams (sub_streams[0] == stream)
     int dbg_skip = 0;   // DNE_DEBUG_SKIP bitmask (timing experiments only): 1 conv1, 2 conv2, 4 render
     int render_threads = 256;
+    int fc_pairs = 2;                // ES full-width fc: antithetic pairs per work item (DNE_FC_PAIRS, 1 = k_fc<2>)
+    int fc2_min_total = 800;         // k_fc2 from this many active groups upwards (DNE_FC2_MIN)
+    bool fc2_now = false;            // decided per burst by eval_core
+    bool uniform_base = false;       // every member perturbs base slot 0 (set by dne_es_eval, cleared by dne_set_members)
     int render_bands = 4, band_threads = 512;   // tail: workgroups per frame (DNE_RENDER_BANDS, 1 = render inside k_tail_step) and their size
     int tail_fused_max = 32;         // up to this many active groups k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
     int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_quad_max = 24, fc_rb = 4, fc_chain_min = 1 << 30;
@@ -478,6 +482,8 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     if (const char *e = getenv("DNE_DEBUG_SKIP")) h->dbg_skip = atoi(e);
     if (const char *e = getenv("DNE_RENDER_THREADS")) h->render_threads = atoi(e);
     if (const char *e = getenv("DNE_TAIL_FUSED_MAX")) h->tail_fused_max = atoi(e);
+    if (const char *e = getenv("DNE_FC_PAIRS")) h->fc_pairs = atoi(e);
+    if (const char *e = getenv("DNE_FC2_MIN")) h->fc2_min_total = atoi(e);
     if (const char *e = getenv("DNE_RENDER_BANDS")) h->render_bands = std::max(1, std::min(12, atoi(e)));
     if (const char *e = getenv("DNE_BAND_THREADS")) h->band_threads = atoi(e);
     if (const char *e = getenv("DNE_FC_CHAIN_MIN")) h->fc_chain_min = atoi(e);
@@ -709,6 +715,8 @@ extern "C" int dne_set_members(dne_handle *h, int n, const int32_t *slot, const 
     HCHECK(h, hipMemcpyAsync(h->m_off, off, n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
     HCHECK(h, hipMemcpyAsync(h->m_scale, scale, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HCHECK(h, hipStreamSynchronize(h->stream));
+    h->uniform_base = true;
+    for (int i = 0; i < n; i++) h->uniform_base = h->uniform_base && slot[i] == slot[0];
     return 0;
 }
 
@@ -808,6 +816,12 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
 #undef FCT
         return;
     }
+    if (gsize == 2 && es && h->uniform_base && h->fc2_now && !logits) {   // two pairs per work item share the base rows
+        const int items = (count + 1) / 2, blocks = std::min(items, h->fc_grid);
+        if (h->fc_rb == 2) hipLaunchKernelGGL((k_fc2<true, 2>), dim3(blocks), dim3(256), 0, st, A, list, count, (const float *)h->y2, h->y3, h->action);
+        else hipLaunchKernelGGL((k_fc2<true, 4>), dim3(blocks), dim3(256), 0, st, A, list, count, (const float *)h->y2, h->y3, h->action);
+        return;
+    }
     const int fc_blocks = std::min(count, h->fc_grid);   // persistent grid (an even groups-per-block split measured slower)
 #define FC(NV, BN, RB) hipLaunchKernelGGL((k_fc<NV, false, BN, RB>), dim3(fc_blocks), dim3(256), 0, st, A, list, count, 1, 0, (const float *)h->y2, h->y3, h->action, logits)
 #define FCR(NV, BN) do { if (h->fc_rb == 2) FC(NV, BN, 2); else if (h->fc_rb == 8) FC(NV, BN, 8); else FC(NV, BN, 4); } while (0)
@@ -871,7 +885,11 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     // two free-running streams at full width, three in the mid range (where no single kernel fills the chip),
     // one when only a handful of episodes are left (measured: tools/kbench.py sweeps).
     auto pick_nsub = [&](int total) {
-        int k = h->nsub_fixed > 0 ? h->nsub_fixed : (total >= 1900 ? 2 : total >= 200 ? 3 : total >= 48 ? 2 : 1);
+        // measured (tools/kbench.py sweeps): k_fc2 wants 3 windows at full width and 4 in the upper mid range; below
+        // ~400 groups the windows are sized to fit the column-split tail kernels (<= fc_tail_max groups each)
+        int k = total >= 1900 ? 3 : total >= h->fc2_min_total ? 4 : total > 4 * h->fc_tail_max ? 3
+              : total >= 48 ? std::max(2, (total + h->fc_tail_max - 1) / h->fc_tail_max) : 1;
+        if (h->nsub_fixed > 0) k = h->nsub_fixed;
         k = std::min(k, (int)h->sub_streams.size());
         return std::max(1, std::min(k, total));
     };
@@ -897,6 +915,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     while (total > 0 && t < tslimit) {
         const int burst = std::min(16, tslimit - t);
         const int nsub = pick_nsub(total);
+        h->fc2_now = h->fc_pairs == 2 && total >= h->fc2_min_total;
         for (int st = 0; st < burst; st++) {
             for (int s = 0; s < nsub; s++) {
                 const int lo = (int)((long long)total * s / nsub), cnt = (int)((long long)total * (s + 1) / nsub) - lo;

@@ -430,6 +430,164 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
     }
 }
 
+// Two antithetic pairs per work item (ES only: every member perturbs the same base vector).  The base rows of the
+// fc matrix are loaded once and combined with both pairs' noise rows, so a quarter of the bytes that k_fc<2> pulls
+// through L1 / L2 per pair disappears (3 row loads per 2 pairs instead of 4) -- at full width that traffic, not HBM,
+// is what keeps k_fc<2> below the read-stream ceiling.  Per member the arithmetic (k-ordered fmaf chain per slice,
+// ((s0+s1)+(s2+s3)) + bias, bn3, output layer, first-max argmax) is exactly k_fc's.
+template <bool HAS_BN, int RB>
+__global__ __launch_bounds__(256) void k_fc2(FwdArgs A, const int *__restrict__ list, int n_groups,
+                                             const float *__restrict__ y2, float *__restrict__ y3,
+                                             int32_t *__restrict__ actions) {
+    constexpr int NM = 4;   // members per item: pair p = members 2p, 2p+1
+    __shared__ float part[4][NM][256];
+    __shared__ float a3[NM][256];
+    __shared__ float lg[NM][32];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const Layout &L = A.L;
+    __builtin_amdgcn_s_setprio(3);
+    const int n_items = (n_groups + 1) >> 1;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int i0 = 2 * item, i1 = min(2 * item + 1, n_groups - 1);
+    const int nm = 2 * item + 1 < n_groups ? NM : 2;   // odd count: the last item repeats its pair and writes it once
+    int member[NM];
+    float scale[NM];
+    {
+        const int g0 = list ? list[i0] : i0, g1 = list ? list[i1] : i1;
+        member[0] = 2 * g0; member[1] = 2 * g0 + 1; member[2] = 2 * g1; member[3] = 2 * g1 + 1;
+    }
+#pragma unroll
+    for (int v = 0; v < NM; v++) scale[v] = A.m_scale[member[v]];
+    const int64_t off[2] = {A.m_off[member[0]], A.m_off[member[2]]};
+    const float *base = A.bases + (size_t)A.m_slot[member[0]] * A.base_stride;
+    const float *eps0 = A.noise + off[0] + L.fcw + lane * 4, *eps1 = A.noise + off[1] + L.fcw + lane * 4;
+    const float *th = base + L.fcw + lane * 4;
+
+    const int ch = (8 * wv + lane) & 31;   // bn2 channel of this lane's activation rows (968 = 8 mod 32)
+    float s2[NM], h2[NM];
+#pragma unroll
+    for (int v = 0; v < NM; v++) {
+        s2[v] = HAS_BN ? A.bn[(size_t)member[v] * 608 + 32 + ch] : 1.0f;
+        h2[v] = HAS_BN ? A.bn[(size_t)member[v] * 608 + 64 + ch] : 0.0f;
+    }
+    float acc[NM][4];
+#pragma unroll
+    for (int v = 0; v < NM; v++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[v][e] = 0.0f;
+
+    const int kbeg = 968 * wv;
+    auto load_x = [&](int c, float (&dst)[NM]) {
+        const int nr = c < 15 ? 64 : 8;
+#pragma unroll
+        for (int v = 0; v < NM; v++) {
+            float t = 0.0f;
+            if (c < 16 && lane < nr) {
+                t = y2[(size_t)member[v] * 3872 + kbeg + 64 * c + lane];
+                if (HAS_BN) {
+                    t = t * s2[v];
+                    t = t + h2[v];
+                }
+                t = t > 0.0f ? t : 0.0f;
+            }
+            dst[v] = t;
+        }
+    };
+    f4u e0_cur[RB], e0_nxt[RB], e1_cur[RB], e1_nxt[RB];
+    f4a t_cur[RB], t_nxt[RB];
+    float xv[NM], xn[NM];
+    load_x(0, xv);
+    load_x(1, xn);
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+        const size_t ro = (size_t)(kbeg + i) * 256;
+        e0_cur[i] = *(const f4u *)(eps0 + ro);
+        e1_cur[i] = *(const f4u *)(eps1 + ro);
+        t_cur[i] = *(const f4a *)(th + ro);
+    }
+    constexpr int NB = 968 / RB, BPC = 64 / RB;
+    for (int bt = 0; bt < NB; bt++) {
+        if (bt + 1 < NB) {
+#pragma unroll
+            for (int i = 0; i < RB; i++) {
+                const size_t ro = (size_t)(kbeg + (bt + 1) * RB + i) * 256;
+                e0_nxt[i] = *(const f4u *)(eps0 + ro);
+                e1_nxt[i] = *(const f4u *)(eps1 + ro);
+                t_nxt[i] = *(const f4a *)(th + ro);
+            }
+        }
+        const int li = (bt % BPC) * RB;
+#pragma unroll
+        for (int i = 0; i < RB; i++) {
+#pragma unroll
+            for (int v = 0; v < NM; v++) {
+                const float x = lane_bcast(xv[v], li + i);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float pv = scale[v] * (v < 2 ? e0_cur[i][q] : e1_cur[i][q]);
+                    float w = t_cur[i][q] + pv;
+                    acc[v][q] = __builtin_fmaf(x, w, acc[v][q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; i++) { e0_cur[i] = e0_nxt[i]; e1_cur[i] = e1_nxt[i]; t_cur[i] = t_nxt[i]; }
+        if (bt % BPC == BPC - 1) {
+#pragma unroll
+            for (int v = 0; v < NM; v++) xv[v] = xn[v];
+            load_x(bt / BPC + 2, xn);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NM; v++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) part[wv][v][lane * 4 + q] = acc[v][q];
+    __syncthreads();
+    for (int i = tid; i < nm * 256; i += 256) {
+        const int v = i >> 8, j = i & 255;
+        const float s01 = part[0][v][j] + part[1][v][j];
+        const float s23 = part[2][v][j] + part[3][v][j];
+        float s = s01 + s23;
+        float pv = scale[v] * A.noise[off[v >> 1] + L.fcb + j];
+        const float bias = base[L.fcb + j] + pv;
+        s = s + bias;
+        y3[(size_t)member[v] * 256 + j] = s;
+        float t = s;
+        if (HAS_BN) {
+            t = t * A.bn[(size_t)member[v] * 608 + 96 + j];
+            t = t + A.bn[(size_t)member[v] * 608 + 352 + j];
+        }
+        a3[v][j] = t > 0.0f ? t : 0.0f;
+    }
+    __syncthreads();
+    const int nact = L.nact;
+    if (tid < nm * nact) {
+        const int v = tid / nact, a = tid % nact;
+        const float *wb = base + L.ow + a;
+        const float *we = A.noise + off[v >> 1] + L.ow + a;
+        float s = 0.0f;
+#pragma unroll 8
+        for (int k = 0; k < 256; k++) {
+            float pv = scale[v] * we[k * nact];
+            float w = wb[k * nact] + pv;
+            s = __builtin_fmaf(a3[v][k], w, s);
+        }
+        float pv = scale[v] * A.noise[off[v >> 1] + L.ob + a];
+        const float bias = base[L.ob + a] + pv;
+        lg[v][a] = s + bias;
+    }
+    __syncthreads();
+    if (tid < nm) {
+        const int v = tid;
+        int best = 0;
+        for (int a = 1; a < nact; a++)
+            if (lg[v][a] > lg[v][best]) best = a;   // tf.argmax: first maximum
+        actions[member[v]] = best;
+    }
+    __syncthreads();   // LDS is reused by the next item
+    }
+}
+
 // ------------------------------------------------------- fc of the reference pass on the matrix cores
 // Virtual batch norm pushes F reference frames through every member's perturbed network (policies.py:399):
 // per member a [F x 3872] x [3872 x 256] GEMM with member-unique weights.  16 workgroups per member = 4 k-slices
