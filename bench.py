@@ -28,6 +28,12 @@ sys.path.insert(0, os.path.join(ROOT, "deep-neuroevolution_amd"))
 
 ALG_BYTES_PER_ENV_STEP = 4 * 1009058 + 28224   # all member weights once + the u8 observation stack
 HBM_PEAK = 8.0e12                              # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FC_KERNELS = {   # the kernel behind the profiled ("full") fc launches of one evaluation (dne_profile.fc_full_kind)
+    2: "dne::k_fc2<true, 4> (streaming fc + bn + out + argmax, two antithetic pairs per work item: every lock-step with "
+       ">= 800 active pairs on the rank)",
+    1: "dne::k_fc<2, false, true, 4> (streaming fc + bn + out + argmax, one pair per work item: every window with > 96 active "
+       "pairs; the rank's share is too small for k_fc2)",
+}
 
 EXP = {
     "config": {"calc_obstat_prob": 0.0, "episodes_per_batch": 5000, "eval_prob": 0.0, "l2coeff": 0.005,
@@ -160,15 +166,16 @@ def main():
     steps_local = 0
     fc_ms = fc_launches = fc_units = 0
     fc_all_ms = 0.0
+    fc_kind = 2
     stage = {"conv_ms": 0.0, "env_ms": 0.0, "ref_ms": 0.0, "reduce_ms": 0.0, "eval_ms": 0.0}
     for _ in range(args.steps):
         rec, ratio = es.es_generation(engine, noise.noise.size, config, n_pairs, gen, args.tslimit, EXP["optimizer"], rank, world, gather_device)
         gen += 1
         p = engine.profile()
         steps_local += p["env_steps"]
-        # roofline kernel = the streaming k_fc launches only (the small-count tail path is a different kernel)
+        # roofline kernel = the k_fc2 launches only (mid-range and tail lock-steps run other fc kernels)
         fc_ms += p["fc_full_ms"]; fc_launches += p["fc_full_launches"]; fc_units += p["fc_full_units"]
-        fc_all_ms += p["fc_ms"]
+        fc_all_ms += p["fc_ms"]; fc_kind = int(p["fc_full_kind"])
         for k in stage:
             stage[k] += p[k]
     barrier()
@@ -202,7 +209,7 @@ def main():
             units_per_launch = fc_units / fc_launches
             achieved = units_per_launch * ALG_BYTES_PER_ENV_STEP / (avg_ms * 1e-3)
             out["roofline"] = {
-                "bound": "hbm", "kernel": "dne::k_fc<2, false, true, 4> (streaming fc + bn + out + argmax; launches with > 96 active pairs)",
+                "bound": "hbm", "kernel": FC_KERNELS[fc_kind],
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                 "traffic": _pmc_traffic(units_per_launch),
                 "algorithmic_bytes_per_unit": ALG_BYTES_PER_ENV_STEP, "unit_def": "one env-step of one member",

@@ -912,6 +912,8 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     }
     hipEvent_t last_fc = nullptr;
     size_t fc_ring_pos = 0;
+    // the profiled ("full") launches are one kernel: k_fc2 when this evaluation starts wide enough to use it, else k_fc
+    const bool fc2_eval = h->fc_pairs == 2 && gsize == 2 && h->L.kind == DNE_KIND_ES && h->uniform_base && groups >= h->fc2_min_total;
     while (total > 0 && t < tslimit) {
         const int burst = std::min(16, tslimit - t);
         const int nsub = pick_nsub(total);
@@ -924,7 +926,8 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 const int *lst = cur + lo;
                 std::array<size_t, 4> e{};
                 // events only around full-width launches: in the latency-bound tail every event packet is a bubble
-                const bool pe = prof && cnt > h->fc_tail_max;
+                // (with k_fc2 enabled the profiled launches are exactly the k_fc2 ones: the roofline kernel of bench.py)
+                const bool pe = prof && (fc2_eval ? h->fc2_now : cnt > h->fc_tail_max);
                 if (pe) { e[0] = ne++; HCHECK(h, hipEventRecord(h->event(e[0]), sst)); }
                 launch_forward(h, lst, cnt, gsize, true, sst);
                 // optional: serialise the fc kernels of the windows (anti-phase); off by default, free-running measured faster
@@ -977,6 +980,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     P.env_steps = 0;
     for (int i = 0; i < n; i++) P.env_steps += lengths[i];
     P.fc_full_ms = P.fc_full_launches = P.fc_full_units = 0;
+    P.fc_full_kind = fc2_eval ? 2 : 1;
     if (prof) {
         HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[0], h->ev_pool[1]));
         P.ref_ms = ms;

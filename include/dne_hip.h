@@ -62,7 +62,8 @@ typedef struct { /* filled by dne_get_profile; times from HIP events on the engi
     double fc_full_ms;
     double fc_full_launches;
     double fc_full_units; /* env-steps (member-steps actually taken) processed by those launches */
-    double reserved[3];
+    double fc_full_kind;  /* which kernel those launches were: 2 = k_fc2 (two pairs per work item), 1 = k_fc */
+    double reserved[2];
 } dne_profile;
 
 /* ---- lifecycle ------------------------------------------------------------------------------------ */

@@ -14,15 +14,15 @@ def agg(kind, cname):
     by = collections.defaultdict(list)
     for r in csv.DictReader(open(R + '/pmc_%s/kb_counter_collection.csv' % kind)):
         if r['Counter_Name'] == cname:
-            by[(r['Kernel_Name'].split('(')[0].replace('void ', ''), int(r['Grid_Size']))].append(float(r['Counter_Value']))
+            by[(r['Kernel_Name'].split('(')[0].replace('void ', ''), int(r.get('Grid_Size', r.get('Grid_Size_X', 0))))].append(float(r['Counter_Value']))
     return {k: (len(v), sum(v) / len(v)) for k, v in by.items()}
 f = agg('fetch', 'FETCH_SIZE'); w = agg('write', 'WRITE_SIZE')
 lines = ["kernel,grid_size,dispatches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg"]
 for k in sorted(set(f) | set(w)):
     lines.append("%s,%d,%d,%.1f,%.1f" % (k[0], k[1], f.get(k, (0, 0))[0], f.get(k, (0, 0))[1], w.get(k, (0, 0))[1]))
 open(P + '/r01_pmc_fetch_write_by_kernel.csv', 'w').write("\n".join(lines) + "\n")
-kf = [k for k in f if k[0].startswith('dne::k_fc<2')][0]
-units = 2500
+kf = max((k for k in f if k[0].startswith('dne::k_fc2<')), key=lambda k: f[k][1])   # the full-width launches (one window: DNE_NSUB=1)
+units = 5000   # 2500 pairs = 5000 member-steps per launch
 fetch = f[kf][1] * 1024 * 2; write = w[kf][1] * 1024
 out = json.load(open(P + '/r01_pmc.json'))
 out['k_fc_step'].update({'kernel': kf[0], 'grid_size': kf[1], 'FETCH_SIZE_KB_avg': f[kf][1], 'WRITE_SIZE_KB_avg': w[kf][1],
