@@ -279,7 +279,7 @@ struct dne_handle {
     bool fc2_now = false;            // decided per burst by eval_core
     bool uniform_base = false;       // every member perturbs base slot 0 (set by dne_es_eval, cleared by dne_set_members)
     int render_bands = 4, band_threads = 512;   // tail: workgroups per frame (DNE_RENDER_BANDS, 1 = render inside k_tail_step) and their size
-    int tail_fused_max = 32;         // up to this many active groups k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
+    int tail_fused_max = 200;        // up to this many active groups (all windows) k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
     int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_quad_max = 24, fc_rb = 4, fc_chain_min = 1 << 30;
     int M = 0, F = 0, ref_chunk = 0;
     size_t base_stride = 0;
@@ -934,7 +934,8 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 const bool chain = nsub > 1 && cnt >= h->fc_chain_min;
                 if (chain && last_fc) HCHECK(h, hipStreamWaitEvent(sst, last_fc, 0));
                 if (pe) { e[1] = ne++; HCHECK(h, hipEventRecord(h->event(e[1]), sst)); }   // after the wait: brackets fc only
-                const bool tail = cnt <= std::min(h->tail_fused_max, h->fc_tail_max);
+                // fused policy head + emulator (+ render): while all windows together still fit the chip one workgroup per member
+                const bool tail = cnt <= h->fc_tail_max && total <= h->tail_fused_max;
                 launch_fc(h, lst, cnt, gsize, nullptr, sst, tail);
                 if (chain) { last_fc = h->fc_ring[fc_ring_pos++ % h->fc_ring.size()]; HCHECK(h, hipEventRecord(last_fc, sst)); }
                 if (pe) { e[2] = ne++; HCHECK(h, hipEventRecord(h->event(e[2]), sst)); }
