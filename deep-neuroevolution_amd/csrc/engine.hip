@@ -433,6 +433,15 @@ static hipError_t dalloc(T **p, size_t n) {
     return hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T));
 }
 
+// scratch device buffer of one call: freed on every exit path
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t n) { return dalloc(&p, n); }
+    operator T *() const { return p; }
+};
+
 extern "C" int dne_num_params(int kind, int nact) {
     Layout L;
     make_layout(kind, nact, &L);
@@ -476,19 +485,24 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipSetDevice(cfg->device_id));
     CH(hipStreamCreate(&h->stream));
     h->sub_streams.push_back(h->stream);
-    if (const char *e = getenv("DNE_NSUB")) h->nsub_fixed = std::max(1, std::min(4, atoi(e)));
-    if (const char *e = getenv("DNE_FC_QUAD_MAX")) h->fc_quad_max = atoi(e);
-    if (const char *e = getenv("DNE_FC_TAIL_MAX")) h->fc_tail_max = std::max(0, atoi(e));
-    if (const char *e = getenv("DNE_DEBUG_SKIP")) h->dbg_skip = atoi(e);
-    if (const char *e = getenv("DNE_RENDER_THREADS")) h->render_threads = atoi(e);
-    if (const char *e = getenv("DNE_TAIL_FUSED_MAX")) h->tail_fused_max = atoi(e);
-    if (const char *e = getenv("DNE_FC_PAIRS")) h->fc_pairs = atoi(e);
-    if (const char *e = getenv("DNE_FC2_MIN")) h->fc2_min_total = atoi(e);
-    if (const char *e = getenv("DNE_RENDER_BANDS")) h->render_bands = std::max(1, std::min(12, atoi(e)));
-    if (const char *e = getenv("DNE_BAND_THREADS")) h->band_threads = atoi(e);
-    if (const char *e = getenv("DNE_FC_CHAIN_MIN")) h->fc_chain_min = atoi(e);
-    if (const char *e = getenv("DNE_FC_RB")) h->fc_rb = atoi(e);
-    if (const char *e = getenv("DNE_FC_GRID")) h->fc_grid = std::max(1, atoi(e));
+    // tuning knobs (measurement only; every value is clamped to what the kernels support)
+    auto env_int = [](const char *name, int lo, int hi, int *dst) {
+        if (const char *e = getenv(name)) *dst = std::max(lo, std::min(hi, atoi(e)));
+    };
+    auto wg_size = [](int v) { return v >= 1024 ? 1024 : v >= 512 ? 512 : 256; };   // the renderer needs >= 210 threads, whole waves
+    env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
+    env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
+    env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
+    env_int("DNE_DEBUG_SKIP", 0, 7, &h->dbg_skip);
+    env_int("DNE_RENDER_THREADS", 256, 1024, &h->render_threads); h->render_threads = wg_size(h->render_threads);
+    env_int("DNE_BAND_THREADS", 256, 1024, &h->band_threads); h->band_threads = wg_size(h->band_threads);
+    env_int("DNE_TAIL_FUSED_MAX", 0, 1 << 20, &h->tail_fused_max);
+    env_int("DNE_FC_PAIRS", 1, 2, &h->fc_pairs);
+    env_int("DNE_FC2_MIN", 2, 1 << 30, &h->fc2_min_total);
+    env_int("DNE_RENDER_BANDS", 1, 12, &h->render_bands);
+    env_int("DNE_FC_CHAIN_MIN", 1, 1 << 30, &h->fc_chain_min);
+    env_int("DNE_FC_RB", 2, 8, &h->fc_rb);
+    env_int("DNE_FC_GRID", 1, 1 << 16, &h->fc_grid);
     for (int s = 1; s < 4; s++) { hipStream_t st; CH(hipStreamCreate(&st)); h->sub_streams.push_back(st); }
     make_layout(cfg->policy_kind, cfg->n_actions, &h->L);
     h->M = cfg->max_members;
@@ -1279,19 +1293,19 @@ extern "C" int dne_novelty(dne_handle *h, const uint8_t *archive, const int32_t 
     std::vector<int64_t> row0(narch);
     int64_t rows = 0;
     for (int a = 0; a < narch; a++) { if (alen[a] < 1) return h->fail("empty archive entry"); row0[a] = rows; rows += alen[a]; }
-    uint8_t *d_arch = nullptr, *d_bc = nullptr; int64_t *d_row0 = nullptr; int32_t *d_len = nullptr; long long *d_out = nullptr;
-    HCHECK(h, dalloc(&d_arch, (size_t)rows * dim)); HCHECK(h, dalloc(&d_bc, (size_t)bc_len * dim));
-    HCHECK(h, dalloc(&d_row0, narch)); HCHECK(h, dalloc(&d_len, narch)); HCHECK(h, dalloc(&d_out, 2 * (size_t)narch));
+    DevBuf<uint8_t> d_arch, d_bc; DevBuf<int64_t> d_row0; DevBuf<int32_t> d_len; DevBuf<long long> d_out;
+    HCHECK(h, d_arch.alloc((size_t)rows * dim)); HCHECK(h, d_bc.alloc((size_t)bc_len * dim));
+    HCHECK(h, d_row0.alloc(narch)); HCHECK(h, d_len.alloc(narch)); HCHECK(h, d_out.alloc(2 * (size_t)narch));
     HCHECK(h, hipMemcpyAsync(d_arch, archive, (size_t)rows * dim, hipMemcpyHostToDevice, h->stream));
     HCHECK(h, hipMemcpyAsync(d_bc, bc, (size_t)bc_len * dim, hipMemcpyHostToDevice, h->stream));
     HCHECK(h, hipMemcpyAsync(d_row0, row0.data(), narch * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
     HCHECK(h, hipMemcpyAsync(d_len, alen, narch * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_bc_sqdist, dim3(narch), dim3(256), 0, h->stream, (const uint8_t *)d_arch, (const int64_t *)d_row0,
-                       (const int32_t *)d_len, (const uint8_t *)d_bc, bc_len, dim, d_out);
+    hipLaunchKernelGGL(k_bc_sqdist, dim3(narch), dim3(256), 0, h->stream, (const uint8_t *)d_arch.p, (const int64_t *)d_row0.p,
+                       (const int32_t *)d_len.p, (const uint8_t *)d_bc.p, bc_len, dim, d_out.p);
+    HCHECK(h, hipGetLastError());
     std::vector<long long> ab(2 * (size_t)narch);
     HCHECK(h, hipMemcpyAsync(ab.data(), d_out, ab.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
     HCHECK(h, hipStreamSynchronize(h->stream));
-    hipFree(d_arch); hipFree(d_bc); hipFree(d_row0); hipFree(d_len); hipFree(d_out);
     std::vector<double> d(narch);
     for (int a = 0; a < narch; a++) {   // nses.py:20 sqrt(a**2 + b**2) with a, b = the two Frobenius norms
         const double na = std::sqrt((double)ab[2 * a]), nb = std::sqrt((double)ab[2 * a + 1]);
@@ -1315,19 +1329,19 @@ extern "C" int dne_novelty_batch(dne_handle *h, const uint8_t *archive, const in
     for (int a = 0; a < narch; a++) { if (alen[a] < 1) return h->fail("empty archive entry"); row0[a] = rows; rows += alen[a]; }
     for (int i = 0; i < n; i++)
         if (lengths[i] < 1 || lengths[i] > h->cfg.bc_max_steps) return h->fail("member %d: trajectory length %d outside the recorded capacity %d", i, lengths[i], h->cfg.bc_max_steps);
-    uint8_t *d_arch = nullptr; int64_t *d_row0 = nullptr; int32_t *d_alen = nullptr, *d_len = nullptr; long long *d_out = nullptr;
-    HCHECK(h, dalloc(&d_arch, (size_t)rows * 128)); HCHECK(h, dalloc(&d_row0, narch)); HCHECK(h, dalloc(&d_alen, narch));
-    HCHECK(h, dalloc(&d_len, n)); HCHECK(h, dalloc(&d_out, (size_t)n * narch * 2));
+    DevBuf<uint8_t> d_arch; DevBuf<int64_t> d_row0; DevBuf<int32_t> d_alen, d_len; DevBuf<long long> d_out;
+    HCHECK(h, d_arch.alloc((size_t)rows * 128)); HCHECK(h, d_row0.alloc(narch)); HCHECK(h, d_alen.alloc(narch));
+    HCHECK(h, d_len.alloc(n)); HCHECK(h, d_out.alloc((size_t)n * narch * 2));
     HCHECK(h, hipMemcpyAsync(d_arch, archive, (size_t)rows * 128, hipMemcpyHostToDevice, h->stream));
     HCHECK(h, hipMemcpyAsync(d_row0, row0.data(), narch * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
     HCHECK(h, hipMemcpyAsync(d_alen, alen, narch * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     HCHECK(h, hipMemcpyAsync(d_len, lengths, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_bc_sqdist_batch, dim3(narch, n), dim3(256), 0, h->stream, (const uint8_t *)d_arch, (const int64_t *)d_row0,
-                       (const int32_t *)d_alen, (const uint8_t *)h->bc, (const int32_t *)d_len, h->cfg.bc_max_steps, narch, d_out);
+    hipLaunchKernelGGL(k_bc_sqdist_batch, dim3(narch, n), dim3(256), 0, h->stream, (const uint8_t *)d_arch.p, (const int64_t *)d_row0.p,
+                       (const int32_t *)d_alen.p, (const uint8_t *)h->bc, (const int32_t *)d_len.p, h->cfg.bc_max_steps, narch, d_out.p);
+    HCHECK(h, hipGetLastError());
     std::vector<long long> ab((size_t)n * narch * 2);
     HCHECK(h, hipMemcpyAsync(ab.data(), d_out, ab.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
     HCHECK(h, hipStreamSynchronize(h->stream));
-    hipFree(d_arch); hipFree(d_row0); hipFree(d_alen); hipFree(d_len); hipFree(d_out);
     std::vector<double> d(narch);
     const int kk = std::min(k, narch);
     for (int i = 0; i < n; i++) {
