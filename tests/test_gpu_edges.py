@@ -139,3 +139,37 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
             thp = oracle.perturb(th, small_noise, idx[::-1][i], 0.02, 1 if s == 0 else -1)
             r, _, l, bc = oracle.rollout(L, thp, ref, seeds[::-1][2 * i + s], 5, want_bc=True)
             assert l == ln[i, s] and nov[2 * i + s] == oracle.novelty(arch, bc, 2)
+
+
+@pytest.mark.parametrize("knobs", [
+    {"DNE_FC2_MIN": "2", "DNE_FC_TAIL_MAX": "1"},                       # k_fc2 (two pairs per work item; odd count: repeated pair)
+    {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1"},                      # k_fc<2> streaming kernel
+    {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1", "DNE_FC_RB": "2"},    # ... with 2-row batches
+    {"DNE_FC_QUAD_MAX": "0", "DNE_TAIL_FUSED_MAX": "0"},                # k_fc_cols + k_out + separate emulator / render launches
+    {"DNE_FC_QUAD_MAX": "0"},                                           # k_fc_cols + fused tail step
+    {"DNE_RENDER_BANDS": "1"},                                          # quad fc + tail step rendering in place
+    {"DNE_RENDER_BANDS": "7", "DNE_BAND_THREADS": "1024"},              # frame split over 7 workgroups
+    {"DNE_NSUB": "3", "DNE_FC_TAIL_MAX": "2", "DNE_FC2_MIN": "4"},      # three windows, k_fc2 / k_fc / tail kernels as the list shrinks
+])
+def test_every_step_kernel_variant_is_bit_exact(knobs, oracle, small_noise, monkeypatch):
+    """the engine picks its lock-step kernels by active count; the tuning knobs force each variant onto a population small
+    enough for the oracle (5 pairs = odd count, episodes of different lengths so that the active list shrinks)"""
+    from dne_hip import _lib
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    e = _lib.Engine(_lib.KIND_ES, NACT, max_members=10, ref_count=NREF)
+    try:
+        e.noise_upload(small_noise)
+        ref = oracle.get_ref_batch(seed=0, batch_size=NREF, nact=NACT)
+        e.set_ref_batch(ref)
+        L = oracle.layout(0, NACT)
+        th = oracle.es_init_theta(L, 0)
+        e.set_theta(th)
+        idx = np.array([11, 222_222, 2_900_001, 1_234_567, 42], np.int64)
+        seeds = (np.arange(10, dtype=np.uint32) * 2654435761).astype(np.uint32)
+        ret, sg, ln = e.es_eval(idx, 0.02, 150, seeds)
+        oret, osg, oln = oracle.es_eval(L, th, small_noise, idx, 0.02, 150, ref, seeds)
+        assert np.array_equal(ln, oln) and np.array_equal(ret, oret) and np.array_equal(sg, osg), knobs
+        assert len(set(ln.reshape(-1).tolist())) > 3          # the list did shrink step by step
+    finally:
+        e.close()
