@@ -120,10 +120,12 @@ __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict_
     }
     __syncthreads();
     float *out = y1 + (size_t)it.row * 7056;
-    for (int j = nsplit == 4 ? 2 * part : 0; j < (nsplit == 4 ? 2 * part + 2 : 8); j += 2) {
+    // 28 position tiles, 7 per wave: three pairs (two independent accumulators cover the dependent-MFMA latency) and
+    // one single tile -- the single one runs on one accumulator instead of dragging an empty partner through the pipe
+    auto run = [&](int j, auto has_b) {
+        constexpr bool HASB = decltype(has_b)::value;
         const int tA = wv + 4 * j, tB = wv + 4 * (j + 1);
-        const bool hasB = j + 1 < 7;
-        const int pA = min(tA * 16 + lp, 440), pB = hasB ? min(tB * 16 + lp, 440) : 0;
+        const int pA = min(tA * 16 + lp, 440), pB = HASB ? min(tB * 16 + lp, 440) : 0;
         const int oA = (pA / 21) * 4 * 88 + (pA % 21) * 4, oB = (pB / 21) * 4 * 88 + (pB % 21) * 4;
         f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -131,17 +133,23 @@ __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict_
 #pragma unroll
             for (int kw = 0; kw < 8; kw++) {
                 const float xA = lut[(img[oA + kh * 88 + kw] >> (8 * ci)) & 255u];
-                const float xB = lut[(img[oB + kh * 88 + kw] >> (8 * ci)) & 255u];
                 accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xA, b[kh * 8 + kw], accA, 0, 0, 0);
-                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xB, b[kh * 8 + kw], accB, 0, 0, 0);
+                if (HASB) {
+                    const float xB = lut[(img[oB + kh * 88 + kw] >> (8 * ci)) & 255u];
+                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xB, b[kh * 8 + kw], accB, 0, 0, 0);
+                }
             }
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {   // D[row = 4*(l>>4) + r][col = l&15]
             const int posA = tA * 16 + ci * 4 + r, posB = tB * 16 + ci * 4 + r;
             if (posA < 441) out[posA * 16 + lp] = accA[r] + bias;
-            if (hasB && posB < 441) out[posB * 16 + lp] = accB[r] + bias;
+            if (HASB && posB < 441) out[posB * 16 + lp] = accB[r] + bias;
         }
+    };
+    for (int j = nsplit == 4 ? 2 * part : 0; j < (nsplit == 4 ? 2 * part + 2 : 8); j += 2) {
+        if (j + 1 < 7) run(j, std::true_type{});
+        else run(j, std::false_type{});
     }
 }
 
