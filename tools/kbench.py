@@ -11,8 +11,9 @@ ap.add_argument("--pairs", type=int, default=2500)
 ap.add_argument("--tslimit", type=int, default=24)
 ap.add_argument("--noise-count", type=int, default=250_000_000)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--ref-chunk", type=int, default=0)
 a = ap.parse_args()
-e = _lib.Engine(_lib.KIND_ES, 18, max_members=2 * a.pairs, ref_count=128, profile_events=True)
+e = _lib.Engine(_lib.KIND_ES, 18, max_members=2 * a.pairs, ref_count=128, profile_events=True, ref_chunk=a.ref_chunk)
 noise = es.SharedNoiseTable(count=a.noise_count); noise.attach(e)
 e.set_theta(policies.xavier_flat(18, 0))
 env = policies.HipAtariEnv(e, seed=0)
