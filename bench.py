@@ -218,6 +218,10 @@ def main():
                         "the rocprofv3 FETCH_SIZE/WRITE_SIZE passes in profiles/) is about half the algorithmic figure and "
                         "frac may exceed 1; traffic_rate is what the memory system actually delivers to this kernel",
             }
+            # SURVEY 8d also asks for the whole-job figure: every env-step of the generation (reference pass, tail and
+            # update included in the time) priced at the same algorithmic bytes
+            out["roofline"]["whole_job"] = {"achieved": value * ALG_BYTES_PER_ENV_STEP / 1e9, "unit": "GB/s",
+                                            "frac": value * ALG_BYTES_PER_ENV_STEP / (HBM_PEAK * world)}
             tr = out["roofline"]["traffic"]
             if tr:
                 out["roofline"]["traffic_rate"] = {"value": tr / (avg_ms * 1e-3) / 1e9, "unit": "GB/s",
