@@ -718,6 +718,19 @@ extern "C" int dne_env_set_observation(dne_handle *h, int n, const uint8_t *obs)
     return 0;
 }
 
+extern "C" int dne_env_set_ram(dne_handle *h, int n, const uint8_t *ram_prev, const uint8_t *ram_cur) {
+    if (check_n(h, n)) return -1;
+    HCHECK(h, hipMemcpyAsync(h->ram_prev, ram_prev, (size_t)n * 128, hipMemcpyHostToDevice, h->stream));
+    HCHECK(h, hipMemcpyAsync(h->ram_cur, ram_cur, (size_t)n * 128, hipMemcpyHostToDevice, h->stream));
+    std::vector<int32_t> ones(n, 1);
+    HCHECK(h, hipMemcpyAsync(h->stepped, ones.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    const EnvArgs E = h->env(0);
+    hipLaunchKernelGGL(k_env_render, dim3(n), dim3(256), 0, h->stream, E, (const int *)nullptr, 1, 1, 1);   // fill: 4 copies
+    HCHECK(h, hipGetLastError());
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------- forward
 extern "C" int dne_set_members(dne_handle *h, int n, const int32_t *slot, const int64_t *off, const float *scale) {
     if (check_n(h, n)) return -1;

@@ -169,6 +169,12 @@ class Engine:
         obs = _arr(obs, np.uint8)
         self._ck(self.lib.dne_env_set_observation(self.h, int(obs.shape[0]), _ptr(obs, C.c_uint8)))
 
+    def env_set_ram(self, ram_prev, ram_cur):
+        """inject emulator states (RAM before / after the last raw frame); observations are re-rendered as after a reset"""
+        ram_prev = _arr(ram_prev, np.uint8).reshape(-1, RAM_BYTES); ram_cur = _arr(ram_cur, np.uint8).reshape(-1, RAM_BYTES)
+        assert ram_prev.shape == ram_cur.shape
+        self._ck(self.lib.dne_env_set_ram(self.h, int(ram_prev.shape[0]), _ptr(ram_prev, C.c_uint8), _ptr(ram_cur, C.c_uint8)))
+
     # ---- forward
     def set_members(self, slot, off, scale):
         slot = _arr(slot, np.int32); off = _arr(off, np.int64); scale = _arr(scale, np.float32)

@@ -93,6 +93,10 @@ int dne_env_step(dne_handle *h, int n, const int32_t *actions, float *reward, in
 int dne_env_observation(dne_handle *h, int n, uint8_t *out /*[n][84][84][4]*/);
 int dne_env_ram(dne_handle *h, int n, uint8_t *out /*[n][128]*/);
 int dne_env_set_observation(dne_handle *h, int n, const uint8_t *obs /*[n][84][84][4]*/);
+/* emulator state injection (ALE's cloneState/restoreState is the nearest reference notion; used by the renderer parity
+ * tests): RAM before / after the last raw frame of n members; the observation becomes 4 copies of the warped max frame,
+ * as after a FrameStack reset (atari_wrappers.py:171-176) */
+int dne_env_set_ram(dne_handle *h, int n, const uint8_t *ram_prev /*[n][128]*/, const uint8_t *ram_cur /*[n][128]*/);
 
 /* ---- policy forward on explicit members (policies.py:319-330,374-375 / 449-459,469-470) ---------------
  * member i uses theta_i = base[base_slot[i]] + scale[i] * noise[noise_off[i]:]   (ES: scale = +-sigma) */

@@ -173,3 +173,52 @@ def test_every_step_kernel_variant_is_bit_exact(knobs, oracle, small_noise, monk
         assert len(set(ln.reshape(-1).tolist())) > 3          # the list did shrink step by step
     finally:
         e.close()
+
+
+def _crafted_rams(rs, n):
+    """valid SynthAtari RAM snapshots that visit every branch of the renderer: sprite on every row
+    band and wrapping over the screen edge, blink on/off, temperature / lives / score HUD, igloo 0..16 with and without the
+    door, both sky colours, hazards active or not at any x, floes visited or not at any offset"""
+    ram = np.zeros((n, 128), np.uint8)
+    ram[:, 0:2] = rs.randint(0, 256, (n, 2))                      # frame counter (bit 2 drives the blink)
+    ram[:, 2:6] = rs.randint(0, 256, (n, 4))                      # LCG state (not rendered)
+    prow = rs.randint(0, 5, n); ram[:, 7] = prow
+    ram[:, 6] = np.where(prow == 0, rs.randint(8, 145, n), rs.randint(0, 160, n))
+    ram[:, 8] = rs.randint(0, 4, n)                               # lives
+    ram[:, 10] = rs.randint(0, 46, n)                             # temperature
+    ram[:, 11] = rs.randint(0, 13, n)
+    ram[:, 12:16] = rs.randint(0, 160, (n, 4))                    # floe offsets
+    ram[:, 16:20] = rs.randint(0, 2, (n, 4))                      # visited
+    ram[:, 20] = rs.choice([0, 1, 3, 4, 7, 8, 11, 12, 15, 16], n) # igloo blocks
+    ram[:, 21] = rs.randint(0, 6, n)                              # level (sky colour, speed)
+    ram[:, 22:25] = rs.randint(0, 256, (n, 3))                    # score / 10
+    ram[:, 25] = rs.choice([0, 0, 1, 64, 128], n)                 # freeze counter
+    ram[:, 26:30] = rs.randint(0, 160, (n, 4))                    # hazard x
+    ram[:, 30:34] = rs.randint(0, 2, (n, 4))                      # hazard active
+    ram[:, 34:38] = rs.randint(0, 2, (n, 4))
+    ram[:, 38] = rs.randint(0, 18, n); ram[:, 39] = rs.randint(0, 48, n)
+    return ram
+
+
+def test_renderer_on_crafted_states(eng, oracle):
+    """observation = warp(max(frame(ram_prev), frame(ram_cur))) for injected RAM pairs vs the oracle's renderer + PIL restatement"""
+    es, _, _ = eng
+    rs = np.random.RandomState(7)
+    pal = oracle.palette()
+    for _ in range(12):
+        n = 9
+        prev = _crafted_rams(rs, n)
+        cur = prev.copy()
+        for i in range(n):                                        # half of them: a genuine next frame; the rest: an unrelated state
+            if i % 2 == 0:
+                oracle.raw_frame(cur[i], int(rs.randint(0, 18)))
+            else:
+                cur[i] = _crafted_rams(rs, 1)[0]
+        es.env_set_ram(prev, cur)
+        obs = es.env_observation(n)
+        assert np.array_equal(es.env_ram(n), cur)
+        for i in range(n):
+            rgb = np.maximum(pal[oracle.raw_render(prev[i])], pal[oracle.raw_render(cur[i])])
+            want = oracle.warp_rgb(rgb)
+            assert np.array_equal(obs[i, :, :, 0], want), (i, prev[i, :40].tolist(), cur[i, :40].tolist())
+            assert all(np.array_equal(obs[i, :, :, c], want) for c in (1, 2, 3))
