@@ -222,3 +222,42 @@ def test_renderer_on_crafted_states(eng, oracle):
             want = oracle.warp_rgb(rgb)
             assert np.array_equal(obs[i, :, :, 0], want), (i, prev[i, :40].tolist(), cur[i, :40].tolist())
             assert all(np.array_equal(obs[i, :, :, c], want) for c in (1, 2, 3))
+
+
+def test_emulator_step_from_crafted_states(eng, oracle):
+    """one wrapped step (4 raw frames, early stop on game over) from injected states, every action: RAM, reward and the
+    game-over flag vs the oracle's emulator -- reaches the branches random play rarely does (level completion, last life,
+    temperature death, direction reversal, hazard collisions on every row)"""
+    es, _, _ = eng
+    rs = np.random.RandomState(11)
+    n = 9
+    seen = {"level_up": 0, "game_over": 0, "direction_flip": 0, "reward": 0}
+    for rep in range(40):
+        cur = _crafted_rams(rs, n)
+        if rep % 4 == 0:                                          # stage the rare events on purpose
+            cur[:, 20] = 16; cur[:, 7] = 0; cur[:, 6] = rs.randint(104, 145, n); cur[:, 25] = 0; cur[:, 11] = 0   # finished igloo, at the door
+        if rep % 4 == 1:
+            cur[:, 8] = 0; cur[:, 10] = 1; cur[:, 39] = 47                                                       # last life, about to freeze
+        if rep % 4 == 2:
+            cur[:, 25] = 0; cur[:, 11] = 0; cur[:, 7] = rs.randint(1, 5, n); cur[:, 20] = rs.randint(1, 17, n)   # on the ice, may FIRE
+        cur[:, 9] = 0
+        actions = rs.randint(0, 18, n).astype(np.int32)
+        if rep % 4 == 0:
+            actions[:] = rs.choice([2, 6, 7, 10, 14, 15], n)      # UP-ish
+        es.env_reset(np.arange(n, dtype=np.uint32))               # clears done / length bookkeeping
+        es.env_set_ram(cur, cur)
+        rew, done = es.env_step(actions)
+        got = es.env_ram(n)
+        for i in range(n):
+            ram = cur[i].copy()
+            tot, over = 0, False
+            for _ in range(4):                                    # atari_wrappers.py:95-107
+                tot += oracle.raw_frame(ram, int(actions[i]))
+                if ram[9]:
+                    over = True
+                    break
+            assert np.array_equal(got[i], ram), (rep, i, int(actions[i]), cur[i, :40].tolist())
+            assert rew[i] == tot and bool(done[i]) == over, (rep, i, rew[i], tot, done[i], over)
+            seen["level_up"] += int(ram[21] > cur[i, 21]); seen["game_over"] += int(over); seen["reward"] += int(tot > 0)
+            seen["direction_flip"] += int(np.any(ram[34:38] != cur[i, 34:38]))
+    assert all(v > 0 for v in seen.values()), seen
