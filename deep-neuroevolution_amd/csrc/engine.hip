@@ -1,5 +1,5 @@
 // engine.hip -- host side of libdne_hip.so: the C ABI of include/dne_hip.h over the gfx950 kernels in
-// env_synth.h / forward.h / reduce.h.  One handle = one HIP device + one stream; all state (noise table,
+// env_synth.h / forward.h / reduce.h.  One handle = one HIP device (a main stream + 3 window streams); all state (noise table,
 // parent vectors, optimizer moments, frame stacks, emulator RAM, activations) lives in HBM for the
 // lifetime of the handle, and a generation only moves (noise_idx, seed) in and (return, length) out.
 #include <hip/hip_runtime.h>
