@@ -229,6 +229,17 @@ def main():
             out["stage_ms_per_generation"] = {k: v / args.steps for k, v in stage.items()}
             out["stage_ms_per_generation"]["fc_ms"] = fc_all_ms / args.steps
             out["stage_ms_per_generation"]["fc_streaming_kernel_ms"] = fc_ms / args.steps
+        else:
+            # this rank's share never reaches the streaming kernels' range (e.g. 312 pairs at N = 8 run in windows of <= 96 pairs
+            # on the column-split kernels, which are not bracketed by events): only the whole-job figure is available
+            per_gpu = value * ALG_BYTES_PER_ENV_STEP / world
+            out["roofline"] = {"bound": "hbm", "kernel": "none profiled (all lock-steps in the column-split / quad fc range)",
+                               "achieved": per_gpu / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": per_gpu / HBM_PEAK,
+                               "traffic": None, "algorithmic_bytes_per_unit": ALG_BYTES_PER_ENV_STEP,
+                               "unit_def": "one env-step of one member", "note": "whole-job algorithmic bytes per GPU / wall time",
+                               "whole_job": {"achieved": value * ALG_BYTES_PER_ENV_STEP / 1e9, "unit": "GB/s",
+                                             "frac": value * ALG_BYTES_PER_ENV_STEP / (HBM_PEAK * world)}}
+            out["stage_ms_per_generation"] = {k: v / args.steps for k, v in stage.items()}
         out["setup_s"] = {"noise_table": t_noise}
         out["theta_abs_sum_after"] = theta_sum
         if world == 1 and not args.no_cpu_baseline:
