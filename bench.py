@@ -167,6 +167,7 @@ def main():
     fc_ms = fc_launches = fc_units = 0
     fc_all_ms = 0.0
     fc_kind = 2
+    fc_union_ms = 0.0
     stage = {"conv_ms": 0.0, "env_ms": 0.0, "ref_ms": 0.0, "reduce_ms": 0.0, "eval_ms": 0.0}
     for _ in range(args.steps):
         rec, ratio = es.es_generation(engine, noise.noise.size, config, n_pairs, gen, args.tslimit, EXP["optimizer"], rank, world, gather_device)
@@ -175,7 +176,7 @@ def main():
         steps_local += p["env_steps"]
         # roofline kernel = the k_fc2 launches only (mid-range and tail lock-steps run other fc kernels)
         fc_ms += p["fc_full_ms"]; fc_launches += p["fc_full_launches"]; fc_units += p["fc_full_units"]
-        fc_all_ms += p["fc_ms"]; fc_kind = int(p["fc_full_kind"])
+        fc_all_ms += p["fc_ms"]; fc_kind = int(p["fc_full_kind"]); fc_union_ms += p["fc_full_union_ms"]
         for k in stage:
             stage[k] += p[k]
     barrier()
@@ -222,6 +223,12 @@ def main():
             # update included in the time) priced at the same algorithmic bytes
             out["roofline"]["whole_job"] = {"achieved": value * ALG_BYTES_PER_ENV_STEP / 1e9, "unit": "GB/s",
                                             "frac": value * ALG_BYTES_PER_ENV_STEP / (HBM_PEAK * world)}
+            # the windows launch this kernel concurrently from several streams; a launch that shares the chip with its siblings is
+            # stretched, so also: all profiled bytes / the time during which at least one such launch was running
+            if fc_union_ms > 0:
+                uni = fc_units * ALG_BYTES_PER_ENV_STEP / (fc_union_ms * 1e-3)
+                out["roofline"]["concurrent_launches"] = {"achieved": uni / 1e9, "unit": "GB/s", "frac": uni / HBM_PEAK,
+                                                          "busy_ms_per_generation": fc_union_ms / args.steps}
             tr = out["roofline"]["traffic"]
             if tr:
                 out["roofline"]["traffic_rate"] = {"value": tr / (avg_ms * 1e-3) / 1e9, "unit": "GB/s",

@@ -1009,18 +1009,30 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     for (int i = 0; i < n; i++) P.env_steps += lengths[i];
     P.fc_full_ms = P.fc_full_launches = P.fc_full_units = 0;
     P.fc_full_kind = fc2_eval ? 2 : 1;
+    P.fc_full_union_ms = 0;
     if (prof) {
         HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[0], h->ev_pool[1]));
         P.ref_ms = ms;
         std::vector<int32_t> units(evs.size());
         if (!evs.empty()) HCHECK(h, hipMemcpy(units.data(), h->launch_units, evs.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        std::vector<std::pair<float, float>> iv;   // fc intervals relative to the start of the reference pass
         for (size_t i = 0; i < evs.size(); i++) {
             const auto &e = evs[i];
             HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e[0]], h->ev_pool[e[1]])); P.conv_ms += ms;
             HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e[1]], h->ev_pool[e[2]])); P.fc_ms += ms;
             P.fc_full_ms += ms; P.fc_full_launches += 1; P.fc_full_units += units[i];
+            float t0 = 0;
+            HCHECK(h, hipEventElapsedTime(&t0, h->ev_pool[0], h->ev_pool[e[1]]));
+            iv.push_back({t0, t0 + ms});
             HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[e[2]], h->ev_pool[e[3]])); P.env_ms += ms;
         }
+        std::sort(iv.begin(), iv.end());
+        double uni = 0; float hi = -1;
+        for (auto &p : iv) {   // length of the union of the intervals
+            if (p.first > hi) { uni += p.second - p.first; hi = p.second; }
+            else if (p.second > hi) { uni += p.second - hi; hi = p.second; }
+        }
+        P.fc_full_union_ms = uni;
     }
     return 0;
 }

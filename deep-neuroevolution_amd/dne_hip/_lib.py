@@ -37,7 +37,7 @@ class Profile(C.Structure):
                 ("fc_group_steps", C.c_int64), ("env_steps", C.c_int64), ("conv_ms", C.c_double),
                 ("env_ms", C.c_double), ("ref_ms", C.c_double), ("reduce_ms", C.c_double),
                 ("materialize_ms", C.c_double), ("fc_full_ms", C.c_double), ("fc_full_launches", C.c_double),
-                ("fc_full_units", C.c_double), ("fc_full_kind", C.c_double), ("reserved", C.c_double * 2)]
+                ("fc_full_units", C.c_double), ("fc_full_kind", C.c_double), ("fc_full_union_ms", C.c_double), ("reserved", C.c_double * 1)]
 
 
 def build(force=False):
