@@ -829,7 +829,9 @@ static void launch_forward(dne_handle *h, const int *list, int count, int gsize,
 static void launch_fc(dne_handle *h, const int *list, int count, int gsize, float *logits, hipStream_t st = nullptr,
                       bool out_fused = false /* tail only: the caller runs k_tail_step instead of k_out */) {
     if (!st) st = h->stream;
-    const FwdArgs A = h->fwd(false);
+    // inside an evaluation (no logits requested) groups whose members are all done are skipped: they stay in the list until
+    // the next compaction, and streaming their weights would be wasted bandwidth
+    const FwdArgs A = h->fwd(logits == nullptr);
     const bool es = h->L.kind == DNE_KIND_ES;
     if (count <= h->fc_tail_max) {   // latency-bound regime: 4 workgroups per group + a separate output-layer kernel
 #define FCT(NV, BN)                                                                                                          \

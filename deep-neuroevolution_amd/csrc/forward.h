@@ -287,6 +287,12 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
         const int g = list ? list[item] : item;
 #pragma unroll
         for (int v = 0; v < NV; v++) { member[v] = g * NV + v; row[v] = member[v]; }
+        if (A.done) {   // finished group still in the list (compaction runs every 16 lock-steps): nothing to compute
+            bool all_done = true;
+#pragma unroll
+            for (int v = 0; v < NV; v++) all_done = all_done && A.done[member[v]] != 0;
+            if (all_done) continue;
+        }
     }
 #pragma unroll
     for (int v = 0; v < NV; v++) scale[v] = A.m_scale[member[v]];
@@ -457,11 +463,18 @@ __global__ __launch_bounds__(256) void k_fc2(FwdArgs A, const int *__restrict__ 
     const int n_items = (n_groups + 1) >> 1;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int i0 = 2 * item, i1 = min(2 * item + 1, n_groups - 1);
-    const int nm = 2 * item + 1 < n_groups ? NM : 2;   // odd count: the last item repeats its pair and writes it once
     int member[NM];
     float scale[NM];
+    int nm;
     {
-        const int g0 = list ? list[i0] : i0, g1 = list ? list[i1] : i1;
+        int g0 = list ? list[i0] : i0, g1 = list ? list[i1] : i1;
+        if (A.done) {   // finished pairs still in the list (compaction runs every 16 lock-steps) are not streamed
+            const bool d0 = A.done[2 * g0] && A.done[2 * g0 + 1], d1 = A.done[2 * g1] && A.done[2 * g1 + 1];
+            if (d0 && d1) continue;
+            if (d0) g0 = g1;
+            if (d1) g1 = g0;
+        }
+        nm = g0 != g1 ? NM : 2;   // odd count or a finished partner: the item repeats its pair (same addresses) and writes it once
         member[0] = 2 * g0; member[1] = 2 * g0 + 1; member[2] = 2 * g1; member[3] = 2 * g1 + 1;
     }
 #pragma unroll
@@ -758,6 +771,12 @@ __global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restric
     float scale[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) { member[v] = g * NV + v; scale[v] = A.m_scale[member[v]]; }
+    if (A.done) {   // finished group still in the list: nothing to compute
+        bool all_done = true;
+#pragma unroll
+        for (int v = 0; v < NV; v++) all_done = all_done && A.done[member[v]] != 0;
+        if (all_done) return;
+    }
     const int64_t off = A.m_off[member[0]];
     const float *base = A.bases + (size_t)A.m_slot[member[0]] * A.base_stride;
     const int col = cg * 16 + cl;
@@ -889,6 +908,12 @@ __global__ __launch_bounds__(256) void k_fc_cols(FwdArgs A, const int *__restric
     float scale[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) { member[v] = g * NV + v; scale[v] = A.m_scale[member[v]]; }
+    if (A.done) {   // finished group still in the list: nothing to compute
+        bool all_done = true;
+#pragma unroll
+        for (int v = 0; v < NV; v++) all_done = all_done && A.done[member[v]] != 0;
+        if (all_done) return;
+    }
     const int64_t off = A.m_off[member[0]];
     const float *base = A.bases + (size_t)A.m_slot[member[0]] * A.base_stride;
     const int col = cq * 64 + lane;
