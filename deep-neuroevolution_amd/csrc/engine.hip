@@ -274,6 +274,7 @@ struct dne_handle {
     std::vector<hipStream_t> sub_streams;   // sub-batch streams (sub_streams[0] == stream)
     int dbg_skip = 0;   // DNE_DEBUG_SKIP bitmask (timing experiments only): 1 conv1, 2 conv2, 4 render
     int render_threads = 256;
+    int conv_split_max = 32;         // members up to which the convolutions use their finest split (DNE_CONV_SPLIT_MAX)
     int fc_pairs = 2;                // ES full-width fc: antithetic pairs per work item (DNE_FC_PAIRS, 1 = k_fc<2>)
     int fc2_min_total = 800;         // k_fc2 from this many active groups upwards (DNE_FC2_MIN)
     bool fc2_now = false;            // decided per burst by eval_core
@@ -498,6 +499,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_BAND_THREADS", 256, 1024, &h->band_threads); h->band_threads = wg_size(h->band_threads);
     env_int("DNE_TAIL_FUSED_MAX", 0, 1 << 20, &h->tail_fused_max);
     env_int("DNE_FC_PAIRS", 1, 2, &h->fc_pairs);
+    env_int("DNE_CONV_SPLIT_MAX", 0, 1 << 20, &h->conv_split_max);
     env_int("DNE_FC2_MIN", 2, 1 << 30, &h->fc2_min_total);
     env_int("DNE_RENDER_BANDS", 1, 12, &h->render_bands);
     env_int("DNE_FC_CHAIN_MIN", 1, 1 << 30, &h->fc_chain_min);
@@ -817,7 +819,8 @@ static void launch_forward(dne_handle *h, const int *list, int count, int gsize,
     const FwdArgs A = h->fwd(use_done);
     const bool es = h->L.kind == DNE_KIND_ES;
     const int items = count * gsize;
-    const int s1 = items <= 64 ? 4 : 1, s2 = items <= 128 ? 2 : 1;   // few members left: several workgroups per member
+    // few members left: several workgroups per member (conv1: 28 position tiles over 4 or 7 workgroups; conv2: 8 over 2 or 4)
+    const int s1 = items <= h->conv_split_max ? 7 : items <= 64 ? 4 : 1, s2 = items <= h->conv_split_max ? 4 : items <= 128 ? 2 : 1;
     if (!(h->dbg_skip & 1))
     hipLaunchKernelGGL(k_conv1, dim3(items * s1), dim3(256), 0, st, A, list, gsize, 1, 0,
                        (const uint8_t *)h->stacks, (const uint8_t *)nullptr, h->y1, s1);

@@ -79,7 +79,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict__ list, int gsize, int F, int member0,
                                                const uint8_t *__restrict__ stacks, const uint8_t *__restrict__ ref,
                                                float *__restrict__ y1, int nsplit) {
-    // nsplit = 4 (few members left): four workgroups share one member's 28 position tiles to cut the latency
+    // nsplit = 4 / 7 (few members left): four / seven workgroups share one member's 28 position tiles to cut the latency
     const int part = blockIdx.x % nsplit;
     const Item it = decode_item(blockIdx.x / nsplit, list, gsize, F, member0, stacks, ref, A.done);
     if (it.skip) return;
@@ -147,6 +147,10 @@ __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict_
             if (HASB && posB < 441) out[posB * 16 + lp] = accB[r] + bias;
         }
     };
+    if (nsplit == 7) {   // the last handful of members: one tile per wave, seven workgroups per member
+        run(part, std::false_type{});
+        return;
+    }
     for (int j = nsplit == 4 ? 2 * part : 0; j < (nsplit == 4 ? 2 * part + 2 : 8); j += 2) {
         if (j + 1 < 7) run(j, std::true_type{});
         else run(j, std::false_type{});
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict_
 template <bool HAS_BN>
 __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict__ list, int gsize, int F, int member0,
                                                const float *__restrict__ y1, float *__restrict__ y2, int nsplit) {
-    const int part = blockIdx.x % nsplit;   // nsplit = 2: two workgroups share one member's position tiles
+    const int part = blockIdx.x % nsplit;   // nsplit = 2 / 4: two / four workgroups share one member's position tiles
     const Item it = decode_item(blockIdx.x / nsplit, list, gsize, F, member0, nullptr, nullptr, A.done);
     if (it.skip) return;
     constexpr int PS = 17;   // LDS pixel stride (16 channels + 1 pad)
@@ -211,8 +215,8 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
     }
     __syncthreads();
     auto run = [&](auto ntl_) {
-        constexpr int NTL = decltype(ntl_)::value;                   // position tiles per wave: 4, or 2 when split
-        const int mtb = mt0 + (NTL == 2 ? 2 * part : 0);
+        constexpr int NTL = decltype(ntl_)::value;                   // position tiles per wave: 4, or 2 / 1 when split
+        const int mtb = mt0 + (NTL == 2 ? 2 * part : NTL == 1 ? part : 0);
         int off[NTL];
         f32x4 acc[NTL];
 #pragma unroll
@@ -245,7 +249,8 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
                 if (pos < 121) o[pos * 32 + nt * 16 + lp] = acc[m][r] + bias;
             }
     };
-    if (nsplit == 2) run(std::integral_constant<int, 2>{});
+    if (nsplit == 4) run(std::integral_constant<int, 1>{});
+    else if (nsplit == 2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 4>{});
 }
 
