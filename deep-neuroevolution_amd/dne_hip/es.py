@@ -104,7 +104,9 @@ def generation_inputs(noise_len, num_params, n_pairs, generation, rank, world):
     generation) u32 draws indexed by global pair id."""
     mine = shard_pairs(n_pairs, rank, world)
     rs = np.random.RandomState(generation * world + rank)
-    idx = np.array([rs.randint(0, noise_len - num_params + 1) for _ in range(len(mine))], dtype=np.int64)
+    # one vectorised draw = the same values, in the same order, as len(mine) successive SharedNoiseTable.sample_index calls
+    # (legacy RandomState.randint with fixed bounds; pinned by tests/test_host_cpu.py)
+    idx = rs.randint(0, noise_len - num_params + 1, size=len(mine)).astype(np.int64)
     all_seeds = np.random.RandomState(1000 + generation).randint(0, 2 ** 32, size=2 * n_pairs, dtype=np.uint64).astype(np.uint32)
     seeds = np.stack([all_seeds[2 * mine], all_seeds[2 * mine + 1]], axis=1).reshape(-1)
     return mine, idx, seeds

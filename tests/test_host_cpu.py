@@ -80,6 +80,11 @@ def test_noise_table_and_sharding(small_noise, golden):
     both = np.zeros(20, np.uint32); both[np.repeat(2 * m0, 2) + np.tile([0, 1], 5)] = s0; both[np.repeat(2 * m1, 2) + np.tile([0, 1], 5)] = s1
     assert np.array_equal(both, sa)                            # env seeds depend on the global pair id only
     assert es.RECORD.itemsize == 32
+    # the vectorised index draw of generation_inputs equals successive sample_index calls on the same stream (es.py:412)
+    rs2 = np.random.RandomState(3 * 1 + 0)
+    t4 = es.SharedNoiseTable(count=100_000, seed=123)
+    _, iv, _ = es.generation_inputs(t4.noise.size, 1000, 64, 3, 0, 1)
+    assert iv.tolist() == [t4.sample_index(rs2, 1000) for _ in range(64)]
 
 
 def _exp(pop, tslimit):
