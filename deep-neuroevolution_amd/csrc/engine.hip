@@ -274,6 +274,7 @@ struct dne_handle {
     std::vector<hipStream_t> sub_streams;   // sub-batch streams (sub_streams[0] == stream)
     int dbg_skip = 0;   // DNE_DEBUG_SKIP bitmask (timing experiments only): 1 conv1, 2 conv2, 4 render
     int render_threads = 256;
+    int conv1_fpw = 8;               // reference pass: frames per conv1 workgroup (DNE_CONV1_FPW: 1, 2, 4, 8)
     int conv_split_max = 32;         // members up to which the convolutions use their finest split (DNE_CONV_SPLIT_MAX)
     int fc_pairs = 2;                // ES full-width fc: antithetic pairs per work item (DNE_FC_PAIRS, 1 = k_fc<2>)
     int fc2_min_total = 800;         // k_fc2 from this many active groups upwards (DNE_FC2_MIN)
@@ -499,6 +500,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_BAND_THREADS", 256, 1024, &h->band_threads); h->band_threads = wg_size(h->band_threads);
     env_int("DNE_TAIL_FUSED_MAX", 0, 1 << 20, &h->tail_fused_max);
     env_int("DNE_FC_PAIRS", 1, 2, &h->fc_pairs);
+    env_int("DNE_CONV1_FPW", 1, 8, &h->conv1_fpw);
     env_int("DNE_CONV_SPLIT_MAX", 0, 1 << 20, &h->conv_split_max);
     env_int("DNE_FC2_MIN", 2, 1 << 30, &h->fc2_min_total);
     env_int("DNE_RENDER_BANDS", 1, 12, &h->render_bands);
@@ -767,8 +769,11 @@ static int ref_pass(dne_handle *h, int n) {
         const int nc = std::min(h->ref_chunk, n - m0), w = c % nways;
         hipStream_t st = h->sub_streams[w];
         float *y1 = h->y1r[w], *y2 = h->y2r[w], *y3p = h->y3pr[w];
-        hipLaunchKernelGGL(k_conv1, dim3(nc * F), dim3(256), 0, st, A, (const int *)nullptr, 1, F, m0,
-                           (const uint8_t *)h->stacks, (const uint8_t *)h->ref, y1, 1);
+        if (h->conv1_fpw == 8 && F % 8 == 0) hipLaunchKernelGGL(k_conv1_ref<8>, dim3(nc * F / 8), dim3(256), 0, st, A, F, m0, (const uint8_t *)h->ref, y1);
+        else if (h->conv1_fpw == 4 && F % 4 == 0) hipLaunchKernelGGL(k_conv1_ref<4>, dim3(nc * F / 4), dim3(256), 0, st, A, F, m0, (const uint8_t *)h->ref, y1);
+        else if (h->conv1_fpw == 2 && F % 2 == 0) hipLaunchKernelGGL(k_conv1_ref<2>, dim3(nc * F / 2), dim3(256), 0, st, A, F, m0, (const uint8_t *)h->ref, y1);
+        else hipLaunchKernelGGL(k_conv1, dim3(nc * F), dim3(256), 0, st, A, (const int *)nullptr, 1, F, m0,
+                                (const uint8_t *)h->stacks, (const uint8_t *)h->ref, y1, 1);
         hipLaunchKernelGGL((k_bn_stats<16, 441>), dim3(nc), dim3(256), F * 16 * sizeof(float), st, A, m0, F,
                            (const float *)y1, 0, h->L.bn1b, h->L.bn1g);
         hipLaunchKernelGGL((k_conv2<true>), dim3(nc * F), dim3(256), 0, st, A, (const int *)nullptr, 1, F, m0,

@@ -157,6 +157,95 @@ __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict_
     }
 }
 
+// Reference-pass conv1 (policies.py:399: 128 reference frames through every member's perturbed net): one workgroup takes
+// FPW consecutive frames of ONE member, so the perturbed weights are formed once per FPW frames, and the next frame's
+// pixels are fetched into registers while the matrix cores work on the current one.  Same tiles, same MFMA order as k_conv1.
+template <int FPW>
+__global__ __launch_bounds__(256) void k_conv1_ref(FwdArgs A, int F, int member0, const uint8_t *__restrict__ ref,
+                                                   float *__restrict__ y1 /*[n_local * F][441][16]*/) {
+    __shared__ float lut[256];
+    __shared__ uint32_t img[88 * 88];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, ci = lane >> 4;
+    const int gpm = F / FPW;                         // frame groups per member
+    const int mloc = blockIdx.x / gpm, f0 = (blockIdx.x % gpm) * FPW;
+    const int member = member0 + mloc;
+    const float *base = A.bases + (size_t)A.m_slot[member] * A.base_stride + A.L.c1w;
+    const float *eps = A.noise + A.m_off[member] + A.L.c1w;
+    const float sc = A.m_scale[member];
+    uint32_t px[28];
+    auto fetch = [&](int f) {
+        const uint32_t *ob = (const uint32_t *)(ref + (size_t)f * OB_BYTES);
+#pragma unroll
+        for (int j = 0; j < 28; j++) {
+            const int e = tid + 256 * j;
+            px[j] = e < 7056 ? ob[e] : 0u;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < 28; j++) {
+            const int e = tid + 256 * j;
+            if (e < 7056) img[(e / 84 + 2) * 88 + e % 84 + 2] = px[j];
+        }
+    };
+    fetch(f0);
+    float b[64];
+#pragma unroll
+    for (int kk = 0; kk < 64; kk++) {
+        float v = sc * eps[64 * kk + lane];
+        b[kk] = base[64 * kk + lane] + v;
+    }
+    float pb = sc * eps[4096 + lp];
+    const float bias = base[4096 + lp] + pb;
+    lut[tid] = (float)tid / 255.0f;
+    for (int i = tid; i < 688; i += 256) {           // the 2-pixel zero border, once
+        int r, c;
+        if (i < 352) { r = i / 88; r = r < 2 ? r : 84 + r; c = i % 88; }
+        else { const int j = i - 352; r = 2 + j / 4; c = j % 4; c = c < 2 ? c : 84 + c; }
+        img[r * 88 + c] = 0u;
+    }
+    stage();
+    __syncthreads();
+    for (int fi = 0; fi < FPW; fi++) {
+        if (fi + 1 < FPW) fetch(f0 + fi + 1);        // in flight under the MFMAs below
+        float *out = y1 + ((size_t)mloc * F + f0 + fi) * 7056;
+        auto run = [&](int j, auto has_b) {
+            constexpr bool HASB = decltype(has_b)::value;
+            const int tA = wv + 4 * j, tB = wv + 4 * (j + 1);
+            const int pA = min(tA * 16 + lp, 440), pB = HASB ? min(tB * 16 + lp, 440) : 0;
+            const int oA = (pA / 21) * 4 * 88 + (pA % 21) * 4, oB = (pB / 21) * 4 * 88 + (pB % 21) * 4;
+            f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 8; kh++) {
+#pragma unroll
+                for (int kw = 0; kw < 8; kw++) {
+                    const float xA = lut[(img[oA + kh * 88 + kw] >> (8 * ci)) & 255u];
+                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xA, b[kh * 8 + kw], accA, 0, 0, 0);
+                    if (HASB) {
+                        const float xB = lut[(img[oB + kh * 88 + kw] >> (8 * ci)) & 255u];
+                        accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xB, b[kh * 8 + kw], accB, 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int posA = tA * 16 + ci * 4 + r, posB = tB * 16 + ci * 4 + r;
+                if (posA < 441) out[posA * 16 + lp] = accA[r] + bias;
+                if (HASB && posB < 441) out[posB * 16 + lp] = accB[r] + bias;
+            }
+        };
+        run(0, std::true_type{});
+        run(2, std::true_type{});
+        run(4, std::true_type{});
+        run(6, std::false_type{});
+        if (fi + 1 < FPW) {
+            __syncthreads();                         // every wave is done reading this frame
+            stage();
+            __syncthreads();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ conv2
 // 4x4 stride 2 SAME(1,2); input = relu(bn1(y1)) formed while staging; y2[row][121][32] raw.
 // GEMM view [121 -> 128 positions] x [256 = (kh,kw,ci)] x [32 co] on the same fp32 MFMA: wave w owns
