@@ -3,6 +3,8 @@
 // parent vectors, optimizer moments, frame stacks, emulator RAM, activations) lives in HBM for the
 // lifetime of the handle, and a generation only moves (noise_idx, seed) in and (return, length) out.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only: librccl.so is opened on demand by dne_comm_init
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <array>
@@ -315,6 +317,58 @@ struct dne_handle {
     // GA parent cache: prefix chain -> base slot
     std::map<std::vector<int64_t>, int> ga_cache;
     std::vector<int> free_slots;
+    // every device allocation of the handle, each between two poisoned red zones (dne_check_redzones)
+    struct Block { std::string name; uint8_t *raw; size_t bytes; };
+    std::vector<Block> blocks;
+    size_t redzone = 4096;           // bytes on each side (DNE_REDZONE=0 disables)
+    bool trace_on = false;           // DNE_TRACE=1: stage breadcrumbs on stderr
+    bool staged_copies = true;       // DNE_STAGED_COPY=0: hand large host buffers straight to hipMemcpy (diagnosis only)
+    bool debug_sync = false;         // DNE_DEBUG_SYNC=1: synchronize + check after every launch set of an evaluation
+    // pinned staging for large host <-> device transfers (the runtime would otherwise pin the caller's pages)
+    uint8_t *stage_buf[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    // gathered per-pair records of one generation, device-resident (dne_allgather_results / dne_records_set)
+    int64_t *rec_idx = nullptr; float *rec_ret = nullptr, *rec_sign = nullptr; int32_t *rec_len = nullptr;
+    uint8_t *rec_send = nullptr, *rec_recv = nullptr; size_t rec_cap = 0, rec_wire_cap = 0; int rec_n = 0;
+    std::vector<int64_t> rec_idx_host;
+    // RCCL communicator (dne_comm_init); the library is opened on demand
+    void *rccl_lib = nullptr; void *comm = nullptr; int comm_rank = 0, comm_size = 1;
+    double *comm_scratch = nullptr;
+
+    template <typename T>
+    hipError_t alloc(T **p, size_t n, const char *name) {
+        const size_t bytes = std::max<size_t>(n, 1) * sizeof(T), rz = redzone;
+        uint8_t *raw = nullptr;
+        hipError_t e = hipMalloc((void **)&raw, bytes + 2 * rz);
+        if (e != hipSuccess) { *p = nullptr; return e; }
+        if (rz) {
+            e = hipMemset(raw, 0xA5, rz);
+            if (e == hipSuccess) e = hipMemset(raw + rz + bytes, 0xA5, rz);
+            if (e != hipSuccess) { hipFree(raw); *p = nullptr; return e; }
+        }
+        blocks.push_back({name, raw, bytes});
+        *p = (T *)(raw + rz);
+        return hipSuccess;
+    }
+    template <typename T>
+    hipError_t release(T *&p) {
+        if (!p) return hipSuccess;
+        uint8_t *raw = (uint8_t *)p - redzone;
+        for (size_t i = 0; i < blocks.size(); i++)
+            if (blocks[i].raw == raw) { blocks.erase(blocks.begin() + i); break; }
+        p = nullptr;
+        return hipFree(raw);
+    }
+    void trace(const char *fmt, ...) {
+        if (!trace_on) return;
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        fprintf(stderr, "[dne %d] %s\n", cfg.device_id, buf);
+        fflush(stderr);
+    }
 
     int fail(const char *fmt, ...) {
         char buf[1024];
@@ -347,6 +401,19 @@ struct dne_handle {
         }
         return ev_pool[i];
     }
+};
+
+static int rec_reserve(dne_handle *h, int n_global, int per_world);
+
+// Every entry point runs on the handle's device whatever the calling thread's current device is, and puts the
+// caller's device back on the way out.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(const dne_handle *h) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != h->cfg.device_id) hipSetDevice(h->cfg.device_id); else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
 };
 
 static void make_layout(int kind, int nact, Layout *L) {
@@ -455,11 +522,11 @@ extern "C" const char *dne_last_error(dne_handle *h) { return h ? h->err.c_str()
 static int grow_bases(dne_handle *h, int cap) {
     if (cap <= h->base_cap) return 0;
     float *nb = nullptr;
-    HCHECK(h, dalloc(&nb, (size_t)cap * h->base_stride));
+    HCHECK(h, h->alloc(&nb, (size_t)cap * h->base_stride, "bases"));
     if (h->bases) {
         HCHECK(h, hipMemcpyAsync(nb, h->bases, (size_t)h->base_cap * h->base_stride * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         HCHECK(h, hipStreamSynchronize(h->stream));
-        HCHECK(h, hipFree(h->bases));
+        HCHECK(h, h->release(h->bases));
     }
     for (int s = cap - 1; s >= std::max(h->base_cap, 1); s--) h->free_slots.push_back(s);
     h->bases = nb;
@@ -492,6 +559,14 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
         if (const char *e = getenv(name)) *dst = std::max(lo, std::min(hi, atoi(e)));
     };
     auto wg_size = [](int v) { return v >= 1024 ? 1024 : v >= 512 ? 512 : 256; };   // the renderer needs >= 210 threads, whole waves
+    {
+        int rz = 1, tr = 0, ds = 0;
+        env_int("DNE_REDZONE", 0, 1, &rz); env_int("DNE_TRACE", 0, 1, &tr); env_int("DNE_DEBUG_SYNC", 0, 1, &ds);
+        h->redzone = rz ? 4096 : 0; h->trace_on = tr != 0; h->debug_sync = ds != 0;
+        int sc = 1;
+        env_int("DNE_STAGED_COPY", 0, 1, &sc);
+        h->staged_copies = sc != 0;
+    }
     env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
     env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
     env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
@@ -518,61 +593,98 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     const size_t M = h->M;
     CCHECK(grow_bases(h, 1));
     CH(hipMemset(h->bases, 0, h->base_stride * sizeof(float)));
-    CH(dalloc(&h->opt_m, h->L.P)); CH(dalloc(&h->opt_v, h->L.P)); CH(dalloc(&h->g, h->L.P));
+    CH(h->alloc(&h->opt_m, h->L.P, "opt_m")); CH(h->alloc(&h->opt_v, h->L.P, "opt_v")); CH(h->alloc(&h->g, h->L.P, "g"));
     CH(hipMemset(h->opt_m, 0, h->L.P * sizeof(float))); CH(hipMemset(h->opt_v, 0, h->L.P * sizeof(float)));
-    CH(dalloc(&h->partial, 2 * ((size_t)h->L.P / 256 + 1)));
-    if (h->F) CH(dalloc(&h->ref, (size_t)h->F * OB_BYTES));
-    CH(dalloc(&h->m_slot, M)); CH(dalloc(&h->m_off, M)); CH(dalloc(&h->m_scale, M));
+    CH(h->alloc(&h->partial, 2 * ((size_t)h->L.P / 256 + 1), "partial"));
+    if (h->F) CH(h->alloc(&h->ref, (size_t)h->F * OB_BYTES, "ref"));
+    CH(h->alloc(&h->m_slot, M, "m_slot")); CH(h->alloc(&h->m_off, M, "m_off")); CH(h->alloc(&h->m_scale, M, "m_scale"));
     CH(hipMemset(h->m_slot, 0, M * sizeof(int32_t))); CH(hipMemset(h->m_off, 0, M * sizeof(int64_t)));
     CH(hipMemset(h->m_scale, 0, M * sizeof(float)));
-    CH(dalloc(&h->bn, M * 608));
-    CH(dalloc(&h->ram_prev, M * 128)); CH(dalloc(&h->ram_cur, M * 128)); CH(dalloc(&h->stacks, M * OB_BYTES));
+    CH(h->alloc(&h->bn, M * 608, "bn"));
+    CH(h->alloc(&h->ram_prev, M * 128, "ram_prev")); CH(h->alloc(&h->ram_cur, M * 128, "ram_cur")); CH(h->alloc(&h->stacks, M * OB_BYTES, "stacks"));
     CH(hipMemset(h->stacks, 0, M * OB_BYTES));
-    CH(dalloc(&h->tables, 1));
+    CH(h->alloc(&h->tables, 1, "tables"));
     {
         ResizeLds T;
         make_tables(&T);
         CH(hipMemcpy(h->tables, &T, sizeof(T), hipMemcpyHostToDevice));
     }
-    CH(dalloc(&h->ret, M)); CH(dalloc(&h->sign, M)); CH(dalloc(&h->step_reward, M));
-    CH(dalloc(&h->logits, M * cfg->n_actions));
-    CH(dalloc(&h->len, M)); CH(dalloc(&h->done, M)); CH(dalloc(&h->action, M)); CH(dalloc(&h->seeds, M)); CH(dalloc(&h->stepped, M));
+    CH(h->alloc(&h->ret, M, "ret")); CH(h->alloc(&h->sign, M, "sign")); CH(h->alloc(&h->step_reward, M, "step_reward"));
+    CH(h->alloc(&h->logits, M * cfg->n_actions, "logits"));
+    CH(h->alloc(&h->len, M, "len")); CH(h->alloc(&h->done, M, "done")); CH(h->alloc(&h->action, M, "action")); CH(h->alloc(&h->seeds, M, "seeds")); CH(h->alloc(&h->stepped, M, "stepped"));
     CH(hipMemset(h->done, 0, M * sizeof(int32_t))); CH(hipMemset(h->len, 0, M * sizeof(int32_t)));
-    CH(dalloc(&h->y1, M * 7056)); CH(dalloc(&h->y2, M * 3872)); CH(dalloc(&h->y3, M * 256)); CH(dalloc(&h->y3t, M * 4 * 256));
+    CH(h->alloc(&h->y1, M * 7056, "y1")); CH(h->alloc(&h->y2, M * 3872, "y2")); CH(h->alloc(&h->y3, M * 256, "y3")); CH(h->alloc(&h->y3t, M * 4 * 256, "y3t"));
     if (h->F) {
         const size_t rr = (size_t)h->ref_chunk * h->F;
         for (int w = 0; w < 2; w++) {
-            CH(dalloc(&h->y1r[w], rr * 7056)); CH(dalloc(&h->y2r[w], rr * 3872)); CH(dalloc(&h->y3pr[w], rr * 4 * 256));
+            CH(h->alloc(&h->y1r[w], rr * 7056, "y1r[w]")); CH(h->alloc(&h->y2r[w], rr * 3872, "y2r[w]")); CH(h->alloc(&h->y3pr[w], rr * 4 * 256, "y3pr[w]"));
             CH(hipEventCreateWithFlags(&h->ev_ref[w], hipEventDisableTiming));
         }
     }
-    CH(dalloc(&h->list_a, M)); CH(dalloc(&h->list_b, M)); CH(dalloc(&h->count_dev, 8));
+    CH(h->alloc(&h->list_a, M, "list_a")); CH(h->alloc(&h->list_b, M, "list_b")); CH(h->alloc(&h->count_dev, 8, "count_dev"));
     if (cfg->record_bc) {
         h->bc_bytes = cfg->policy_kind == DNE_KIND_ES ? M * (size_t)std::max(cfg->bc_max_steps, 1) * 128 : M * 128;
-        CH(dalloc(&h->bc, h->bc_bytes));
+        CH(h->alloc(&h->bc, h->bc_bytes, "bc"));
         CH(hipMemset(h->bc, 0, h->bc_bytes));   // the emulator writes the RAM_LIVE bytes of a row; the other bytes of the 128 stay zero for good
     }
     h->scratch_cap = std::max<size_t>(4 * M + 64, 65536);
-    CH(dalloc(&h->scratch_f, h->scratch_cap)); CH(dalloc(&h->scratch_i, h->scratch_cap));
+    CH(h->alloc(&h->scratch_f, h->scratch_cap, "scratch_f")); CH(h->alloc(&h->scratch_i, h->scratch_cap, "scratch_i"));
     CH(hipEventCreate(&h->ev_a)); CH(hipEventCreate(&h->ev_b));
     for (int i = 0; i < 64; i++) { hipEvent_t ev; CH(hipEventCreateWithFlags(&ev, hipEventDisableTiming)); h->fc_ring.push_back(ev); }
     CH(hipDeviceSynchronize());
 #undef CH
 #undef CCHECK
+    {
+        size_t tot = 0;
+        for (auto &b : h->blocks) tot += b.bytes;
+        h->trace("engine created: kind %d, %d members, %d reference frames, %zu device buffers, %.2f GB", cfg->policy_kind, h->M,
+                 h->F, h->blocks.size(), tot / 1e9);
+    }
     *out = h;
     return 0;
 }
 
+// Every device buffer sits between two 4 KiB zones filled with 0xA5 at allocation; a kernel that writes outside its
+// buffer shows up here (reads cannot be seen).  Returns the number of damaged zones (0 = clean), -1 on a HIP error;
+// dne_last_error names the first damaged buffer.
+extern "C" int dne_check_redzones(dne_handle *h) {
+    DeviceGuard dg(h);
+    if (!h->redzone) return 0;
+    HCHECK(h, hipDeviceSynchronize());
+    const size_t rz = h->redzone;
+    std::vector<uint8_t> host(2 * rz);
+    int bad = 0;
+    for (auto &b : h->blocks) {
+        HCHECK(h, hipMemcpy(host.data(), b.raw, rz, hipMemcpyDeviceToHost));
+        HCHECK(h, hipMemcpy(host.data() + rz, b.raw + rz + b.bytes, rz, hipMemcpyDeviceToHost));
+        for (int side = 0; side < 2; side++) {
+            size_t first = rz;
+            for (size_t i = 0; i < rz; i++)
+                if (host[side * rz + i] != 0xA5) { first = i; break; }
+            if (first < rz) {
+                if (!bad) h->fail("red zone %s buffer '%s' (%zu bytes) damaged at byte %zu", side ? "after" : "before", b.name.c_str(),
+                                  b.bytes, side ? first : rz - first);
+                bad++;
+            }
+        }
+    }
+    return bad;
+}
+
+static void comm_destroy(dne_handle *h);
+
 extern "C" void dne_destroy(dne_handle *h) {
     if (!h) return;
-    hipSetDevice(h->cfg.device_id);
+    DeviceGuard dg(h);
     hipDeviceSynchronize();
-    void *ptrs[] = {h->noise, h->bases, h->opt_m, h->opt_v, h->g, h->partial, h->ref, h->m_slot, h->m_off, h->m_scale,
-                    h->bn, h->ram_prev, h->ram_cur, h->stacks, h->tables, h->ret, h->sign, h->step_reward, h->logits,
-                    h->len, h->done, h->action, h->seeds, h->stepped, h->launch_units, h->y1, h->y2, h->y3, h->y3t, h->y1r[0], h->y1r[1], h->y2r[0], h->y2r[1], h->y3pr[0], h->y3pr[1], h->list_a, h->list_b, h->count_dev,
-                    h->bc, h->mat_out, h->scratch_f, h->scratch_i};
-    for (void *p : ptrs)
-        if (p) hipFree(p);
+    if (dne_check_redzones(h) > 0) fprintf(stderr, "libdne_hip: %s\n", h->err.c_str());
+    comm_destroy(h);
+    for (auto &b : h->blocks) hipFree(b.raw);
+    h->blocks.clear();
+    for (int i = 0; i < 2; i++) {
+        if (h->stage_buf[i]) hipHostFree(h->stage_buf[i]);
+        if (h->stage_ev[i]) hipEventDestroy(h->stage_ev[i]);
+    }
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     for (hipEvent_t e : h->fc_ring) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_ref) if (e) hipEventDestroy(e);
@@ -589,13 +701,85 @@ extern "C" int dne_get_profile(dne_handle *h, dne_profile *out) {
 }
 
 // ------------------------------------------------------------------------------- noise / theta
-extern "C" int dne_noise_upload(dne_handle *h, const float *host, size_t count) {
-    HCHECK(h, hipSetDevice(h->cfg.device_id));
-    if (h->noise) { HCHECK(h, hipFree(h->noise)); h->noise = nullptr; }
-    HCHECK(h, dalloc(&h->noise, count + 64));
-    HCHECK(h, hipMemcpy(h->noise, host, count * sizeof(float), hipMemcpyHostToDevice));
+// Large transfers go through two engine-owned pinned buffers instead of handing the caller's pageable memory to the
+// runtime (which, above 128 MiB, registers the caller's pages with the GPU and copies from them in place -- the only
+// transfer of that kind in a generation's life is the 1 GB table upload).  Small copies keep using hipMemcpy.
+constexpr size_t STAGE_BYTES = 32u << 20, STAGE_MIN = 64u << 20;
+
+static int stage_init(dne_handle *h) {
+    for (int i = 0; i < 2; i++) {
+        if (!h->stage_buf[i]) HCHECK(h, hipHostMalloc((void **)&h->stage_buf[i], STAGE_BYTES, hipHostMallocDefault));
+        if (!h->stage_ev[i]) HCHECK(h, hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+static int copy_h2d(dne_handle *h, void *dst, const void *src, size_t bytes) {
+    if (bytes < STAGE_MIN || !h->staged_copies) { HCHECK(h, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+    if (stage_init(h)) return -1;
+    size_t done = 0;
+    for (int c = 0; done < bytes; c++) {
+        const int b = c & 1;
+        const size_t n = std::min(STAGE_BYTES, bytes - done);
+        if (c >= 2) HCHECK(h, hipEventSynchronize(h->stage_ev[b]));   // the copy that last read this buffer
+        memcpy(h->stage_buf[b], (const uint8_t *)src + done, n);
+        HCHECK(h, hipMemcpyAsync((uint8_t *)dst + done, h->stage_buf[b], n, hipMemcpyHostToDevice, h->stream));
+        HCHECK(h, hipEventRecord(h->stage_ev[b], h->stream));
+        done += n;
+    }
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int copy_d2h(dne_handle *h, void *dst, const void *src, size_t bytes) {
+    if (bytes < STAGE_MIN || !h->staged_copies) { HCHECK(h, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return 0; }
+    if (stage_init(h)) return -1;
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    size_t issued = 0, drained = 0;
+    for (int c = 0; drained < bytes; c++) {   // chunk c is copied out of its buffer while chunk c + 1 arrives in the other
+        const int b = c & 1;
+        if (c == 0) {
+            const size_t n = std::min(STAGE_BYTES, bytes);
+            HCHECK(h, hipMemcpyAsync(h->stage_buf[0], src, n, hipMemcpyDeviceToHost, h->stream));
+            HCHECK(h, hipEventRecord(h->stage_ev[0], h->stream));
+            issued = n;
+        }
+        const size_t mine = std::min(STAGE_BYTES, bytes - drained);
+        if (issued < bytes) {
+            const size_t n = std::min(STAGE_BYTES, bytes - issued);
+            HCHECK(h, hipMemcpyAsync(h->stage_buf[b ^ 1], (const uint8_t *)src + issued, n, hipMemcpyDeviceToHost, h->stream));
+            HCHECK(h, hipEventRecord(h->stage_ev[b ^ 1], h->stream));
+            issued += n;
+        }
+        HCHECK(h, hipEventSynchronize(h->stage_ev[b]));
+        memcpy((uint8_t *)dst + drained, h->stage_buf[b], mine);
+        drained += mine;
+    }
+    return 0;
+}
+
+extern "C" int dne_noise_alloc(dne_handle *h, size_t count) {
+    DeviceGuard dg(h);
+    if (count == 0) return h->fail("dne_noise_alloc: empty table");
+    HCHECK(h, h->release(h->noise));
+    h->noise_count = 0;
+    HCHECK(h, h->alloc(&h->noise, count + 64, "noise"));
     HCHECK(h, hipMemset(h->noise + count, 0, 64 * sizeof(float)));
     h->noise_count = count;
+    h->trace("noise table allocated: %zu floats", count);
+    return 0;
+}
+
+extern "C" int dne_noise_write(dne_handle *h, size_t offset, const float *host, size_t count) {
+    DeviceGuard dg(h);
+    if (!h->noise || offset + count > h->noise_count) return h->fail("dne_noise_write: [%zu, %zu) outside the table of %zu", offset, offset + count, h->noise_count);
+    return copy_h2d(h, h->noise + offset, host, count * sizeof(float));
+}
+
+extern "C" int dne_noise_upload(dne_handle *h, const float *host, size_t count) {
+    if (dne_noise_alloc(h, count)) return -1;
+    if (dne_noise_write(h, 0, host, count)) return -1;
+    h->trace("noise table uploaded");
     return 0;
 }
 
@@ -606,12 +790,14 @@ static int check_noise_range(dne_handle *h, int64_t idx, int64_t dim) {
 }
 
 extern "C" int dne_noise_get(dne_handle *h, int64_t idx, int dim, float *out) {
+    DeviceGuard dg(h);
     if (check_noise_range(h, idx, dim)) return -1;
     HCHECK(h, hipMemcpy(out, h->noise + idx, (size_t)dim * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 
 extern "C" int dne_set_theta(dne_handle *h, int slot, const float *theta, size_t n) {
+    DeviceGuard dg(h);
     if (n != (size_t)h->L.P) return h->fail("dne_set_theta: expected %d parameters, got %zu", h->L.P, n);
     if (slot < 0) return h->fail("bad slot");
     if (grow_bases(h, slot + 1)) return -1;
@@ -620,6 +806,7 @@ extern "C" int dne_set_theta(dne_handle *h, int slot, const float *theta, size_t
 }
 
 extern "C" int dne_get_theta(dne_handle *h, int slot, float *out, size_t n) {
+    DeviceGuard dg(h);
     if (n != (size_t)h->L.P) return h->fail("dne_get_theta: expected %d parameters, got %zu", h->L.P, n);
     if (slot < 0 || slot >= h->base_cap) return h->fail("bad slot");
     HCHECK(h, hipStreamSynchronize(h->stream));
@@ -628,6 +815,7 @@ extern "C" int dne_get_theta(dne_handle *h, int slot, float *out, size_t n) {
 }
 
 extern "C" int dne_set_ref_batch(dne_handle *h, const uint8_t *ref, int count) {
+    DeviceGuard dg(h);
     if (h->L.kind != DNE_KIND_ES) return h->fail("reference batch is an ESAtariPolicy concept");
     if (count != h->F) return h->fail("dne_set_ref_batch: engine was created for %d reference frames, got %d", h->F, count);
     HCHECK(h, hipMemcpy(h->ref, ref, (size_t)count * OB_BYTES, hipMemcpyHostToDevice));
@@ -636,12 +824,13 @@ extern "C" int dne_set_ref_batch(dne_handle *h, const uint8_t *ref, int count) {
 }
 
 extern "C" int dne_materialize(dne_handle *h, const int64_t *idx, int n, float sigma, float *out_host) {
+    DeviceGuard dg(h);
     for (int i = 0; i < n; i++)
         if (check_noise_range(h, idx[i], h->L.P)) return -1;
     const size_t need = (size_t)n * 2 * h->L.P;
     if (need > h->mat_cap) {
-        if (h->mat_out) HCHECK(h, hipFree(h->mat_out));
-        HCHECK(h, dalloc(&h->mat_out, need));
+        HCHECK(h, h->release(h->mat_out));
+        HCHECK(h, h->alloc(&h->mat_out, need, "mat_out"));
         h->mat_cap = need;
     }
     if ((size_t)n > h->scratch_cap) return h->fail("too many pairs");
@@ -654,7 +843,7 @@ extern "C" int dne_materialize(dne_handle *h, const int64_t *idx, int n, float s
     float ms = 0;
     HCHECK(h, hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
     h->prof.materialize_ms = ms;
-    if (out_host) HCHECK(h, hipMemcpy(out_host, h->mat_out, need * sizeof(float), hipMemcpyDeviceToHost));
+    if (out_host && copy_d2h(h, out_host, h->mat_out, need * sizeof(float))) return -1;
     return 0;
 }
 
@@ -680,6 +869,7 @@ static int check_n(dne_handle *h, int n) {
 }
 
 extern "C" int dne_env_reset(dne_handle *h, int n, const uint32_t *seeds) {
+    DeviceGuard dg(h);
     if (check_n(h, n)) return -1;
     HCHECK(h, hipMemcpyAsync(h->seeds, seeds, n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     launch_env_reset(h, n);
@@ -689,6 +879,7 @@ extern "C" int dne_env_reset(dne_handle *h, int n, const uint32_t *seeds) {
 }
 
 extern "C" int dne_env_step(dne_handle *h, int n, const int32_t *actions, float *reward, int32_t *done) {
+    DeviceGuard dg(h);
     if (check_n(h, n)) return -1;
     for (int i = 0; i < n; i++)
         if (actions[i] < 0 || actions[i] >= h->cfg.n_actions) return h->fail("action %d out of range", actions[i]);
@@ -703,6 +894,7 @@ extern "C" int dne_env_step(dne_handle *h, int n, const int32_t *actions, float 
 }
 
 extern "C" int dne_env_observation(dne_handle *h, int n, uint8_t *out) {
+    DeviceGuard dg(h);
     if (check_n(h, n)) return -1;
     HCHECK(h, hipStreamSynchronize(h->stream));
     HCHECK(h, hipMemcpy(out, h->stacks, (size_t)n * OB_BYTES, hipMemcpyDeviceToHost));
@@ -710,6 +902,7 @@ extern "C" int dne_env_observation(dne_handle *h, int n, uint8_t *out) {
 }
 
 extern "C" int dne_env_ram(dne_handle *h, int n, uint8_t *out) {
+    DeviceGuard dg(h);
     if (check_n(h, n)) return -1;
     HCHECK(h, hipStreamSynchronize(h->stream));
     HCHECK(h, hipMemcpy(out, h->ram_cur, (size_t)n * 128, hipMemcpyDeviceToHost));
@@ -717,12 +910,14 @@ extern "C" int dne_env_ram(dne_handle *h, int n, uint8_t *out) {
 }
 
 extern "C" int dne_env_set_observation(dne_handle *h, int n, const uint8_t *obs) {
+    DeviceGuard dg(h);
     if (check_n(h, n)) return -1;
     HCHECK(h, hipMemcpy(h->stacks, obs, (size_t)n * OB_BYTES, hipMemcpyHostToDevice));
     return 0;
 }
 
 extern "C" int dne_env_set_ram(dne_handle *h, int n, const uint8_t *ram_prev, const uint8_t *ram_cur) {
+    DeviceGuard dg(h);
     if (check_n(h, n)) return -1;
     HCHECK(h, hipMemcpyAsync(h->ram_prev, ram_prev, (size_t)n * 128, hipMemcpyHostToDevice, h->stream));
     HCHECK(h, hipMemcpyAsync(h->ram_cur, ram_cur, (size_t)n * 128, hipMemcpyHostToDevice, h->stream));
@@ -737,6 +932,7 @@ extern "C" int dne_env_set_ram(dne_handle *h, int n, const uint8_t *ram_prev, co
 
 // ------------------------------------------------------------------------------- forward
 extern "C" int dne_set_members(dne_handle *h, int n, const int32_t *slot, const int64_t *off, const float *scale) {
+    DeviceGuard dg(h);
     if (check_n(h, n)) return -1;
     for (int i = 0; i < n; i++) {
         if (slot[i] < 0 || slot[i] >= h->base_cap) return h->fail("member %d: base slot %d not allocated", i, slot[i]);
@@ -804,6 +1000,7 @@ static int ref_pass(dne_handle *h, int n) {
 }
 
 extern "C" int dne_ref_pass(dne_handle *h, int n) {
+    DeviceGuard dg(h);
     if (check_n(h, n)) return -1;
     if (h->L.kind != DNE_KIND_ES) return h->fail("dne_ref_pass: GAAtariPolicy has no reference batch");
     if (ref_pass(h, n)) return -1;
@@ -812,6 +1009,7 @@ extern "C" int dne_ref_pass(dne_handle *h, int n) {
 }
 
 extern "C" int dne_get_bn(dne_handle *h, int n, float *out) {
+    DeviceGuard dg(h);
     if (check_n(h, n)) return -1;
     HCHECK(h, hipStreamSynchronize(h->stream));
     HCHECK(h, hipMemcpy(out, h->bn, (size_t)n * 608 * sizeof(float), hipMemcpyDeviceToHost));
@@ -869,6 +1067,7 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
 }
 
 extern "C" int dne_act(dne_handle *h, int n, int32_t *actions, float *logits) {
+    DeviceGuard dg(h);
     if (check_n(h, n)) return -1;
     launch_forward(h, nullptr, n, 1, false);
     launch_fc(h, nullptr, n, 1, h->logits);
@@ -880,6 +1079,7 @@ extern "C" int dne_act(dne_handle *h, int n, int32_t *actions, float *logits) {
 }
 
 extern "C" int dne_debug_activations(dne_handle *h, int member, float *y1, float *y2, float *y3) {
+    DeviceGuard dg(h);
     if (member < 0 || member >= h->M) return h->fail("bad member");
     HCHECK(h, hipStreamSynchronize(h->stream));
     if (y1) HCHECK(h, hipMemcpy(y1, h->y1 + (size_t)member * 7056, 7056 * sizeof(float), hipMemcpyDeviceToHost));
@@ -910,7 +1110,11 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     HCHECK(h, hipMemcpyAsync(h->seeds, env_seed, n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     launch_env_reset(h, n);
     if (prof) HCHECK(h, hipEventRecord(h->event(0), h->stream));
+    h->trace("eval: %d members (groups of %d), tslimit %d: reset launched", n, gsize, tslimit);
+    if (h->debug_sync) { HCHECK(h, hipStreamSynchronize(h->stream)); HCHECK(h, hipGetLastError()); }
     if (ref_pass(h, n)) return -1;
+    if (h->debug_sync) { HCHECK(h, hipDeviceSynchronize()); HCHECK(h, hipGetLastError()); }
+    h->trace("eval: reference pass %s", h->debug_sync ? "done" : "launched");
     HCHECK(h, hipEventRecord(h->event(1), h->stream));
     const int groups = n / gsize;
     hipLaunchKernelGGL(k_iota, dim3((groups + 255) / 256), dim3(256), 0, h->stream, h->list_a, groups);
@@ -940,8 +1144,8 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     if (prof) {
         const size_t need = (size_t)h->sub_streams.size() * (size_t)tslimit + 64;
         if (need > h->launch_units_cap) {
-            if (h->launch_units) HCHECK(h, hipFree(h->launch_units));
-            HCHECK(h, dalloc(&h->launch_units, need));
+            HCHECK(h, h->release(h->launch_units));
+            HCHECK(h, h->alloc(&h->launch_units, need, "launch_units"));
             h->launch_units_cap = need;
         }
         HCHECK(h, hipMemsetAsync(h->launch_units, 0, need * sizeof(int32_t), h->stream));
@@ -989,6 +1193,12 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
 #undef TS
                 } else launch_env_step(h, E, lst, cnt, gsize, tslimit, sst);
                 if (pe) { e[3] = ne++; HCHECK(h, hipEventRecord(h->event(e[3]), sst)); evs.push_back(e); }
+                if (h->debug_sync) {
+                    hipError_t de = hipStreamSynchronize(sst);
+                    if (de == hipSuccess) de = hipGetLastError();
+                    if (de != hipSuccess) return h->fail("lock-step %d window %d/%d (%d of %d active groups, %s fc): %s", t + st, s, nsub, cnt, total,
+                                                         cnt <= h->fc_tail_max ? "tail" : h->fc2_now ? "k_fc2" : "k_fc", hipGetErrorString(de));
+                }
                 group_steps += cnt;
                 launch_sets++;
             }
@@ -1000,6 +1210,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
         HCHECK(h, hipMemcpyAsync(&total, h->count_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HCHECK(h, hipStreamSynchronize(h->stream));
         std::swap(cur, nxt);
+        h->trace("eval: lock-step %d, %d active groups", t, total);
     }
     HCHECK(h, hipGetLastError());
     HCHECK(h, hipEventRecord(h->ev_b, h->stream));
@@ -1007,7 +1218,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     if (signreturns) HCHECK(h, hipMemcpyAsync(signreturns, h->sign, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HCHECK(h, hipMemcpyAsync(lengths, h->len, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HCHECK(h, hipStreamSynchronize(h->stream));
-    if (bc_out) HCHECK(h, hipMemcpy(bc_out, h->bc, bc_mode == 1 ? (size_t)n * h->cfg.bc_max_steps * 128 : (size_t)n * 128, hipMemcpyDeviceToHost));
+    if (bc_out && copy_d2h(h, bc_out, h->bc, bc_mode == 1 ? (size_t)n * h->cfg.bc_max_steps * 128 : (size_t)n * 128)) return -1;
     float ms = 0;
     HCHECK(h, hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
     dne_profile &P = h->prof;
@@ -1049,6 +1260,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
 
 extern "C" int dne_es_eval(dne_handle *h, const int64_t *idx, int n, float sigma, int tslimit, const uint32_t *env_seed,
                            float *returns_n2, float *signreturns_n2, int32_t *lengths_n2, uint8_t *bc) {
+    DeviceGuard dg(h);
     if (h->L.kind != DNE_KIND_ES) return h->fail("dne_es_eval needs an ESAtariPolicy engine");
     if (n <= 0 || 2 * n > h->M) return h->fail("%d pairs exceed max_members = %d", n, h->M);
     std::vector<int32_t> slot(2 * n, 0);
@@ -1065,6 +1277,7 @@ extern "C" int dne_es_eval(dne_handle *h, const int64_t *idx, int n, float sigma
 
 extern "C" int dne_eval_members(dne_handle *h, int n, int tslimit, const uint32_t *env_seed, float *returns,
                                 float *signreturns, int32_t *lengths, uint8_t *bc) {
+    DeviceGuard dg(h);
     if (check_n(h, n)) return -1;
     return eval_core(h, n, 1, tslimit, env_seed, returns, signreturns, lengths, bc);
 }
@@ -1107,6 +1320,7 @@ static int build_chain(dne_handle *h, int slot, const int64_t *seeds, int nseeds
 }
 
 extern "C" int dne_ga_rebuild(dne_handle *h, int slot, const int64_t *seeds, int nseeds, float sigma, float *out_host) {
+    DeviceGuard dg(h);
     if (h->L.kind != DNE_KIND_GA) return h->fail("dne_ga_rebuild needs a GAAtariPolicy engine");
     if (slot < 0 || nseeds < 1) return h->fail("bad arguments");
     if (grow_bases(h, slot + 1)) return -1;
@@ -1120,6 +1334,7 @@ extern "C" int dne_ga_rebuild(dne_handle *h, int slot, const int64_t *seeds, int
 
 extern "C" int dne_ga_eval(dne_handle *h, const int32_t *co, const int64_t *seeds, int n, float sigma, int tslimit,
                            const uint32_t *env_seed, float *returns, float *signreturns, int32_t *lengths, uint8_t *bc) {
+    DeviceGuard dg(h);
     if (h->L.kind != DNE_KIND_GA) return h->fail("dne_ga_eval needs a GAAtariPolicy engine");
     if (check_n(h, n)) return -1;
     // Every child = parent chain + one fresh seed (ga.py:251-254).  Parents are materialised once into
@@ -1208,7 +1423,9 @@ extern "C" int dne_ga_eval(dne_handle *h, const int32_t *co, const int64_t *seed
 
 // ------------------------------------------------------------------------------- reduce
 extern "C" int dne_centered_ranks(dne_handle *h, const float *x, int n, float *out) {
-    if (n < 2 || (size_t)2 * n > h->scratch_cap) return h->fail("dne_centered_ranks: n = %d unsupported", n);
+    DeviceGuard dg(h);
+    if (n < 2) return h->fail("dne_centered_ranks: n = %d unsupported", n);
+    if (rec_reserve(h, (n + 1) / 2, 1)) return -1;
     HCHECK(h, hipMemcpyAsync(h->scratch_f, x, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_centered_ranks, dim3((n + 255) / 256), dim3(256), 0, h->stream, (const float *)h->scratch_f, n, h->scratch_f + n);
     HCHECK(h, hipMemcpyAsync(out, h->scratch_f + n, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1233,7 +1450,9 @@ static int weighted_sum_dev(dne_handle *h, const int64_t *idx_host, const float 
 }
 
 extern "C" int dne_weighted_sum(dne_handle *h, const int64_t *idx, const float *w, int n, float denom, float *g_host) {
-    if (n < 1 || (size_t)n > h->scratch_cap) return h->fail("dne_weighted_sum: n = %d unsupported", n);
+    DeviceGuard dg(h);
+    if (n < 1) return h->fail("dne_weighted_sum: n = %d unsupported", n);
+    if (rec_reserve(h, n, 1)) return -1;
     HCHECK(h, hipMemcpyAsync(h->scratch_f, w, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     if (weighted_sum_dev(h, idx, h->scratch_f, n, denom)) return -1;
     if (g_host) HCHECK(h, hipMemcpy(g_host, h->g, (size_t)h->L.P * sizeof(float), hipMemcpyDeviceToHost));
@@ -1241,6 +1460,7 @@ extern "C" int dne_weighted_sum(dne_handle *h, const int64_t *idx, const float *
 }
 
 extern "C" int dne_optimizer_reset(dne_handle *h) {
+    DeviceGuard dg(h);
     HCHECK(h, hipMemsetAsync(h->opt_m, 0, h->L.P * sizeof(float), h->stream));
     HCHECK(h, hipMemsetAsync(h->opt_v, 0, h->L.P * sizeof(float), h->stream));
     HCHECK(h, hipStreamSynchronize(h->stream));
@@ -1249,6 +1469,7 @@ extern "C" int dne_optimizer_reset(dne_handle *h) {
 }
 
 extern "C" int dne_optimizer_get_state(dne_handle *h, float *m, float *v, int32_t *t) {
+    DeviceGuard dg(h);
     HCHECK(h, hipStreamSynchronize(h->stream));
     if (m) HCHECK(h, hipMemcpy(m, h->opt_m, (size_t)h->L.P * sizeof(float), hipMemcpyDeviceToHost));
     if (v) HCHECK(h, hipMemcpy(v, h->opt_v, (size_t)h->L.P * sizeof(float), hipMemcpyDeviceToHost));
@@ -1257,6 +1478,7 @@ extern "C" int dne_optimizer_get_state(dne_handle *h, float *m, float *v, int32_
 }
 
 extern "C" int dne_optimizer_set_state(dne_handle *h, const float *m, const float *v, int32_t t) {
+    DeviceGuard dg(h);
     if (t < 0) return h->fail("optimizer step count must be >= 0");
     if (m) HCHECK(h, hipMemcpy(h->opt_m, m, (size_t)h->L.P * sizeof(float), hipMemcpyHostToDevice));
     if (v) HCHECK(h, hipMemcpy(h->opt_v, v, (size_t)h->L.P * sizeof(float), hipMemcpyHostToDevice));
@@ -1266,6 +1488,7 @@ extern "C" int dne_optimizer_set_state(dne_handle *h, const float *m, const floa
 
 extern "C" int dne_optimizer_step(dne_handle *h, int kind, float l2, double stepsize, double b1m, double b2, double eps,
                                   double *ratio) {
+    DeviceGuard dg(h);
     const int P = h->L.P, nb = (P + 255) / 256;
     h->opt_t += 1;   // optimizers.py:11
     if (kind == DNE_OPT_ADAM) {
@@ -1288,32 +1511,244 @@ extern "C" int dne_optimizer_step(dne_handle *h, int kind, float l2, double step
     return 0;
 }
 
-extern "C" int dne_es_update(dne_handle *h, const int64_t *idx, const float *returns_n2, const float *signreturns_n2, int n,
-                             int proc_mode, int opt_kind, float l2, double stepsize, double b1m, double b2, double eps,
-                             double *ratio) {
-    if (n < 1 || (size_t)5 * n > h->scratch_cap) return h->fail("dne_es_update: n = %d unsupported", n);
-    const int n2 = 2 * n;
-    float *x = h->scratch_f, *proc = h->scratch_f + n2, *w = h->scratch_f + 2 * n2;
+// ------------------------------------------------------------------------------- exchange
+// One generation's per-pair records, gathered from every GPU, live on the device in global pair order
+// (rec_idx / rec_ret / rec_sign / rec_len) and feed the update directly.
+static int rec_reserve(dne_handle *h, int n_global, int per_world) {
+    if ((size_t)n_global > h->rec_cap) {
+        HCHECK(h, h->release(h->rec_idx)); HCHECK(h, h->release(h->rec_ret)); HCHECK(h, h->release(h->rec_sign));
+        HCHECK(h, h->release(h->rec_len));
+        const size_t cap = std::max<size_t>((size_t)n_global, 4096);
+        HCHECK(h, h->alloc(&h->rec_idx, cap, "rec_idx")); HCHECK(h, h->alloc(&h->rec_ret, 2 * cap, "rec_ret"));
+        HCHECK(h, h->alloc(&h->rec_sign, 2 * cap, "rec_sign")); HCHECK(h, h->alloc(&h->rec_len, 2 * cap, "rec_len"));
+        h->rec_cap = cap;
+    }
+    // wire buffers: send = one shard, recv = all shards (padded to equal size), + the ordered copy for the host
+    const size_t wire = (size_t)std::max(per_world, n_global) * sizeof(PairRecord);
+    if (wire > h->rec_wire_cap) {
+        HCHECK(h, h->release(h->rec_send)); HCHECK(h, h->release(h->rec_recv));
+        HCHECK(h, h->alloc(&h->rec_send, wire, "rec_send")); HCHECK(h, h->alloc(&h->rec_recv, 2 * wire, "rec_recv"));
+        h->rec_wire_cap = wire;
+    }
+    // scratch for processed returns [2N] + raw copy [2N] + weights [N]
+    if ((size_t)5 * n_global + 64 > h->scratch_cap) {
+        HCHECK(h, h->release(h->scratch_f)); HCHECK(h, h->release(h->scratch_i));
+        h->scratch_cap = (size_t)5 * n_global + 64;
+        HCHECK(h, h->alloc(&h->scratch_f, h->scratch_cap, "scratch_f")); HCHECK(h, h->alloc(&h->scratch_i, h->scratch_cap, "scratch_i"));
+    }
+    return 0;
+}
+
+struct Rccl {   // the few entry points of librccl.so the exchange needs
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    const char *(*GetErrorString)(ncclResult_t);
+    void *lib = nullptr;
+};
+static Rccl g_rccl;
+
+static const char *rccl_open() {   // nullptr on success, else the reason
+    if (g_rccl.lib) return nullptr;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return dlerror();
+#define SYM(field, name) do { *(void **)&g_rccl.field = dlsym(lib, name); if (!g_rccl.field) return "librccl.so.1 lacks " name; } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    g_rccl.lib = lib;
+    return nullptr;
+}
+#define NCHECK(h, expr)                                                                                   \
+    do {                                                                                                  \
+        ncclResult_t _r = (expr);                                                                         \
+        if (_r != ncclSuccess) return (h)->fail("%s:%d %s -> %s", __FILE__, __LINE__, #expr, g_rccl.GetErrorString(_r)); \
+    } while (0)
+
+extern "C" int dne_comm_unique_id(void *out128) {
+    if (const char *why = rccl_open()) { g_create_error = std::string("dne_comm_unique_id: cannot open librccl.so.1: ") + why; return -1; }
+    ncclUniqueId id;
+    const ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return -1; }
+    memcpy(out128, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" int dne_comm_init(dne_handle *h, int rank, int nranks, const void *unique_id128) {
+    DeviceGuard dg(h);
+    if (nranks < 1 || rank < 0 || rank >= nranks) return h->fail("dne_comm_init: rank %d of %d", rank, nranks);
+    if (h->comm) return h->fail("dne_comm_init: communicator already initialised");
+    if (const char *why = rccl_open()) return h->fail("dne_comm_init: cannot open librccl.so.1: %s", why);
+    ncclUniqueId id;
+    memcpy(&id, unique_id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    h->trace("comm init: rank %d of %d", rank, nranks);
+    NCHECK(h, g_rccl.CommInitRank(&c, nranks, id, rank));
+    h->comm = c; h->comm_rank = rank; h->comm_size = nranks;
+    HCHECK(h, h->alloc(&h->comm_scratch, 64, "comm_scratch"));
+    h->trace("comm ready");
+    return 0;
+}
+
+static void comm_destroy(dne_handle *h) {
+    if (h->comm) { g_rccl.CommDestroy((ncclComm_t)h->comm); h->comm = nullptr; }
+}
+
+// element-wise sum (op 0) or max (op 1) of n <= 64 doubles over all ranks; with n = 0 it is the barrier of bench.py
+extern "C" int dne_comm_allreduce(dne_handle *h, double *inout, int n, int op) {
+    DeviceGuard dg(h);
+    if (n < 0 || n > 64 || (op != 0 && op != 1)) return h->fail("dne_comm_allreduce: bad arguments");
+    if (!h->comm) {   // a single rank: nothing to combine
+        HCHECK(h, hipDeviceSynchronize());
+        return 0;
+    }
+    const int cnt = std::max(n, 1);
+    double zero = 0.0;
+    HCHECK(h, hipMemcpyAsync(h->comm_scratch, n ? inout : &zero, cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    NCHECK(h, g_rccl.AllReduce(h->comm_scratch, h->comm_scratch, cnt, ncclDouble, op == 0 ? ncclSum : ncclMax, (ncclComm_t)h->comm, h->stream));
+    if (n) HCHECK(h, hipMemcpyAsync(inout, h->comm_scratch, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    HCHECK(h, hipDeviceSynchronize());
+    return 0;
+}
+
+// generic small all-gather (the GA's child records, ga.py:266-271 Results): every rank contributes `bytes` bytes from the
+// host and receives nranks * bytes in rank order; staged through the wire buffers, RCCL on the engine's stream
+extern "C" int dne_comm_allgather(dne_handle *h, const void *send, size_t bytes, void *recv) {
+    DeviceGuard dg(h);
+    if (!bytes) return 0;
+    if (!h->comm) { memcpy(recv, send, bytes); return 0; }
+    const size_t world = (size_t)h->comm_size;
+    const int as_pairs = (int)((bytes * world + sizeof(PairRecord) - 1) / sizeof(PairRecord));
+    if (rec_reserve(h, 1, as_pairs)) return -1;   // wire buffers: send >= bytes, recv >= world * bytes
+    HCHECK(h, hipMemcpyAsync(h->rec_send, send, bytes, hipMemcpyHostToDevice, h->stream));
+    NCHECK(h, g_rccl.AllGather(h->rec_send, h->rec_recv, bytes, ncclChar, (ncclComm_t)h->comm, h->stream));
+    HCHECK(h, hipMemcpyAsync(recv, h->rec_recv, bytes * world, hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int check_records_host(dne_handle *h, int n_global) {
+    for (int i = 0; i < n_global; i++)
+        if (check_noise_range(h, h->rec_idx_host[i], h->L.P)) return -1;
+    return 0;
+}
+
+// this rank's shard of the last dne_es_eval as wire records (for transports other than RCCL: the redis Result path,
+// the gloo tests)
+extern "C" int dne_records_pack(dne_handle *h, int n_local, void *records_out) {
+    DeviceGuard dg(h);
+    if (h->L.kind != DNE_KIND_ES || n_local < 1 || 2 * n_local > h->M) return h->fail("dne_records_pack: %d pairs", n_local);
+    if (rec_reserve(h, n_local, n_local)) return -1;
+    hipLaunchKernelGGL(k_records_pack, dim3((n_local + 255) / 256), dim3(256), 0, h->stream, (const int64_t *)h->m_off, (const float *)h->ret,
+                       (const float *)h->sign, (const int32_t *)h->len, n_local, n_local, (PairRecord *)h->rec_send);
+    HCHECK(h, hipGetLastError());
+    HCHECK(h, hipMemcpyAsync(records_out, h->rec_send, (size_t)n_local * sizeof(PairRecord), hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// gathered records from the host (global pair order) -> device-resident, ready for dne_es_update_gathered
+extern "C" int dne_records_set(dne_handle *h, const void *records, int n_global) {
+    DeviceGuard dg(h);
+    if (n_global < 1) return h->fail("dne_records_set: %d pairs", n_global);
+    if (rec_reserve(h, n_global, n_global)) return -1;
+    HCHECK(h, hipMemcpyAsync(h->rec_recv, records, (size_t)n_global * sizeof(PairRecord), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_records_unpack, dim3((n_global + 255) / 256), dim3(256), 0, h->stream, (const PairRecord *)h->rec_recv, n_global, 1,
+                       n_global, h->rec_idx, h->rec_ret, h->rec_sign, h->rec_len, (PairRecord *)nullptr);
+    HCHECK(h, hipGetLastError());
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    const PairRecord *r = (const PairRecord *)records;
+    h->rec_idx_host.resize(n_global);
+    for (int i = 0; i < n_global; i++) h->rec_idx_host[i] = r[i].noise_idx;
+    h->rec_n = n_global;
+    return check_records_host(h, n_global);
+}
+
+// The exchange step of a generation: every rank contributes the records of the n_local pairs it just evaluated
+// (global pairs rank, rank + world, ...) straight from its device accumulators; one RCCL all-gather over xGMI; the
+// result stays on the device in global pair order.  records_out (n_global x 32 bytes, may be NULL) receives a host copy
+// for logging.  Without a communicator (one GPU) it is a local repack.
+extern "C" int dne_allgather_results(dne_handle *h, int n_local, int n_global, void *records_out) {
+    DeviceGuard dg(h);
+    const int world = h->comm ? h->comm_size : 1, rank = h->comm ? h->comm_rank : 0;
+    if (h->L.kind != DNE_KIND_ES) return h->fail("dne_allgather_results needs an ESAtariPolicy engine");
+    const int mine = n_global > rank ? (n_global - rank + world - 1) / world : 0;
+    if (n_global < 1 || n_local != mine || 2 * n_local > h->M)
+        return h->fail("dne_allgather_results: rank %d of %d holds %d pairs, a population of %d pairs gives it %d", rank, world, n_local, n_global, mine);
+    const int per = (n_global + world - 1) / world;
+    if (rec_reserve(h, n_global, per * world)) return -1;
+    hipLaunchKernelGGL(k_records_pack, dim3((per + 255) / 256), dim3(256), 0, h->stream, (const int64_t *)h->m_off, (const float *)h->ret,
+                       (const float *)h->sign, (const int32_t *)h->len, n_local, per, (PairRecord *)h->rec_send);
+    PairRecord *gathered = (PairRecord *)h->rec_recv, *ordered = gathered + (size_t)per * world;
+    if (world > 1) NCHECK(h, g_rccl.AllGather(h->rec_send, gathered, (size_t)per * sizeof(PairRecord), ncclChar, (ncclComm_t)h->comm, h->stream));
+    else HCHECK(h, hipMemcpyAsync(gathered, h->rec_send, (size_t)per * sizeof(PairRecord), hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_records_unpack, dim3((n_global + 255) / 256), dim3(256), 0, h->stream, (const PairRecord *)gathered, n_global, world,
+                       per, h->rec_idx, h->rec_ret, h->rec_sign, h->rec_len, ordered);
+    HCHECK(h, hipGetLastError());
+    std::vector<PairRecord> host(n_global);
+    HCHECK(h, hipMemcpyAsync(host.data(), ordered, (size_t)n_global * sizeof(PairRecord), hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    h->rec_idx_host.resize(n_global);
+    for (int i = 0; i < n_global; i++) h->rec_idx_host[i] = host[i].noise_idx;
+    h->rec_n = n_global;
+    if (records_out) memcpy(records_out, host.data(), (size_t)n_global * sizeof(PairRecord));
+    return check_records_host(h, n_global);
+}
+
+// es.py:281-298 on the gathered, device-resident records: process returns, aggregate, optimizer step
+extern "C" int dne_es_update_gathered(dne_handle *h, int proc_mode, int opt_kind, float l2, double stepsize, double b1m, double b2,
+                                      double eps, double *ratio) {
+    DeviceGuard dg(h);
+    const int n = h->rec_n, n2 = 2 * n;
+    if (n < 1) return h->fail("dne_es_update_gathered: no gathered records (dne_allgather_results / dne_records_set first)");
+    float *proc = h->scratch_f, *w = h->scratch_f + n2;
     if (proc_mode == DNE_PROC_CENTERED_RANK) {          // es.py:281-282
-        HCHECK(h, hipMemcpyAsync(x, returns_n2, n2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_centered_ranks, dim3((n2 + 255) / 256), dim3(256), 0, h->stream, (const float *)x, n2, proc);
+        hipLaunchKernelGGL(k_centered_ranks, dim3((n2 + 255) / 256), dim3(256), 0, h->stream, (const float *)h->rec_ret, n2, proc);
     } else if (proc_mode == DNE_PROC_SIGN) {            // es.py:283-284
-        if (!signreturns_n2) return h->fail("sign mode needs signreturns_n2");
-        HCHECK(h, hipMemcpyAsync(proc, signreturns_n2, n2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HCHECK(h, hipMemcpyAsync(proc, h->rec_sign, n2 * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     } else if (proc_mode == DNE_PROC_CENTERED_SIGN_RANK) {   // es.py:285-286
-        if (!signreturns_n2) return h->fail("centered_sign_rank mode needs signreturns_n2");
-        HCHECK(h, hipMemcpyAsync(x, signreturns_n2, n2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_centered_ranks, dim3((n2 + 255) / 256), dim3(256), 0, h->stream, (const float *)x, n2, proc);
+        hipLaunchKernelGGL(k_centered_ranks, dim3((n2 + 255) / 256), dim3(256), 0, h->stream, (const float *)h->rec_sign, n2, proc);
     } else {
         return h->fail("unknown return_proc_mode %d", proc_mode);
     }
     hipLaunchKernelGGL(k_pair_weights, dim3((n + 255) / 256), dim3(256), 0, h->stream, (const float *)proc, n, w);
-    if (weighted_sum_dev(h, idx, w, n, (float)n2)) return -1;   // es.py:296 g /= returns_n2.size
+    HCHECK(h, hipEventRecord(h->ev_a, h->stream));
+    hipLaunchKernelGGL(k_weighted_sum, dim3((h->L.P + 255) / 256), dim3(256), 0, h->stream, (const float *)h->noise,
+                       (const int64_t *)h->rec_idx, (const float *)w, n, h->L.P, (float)n2, h->g);   // es.py:296 g /= returns_n2.size
+    HCHECK(h, hipEventRecord(h->ev_b, h->stream));
+    HCHECK(h, hipGetLastError());
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    float ms = 0;
+    HCHECK(h, hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    h->prof.reduce_ms = ms;
     return dne_optimizer_step(h, opt_kind, l2, stepsize, b1m, b2, eps, ratio);
 }
 
+extern "C" int dne_es_update(dne_handle *h, const int64_t *idx, const float *returns_n2, const float *signreturns_n2, int n,
+                             int proc_mode, int opt_kind, float l2, double stepsize, double b1m, double b2, double eps,
+                             double *ratio) {
+    DeviceGuard dg(h);
+    if (n < 1) return h->fail("dne_es_update: n = %d unsupported", n);
+    if (proc_mode != DNE_PROC_CENTERED_RANK && !signreturns_n2) return h->fail("this return_proc_mode needs signreturns_n2");
+    std::vector<PairRecord> rec(n);
+    for (int i = 0; i < n; i++) {
+        rec[i].noise_idx = idx[i];
+        rec[i].ret[0] = returns_n2[2 * i]; rec[i].ret[1] = returns_n2[2 * i + 1];
+        rec[i].len[0] = rec[i].len[1] = 0;
+        rec[i].sign[0] = signreturns_n2 ? signreturns_n2[2 * i] : 0.0f; rec[i].sign[1] = signreturns_n2 ? signreturns_n2[2 * i + 1] : 0.0f;
+    }
+    if (dne_records_set(h, rec.data(), n)) return -1;
+    return dne_es_update_gathered(h, proc_mode, opt_kind, l2, stepsize, b1m, b2, eps, ratio);
+}
+
 extern "C" int dne_ga_select(dne_handle *h, const float *returns, int m, int t, int32_t *out_idx) {
-    if (m < 1 || t < 1 || t > m || (size_t)2 * m > h->scratch_cap) return h->fail("dne_ga_select: bad sizes m = %d t = %d", m, t);
+    DeviceGuard dg(h);
+    if (m < 1 || t < 1 || t > m) return h->fail("dne_ga_select: bad sizes m = %d t = %d", m, t);
+    if (rec_reserve(h, m, 1)) return -1;
     HCHECK(h, hipMemcpyAsync(h->scratch_f, returns, m * sizeof(float), hipMemcpyHostToDevice, h->stream));
     int32_t *out = (int32_t *)(h->scratch_f + m);
     hipLaunchKernelGGL(k_ga_select, dim3((m + 255) / 256), dim3(256), 0, h->stream, (const float *)h->scratch_f, m, t, out);
@@ -1324,6 +1759,7 @@ extern "C" int dne_ga_select(dne_handle *h, const float *returns, int m, int t, 
 
 extern "C" int dne_novelty(dne_handle *h, const uint8_t *archive, const int32_t *alen, int narch, const uint8_t *bc,
                            int bc_len, int dim, int k, double *out) {
+    DeviceGuard dg(h);
     if (narch < 1 || bc_len < 1 || dim < 1 || k < 1) return h->fail("dne_novelty: bad sizes");
     std::vector<int64_t> row0(narch);
     int64_t rows = 0;
@@ -1356,6 +1792,7 @@ extern "C" int dne_novelty(dne_handle *h, const uint8_t *archive, const int32_t 
 
 extern "C" int dne_novelty_batch(dne_handle *h, const uint8_t *archive, const int32_t *alen, int narch, int n,
                                  const int32_t *lengths, int k, double *out) {
+    DeviceGuard dg(h);
     if (h->L.kind != DNE_KIND_ES || !h->bc) return h->fail("dne_novelty_batch needs an ES engine created with record_bc = 1");
     if (check_n(h, n)) return -1;
     if (narch < 1 || k < 1) return h->fail("dne_novelty_batch: bad sizes");

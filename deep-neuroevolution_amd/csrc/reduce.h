@@ -39,6 +39,45 @@ __global__ void k_average2(const float *__restrict__ a, const float *__restrict_
     if (i < n) { float s = a[i] + b[i]; out[i] = s / 2.0f; }
 }
 
+// The per-pair record that travels between GPUs: what a worker's Result carries per antithetic pair
+// (es.py:18-23: noise_inds_n, returns_n2, lengths_n2, signreturns_n2), 32 bytes.
+struct PairRecord {
+    int64_t noise_idx;
+    float ret[2];
+    int32_t len[2];
+    float sign[2];
+};
+static_assert(sizeof(PairRecord) == 32, "wire record is 32 bytes");
+
+// this rank's shard of the last evaluation -> `per` wire records (the tail past n_local is zero)
+__global__ void k_records_pack(const int64_t *__restrict__ m_off, const float *__restrict__ ret, const float *__restrict__ sign,
+                               const int32_t *__restrict__ len, int n_local, int per, PairRecord *__restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= per) return;
+    PairRecord r{};
+    if (j < n_local) {
+        r.noise_idx = m_off[2 * j];
+        r.ret[0] = ret[2 * j]; r.ret[1] = ret[2 * j + 1];
+        r.len[0] = len[2 * j]; r.len[1] = len[2 * j + 1];
+        r.sign[0] = sign[2 * j]; r.sign[1] = sign[2 * j + 1];
+    }
+    out[j] = r;
+}
+
+// gathered [world][per] records -> arrays in global pair order (pair i was evaluated by rank i % world as its (i / world)-th)
+__global__ void k_records_unpack(const PairRecord *__restrict__ in, int n_global, int world, int per, int64_t *__restrict__ idx,
+                                 float *__restrict__ ret, float *__restrict__ sign, int32_t *__restrict__ len,
+                                 PairRecord *__restrict__ ordered) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_global) return;
+    const PairRecord r = in[(size_t)(i % world) * per + i / world];
+    idx[i] = r.noise_idx;
+    ret[2 * i] = r.ret[0]; ret[2 * i + 1] = r.ret[1];
+    sign[2 * i] = r.sign[0]; sign[2 * i + 1] = r.sign[1];
+    len[2 * i] = r.len[0]; len[2 * i + 1] = r.len[1];
+    if (ordered) ordered[i] = r;
+}
+
 // es.py:291-296: g[p] = (sum_i w_i * noise[idx_i + p]) / denom as an i-ordered fmaf chain per parameter.
 // Every noise slice is read exactly once: N * 4P bytes of coalesced HBM gathers.
 __global__ __launch_bounds__(256) void k_weighted_sum(const float *__restrict__ noise, const int64_t *__restrict__ idx,

@@ -26,6 +26,20 @@ class DneError(RuntimeError):
     pass
 
 
+# one (noise_idx, returns, lengths, sign-returns) record per antithetic pair -- what travels between GPUs;
+# the layout of struct PairRecord in csrc/reduce.h
+RECORD = np.dtype([('noise_idx', '<i8'), ('ret', '<f4', (2,)), ('len', '<i4', (2,)), ('aux', '<f4', (2,))])
+assert RECORD.itemsize == 32
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C ABI (rank 0 calls it and hands the 128 bytes to every rank)"""
+    buf = (C.c_char * 128)()
+    if load().dne_comm_unique_id(buf) != 0:
+        raise DneError(load().dne_last_error(None).decode())
+    return bytes(buf.raw)
+
+
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("device_id", "policy_kind", "n_actions", "max_members", "ref_count",
                                          "ref_chunk", "record_bc", "bc_max_steps", "profile_events")] + \
@@ -96,6 +110,7 @@ class Engine:
             raise DneError(self.lib.dne_last_error(None).decode())
         self.P = self.lib.dne_num_params(self.kind, self.n_actions)
         self.noise_count = 0
+        self.comm_size = 1
 
     def close(self):
         if getattr(self, "h", None):
@@ -117,6 +132,21 @@ class Engine:
         noise = _arr(noise, np.float32)
         self._ck(self.lib.dne_noise_upload(self.h, _ptr(noise, C.c_float), C.c_size_t(noise.size)))
         self.noise_count = noise.size
+
+    def noise_alloc(self, count):
+        self._ck(self.lib.dne_noise_alloc(self.h, C.c_size_t(int(count))))
+        self.noise_count = int(count)
+
+    def noise_write(self, offset, chunk):
+        chunk = _arr(chunk, np.float32)
+        self._ck(self.lib.dne_noise_write(self.h, C.c_size_t(int(offset)), _ptr(chunk, C.c_float), C.c_size_t(chunk.size)))
+
+    def check_redzones(self):
+        """0 = no kernel wrote outside its device buffer; raises with the buffer's name otherwise"""
+        rc = self.lib.dne_check_redzones(self.h)
+        if rc != 0:
+            raise DneError(self.lib.dne_last_error(self.h).decode())
+        return 0
 
     def noise_get(self, idx, dim):
         out = np.empty(dim, np.float32)
@@ -285,6 +315,51 @@ class Engine:
         self._ck(self.lib.dne_es_update(self.h, _ptr(idx, C.c_int64), _ptr(r, C.c_float), _ptr(s, C.c_float), int(idx.size),
                                         PROC_MODES[proc_mode], OPT_KINDS[opt_kind], C.c_float(l2coeff), C.c_double(stepsize),
                                         C.c_double(beta1_or_momentum), C.c_double(beta2), C.c_double(epsilon), C.byref(ratio)))
+        return ratio.value
+
+    # ---- exchange between GPUs (RCCL behind the C ABI; the host transports use pack / set)
+    def comm_init(self, rank, nranks, unique_id):
+        assert len(unique_id) == 128
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        self._ck(self.lib.dne_comm_init(self.h, int(rank), int(nranks), buf))
+        self.comm_size = int(nranks)
+
+    def comm_allreduce(self, values, op="sum"):
+        v = np.array(values, np.float64).reshape(-1)
+        self._ck(self.lib.dne_comm_allreduce(self.h, _ptr(v, C.c_double), int(v.size), {"sum": 0, "max": 1}[op]))
+        return v
+
+    def barrier(self):
+        self._ck(self.lib.dne_comm_allreduce(self.h, None, 0, 0))
+
+    def comm_allgather(self, arr):
+        """every rank's `arr` (same shape and dtype everywhere) stacked in rank order"""
+        arr = np.ascontiguousarray(arr)
+        world = self.comm_size
+        out = np.empty((world,) + arr.shape, arr.dtype)
+        self._ck(self.lib.dne_comm_allgather(self.h, arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes),
+                                             out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def allgather_results(self, n_local, n_global):
+        rec = np.zeros(int(n_global), RECORD)
+        self._ck(self.lib.dne_allgather_results(self.h, int(n_local), int(n_global), rec.ctypes.data_as(C.c_void_p)))
+        return rec
+
+    def records_pack(self, n_local):
+        rec = np.zeros(int(n_local), RECORD)
+        self._ck(self.lib.dne_records_pack(self.h, int(n_local), rec.ctypes.data_as(C.c_void_p)))
+        return rec
+
+    def records_set(self, rec):
+        rec = np.ascontiguousarray(rec, RECORD)
+        self._ck(self.lib.dne_records_set(self.h, rec.ctypes.data_as(C.c_void_p), int(rec.size)))
+
+    def es_update_gathered(self, proc_mode, opt_kind, l2coeff, stepsize, beta1_or_momentum=0.9, beta2=0.999, epsilon=1e-8):
+        ratio = C.c_double()
+        self._ck(self.lib.dne_es_update_gathered(self.h, PROC_MODES[proc_mode], OPT_KINDS[opt_kind], C.c_float(l2coeff),
+                                                 C.c_double(stepsize), C.c_double(beta1_or_momentum), C.c_double(beta2),
+                                                 C.c_double(epsilon), C.byref(ratio)))
         return ratio.value
 
     def ga_select(self, returns, t):

@@ -32,9 +32,8 @@ Result = namedtuple('Result', [
     'ob_sum', 'ob_sumsq', 'ob_count'
 ])
 
-# one (noise_idx, returns, lengths, aux) record per antithetic pair -- what travels between GPUs
-RECORD = np.dtype([('noise_idx', '<i8'), ('ret', '<f4', (2,)), ('len', '<i4', (2,)), ('aux', '<f4', (2,))])
-assert RECORD.itemsize == 32
+# one (noise_idx, returns, lengths, sign-returns) record per antithetic pair -- what travels between GPUs
+RECORD = _lib.RECORD
 
 
 class SharedNoiseTable(object):
@@ -87,7 +86,7 @@ def parse_cutoff(mode):
         _, args = mode.split(':')
         a0, a1, a2, a3 = args.split(',')
         return int(a0), float(a1), float(a2), float(a3), True
-    if mode == 'env_default':
+    if mode == 'env_default':   # es.py:184-185: no task limit; the environment's own TimeLimit applies (policies.py:383-385)
         return None, None, None, None, False
     raise NotImplementedError(mode)
 
@@ -119,9 +118,9 @@ def pack_records(idx, returns_n2, lengths_n2, aux_n2):
 
 
 def allgather_records(rec, n_pairs, rank, world, device=None):
-    """The one exchange step of a generation: every rank contributes its shard's 32-byte records and gets
-    all N back in global pair order.  torch.distributed all_gather ('nccl' = RCCL over xGMI on GPU tensors,
-    'gloo' on CPU for the tests); world == 1 is a no-op."""
+    """Host transport of the exchange step (the CPU tests' gloo path, or any torch.distributed backend a deployment
+    already has): every rank contributes its shard's 32-byte records and gets all N back in global pair order.
+    On MI355X nodes the exchange is Engine.allgather_results instead -- RCCL behind the C ABI, device to device."""
     if world == 1:
         return rec
     import torch
@@ -142,16 +141,22 @@ def allgather_records(rec, n_pairs, rank, world, device=None):
     return full
 
 
-def es_generation(engine, noise_len, config, n_pairs, generation, tslimit, optimizer, rank=0, world=1, device=None):
+def es_generation(engine, noise_len, config, n_pairs, generation, tslimit, optimizer, rank=0, world=1, transport=None):
     """One ES generation on this rank's shard + the redundant update (es.py:411-426 + 274-301).
     optimizer: dict(type='adam'|'sgd', args=dict(stepsize=..., ...)) as in the experiment JSON.
-    Returns (records[N], update_ratio)."""
+    The records never leave the device on the default path: dne_allgather_results packs them from the evaluation's
+    accumulators, all-gathers them over RCCL (engine.comm_init beforehand when world > 1) and dne_es_update_gathered
+    consumes the gathered buffer.  transport(rec, n_pairs, rank, world) -> all records is the host alternative
+    (allgather_records over gloo in the CPU tests).  Returns (records[N], update_ratio)."""
     P = engine.P
     mine, idx, seeds = generation_inputs(noise_len, P, n_pairs, generation, rank, world)
-    ret, sg, ln = engine.es_eval(idx, config.noise_stdev, tslimit, seeds)
-    rec = allgather_records(pack_records(idx, ret, ln, sg), n_pairs, rank, world, device)
-    ratio = engine.es_update(rec['noise_idx'], rec['ret'], rec['aux'], config.return_proc_mode, optimizer['type'],
-                             config.l2coeff, *optimizer_args(optimizer))
+    engine.es_eval(idx, config.noise_stdev, tslimit, seeds)
+    if transport is None:
+        rec = engine.allgather_results(len(mine), n_pairs)
+    else:
+        rec = transport(engine.records_pack(len(mine)), n_pairs, rank, world)
+        engine.records_set(rec)
+    ratio = engine.es_update_gathered(config.return_proc_mode, optimizer['type'], config.l2coeff, *optimizer_args(optimizer))
     return rec, ratio
 
 
@@ -296,8 +301,40 @@ def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_i
     return policy
 
 
+class TaskPacer:
+    """Worker-side pacing.  The reference's CPU workers loop without pause, a few episodes per Result (es.py:377-439),
+    so the master's collection loop (es.py:230-265: until episodes_per_batch AND timesteps_per_batch) always ends.  A
+    GPU worker delivers its whole shard in one Result; if the master has still not declared a new task `reeval_after`
+    seconds later it evidently needs more (odd episodes_per_batch, short episodes vs. timesteps_per_batch), and the
+    worker evaluates another shard with fresh indices instead of sleeping forever.  max_tasks (tests) counts distinct
+    task ids that received at least one Result."""
+
+    def __init__(self, worker, max_tasks=None, reeval_after=1.0):
+        self.worker, self.max_tasks, self.reeval_after = worker, max_tasks, reeval_after
+        self.last_task, self.pushed_at, self.distinct = None, 0.0, 0
+
+    def next_task(self):
+        """-> (task_id, task_data), or None when max_tasks distinct tasks have been served"""
+        while True:
+            task_id, task_data = self.worker.get_current_task()
+            if task_id != self.last_task:
+                if self.max_tasks is not None and self.distinct >= self.max_tasks:
+                    return None
+                return task_id, task_data
+            if self.max_tasks is not None and self.distinct >= self.max_tasks:
+                return None
+            if time.time() - self.pushed_at >= self.reeval_after:
+                return task_id, task_data
+            time.sleep(0.001)
+
+    def pushed(self, task_id):
+        if task_id != self.last_task:
+            self.distinct += 1
+        self.last_task, self.pushed_at = task_id, time.time()
+
+
 def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2, engine=None, max_tasks=None,
-               seed=None, rank=0, world=1):
+               seed=None, rank=0, world=1, reeval_after=1.0):
     """es.py:366-439 for one GPU: per task, evaluate this worker's whole shard of antithetic pairs in one
     device call and push one Result with n pairs (exactly episodes_per_batch/2 pairs per
     generation across the `world` GPU workers).  min_task_runtime is accepted for signature parity."""
@@ -312,13 +349,12 @@ def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2,
     worker_id = rs.randint(2 ** 31)
     assert policy.needs_ob_stat == (config.calc_obstat_prob != 0)
     n_pairs = max(config.episodes_per_batch // 2, 1)
-    done_tasks, last_task = 0, None
-    while max_tasks is None or done_tasks < max_tasks:
-        task_id, task_data = worker.get_current_task()
-        if task_id == last_task:   # one shard per task: wait for the next declaration instead of re-evaluating
-            time.sleep(0.001)
-            continue
-        last_task = task_id
+    pacer = TaskPacer(worker, max_tasks, reeval_after)
+    while True:
+        nxt = pacer.next_task()
+        if nxt is None:
+            break
+        task_id, task_data = nxt
         assert isinstance(task_id, int) and isinstance(task_data, Task)
         if policy.needs_ref_batch:
             policy.set_ref_batch(task_data.ref_batch)
@@ -326,9 +362,10 @@ def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2,
         tslimit = task_data.timestep_limit
         tslimit = _lib.ENV_MAX_EPISODE_STEPS if tslimit is None else min(tslimit, _lib.ENV_MAX_EPISODE_STEPS)
         if rs.rand() < config.eval_prob:
-            # es.py:388-405: noiseless weights, reported separately, never part of the update
+            # es.py:388-405: noiseless weights, reported separately, never part of the update; "eval rollouts don't obey
+            # task_data.timestep_limit" (es.py:391) -- only the environment's own limit applies
             engine.set_members(np.zeros(1, np.int32), np.zeros(1, np.int64), np.zeros(1, np.float32))
-            er, _, el = engine.eval_members(1, tslimit, rs.randint(0, 2 ** 32, size=1, dtype=np.uint64).astype(np.uint32))
+            er, _, el = engine.eval_members(1, _lib.ENV_MAX_EPISODE_STEPS, rs.randint(0, 2 ** 32, size=1, dtype=np.uint64).astype(np.uint32))
             worker.push_result(task_id, Result(worker_id=worker_id, noise_inds_n=None, returns_n2=None,
                                                signreturns_n2=None, lengths_n2=None, eval_return=float(er[0]),
                                                eval_length=int(el[0]), ob_sum=None, ob_sumsq=None, ob_count=None))
@@ -339,4 +376,4 @@ def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2,
         worker.push_result(task_id, Result(
             worker_id=worker_id, noise_inds_n=noise_inds, returns_n2=returns, signreturns_n2=signreturns,
             lengths_n2=lengths, eval_return=None, eval_length=None, ob_sum=None, ob_sumsq=None, ob_count=0))
-        done_tasks += 1
+        pacer.pushed(task_id)

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from .dist import MasterClient, WorkerClient
-from .es import Config, Result, SharedNoiseTable, collect_batch, log_generation, namedtuple, parse_cutoff  # noqa: F401
+from .es import Config, Result, SharedNoiseTable, TaskPacer, collect_batch, log_generation, namedtuple, parse_cutoff  # noqa: F401
 
 logger = logging.getLogger(__name__)
 
@@ -97,11 +97,32 @@ def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_i
     return policy, population, population_score
 
 
-def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2, engine=None, max_tasks=None, seed=None):
-    """ga.py:209-284 for one GPU: all episodes_per_batch children of a task in one device call."""
+def shard_children(n_children, rank, world):
+    """children of a generation owned by `rank`: round-robin like es.shard_pairs"""
+    return np.arange(rank, n_children, world, dtype=np.int64)
+
+
+def make_children(population, n, noise, rs, num_params):
+    """ga.py:251-254: a random parent's chain + one fresh index (generation 0: a single fresh index)"""
+    chains = []
+    for _ in range(n):
+        if len(population) > 0:
+            seeds = list(population[rs.randint(len(population))]) + [noise.sample_index(rs, num_params)]
+        else:
+            seeds = [noise.sample_index(rs, num_params)]
+        chains.append(seeds)
+    return chains
+
+
+def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2, engine=None, max_tasks=None, seed=None,
+               rank=0, world=1, reeval_after=1.0):
+    """ga.py:209-284 for one GPU: this worker's share (children rank, rank + world, ...) of the episodes_per_batch children
+    of a task in one device call.  The reference constructs WorkerClient(master_redis_cfg, relay_redis_cfg) -- its
+    arguments swapped against the class's (relay, master) order (ga.py:212); with distinct master / relay
+    configurations that attaches the worker to the wrong server, so the order is put right here."""
     logger.info('run_worker: {}'.format(locals()))
     assert isinstance(noise, SharedNoiseTable)
-    worker = WorkerClient(master_redis_cfg, relay_redis_cfg)   # reference quirk Q3: arguments swapped in ga.py:212
+    worker = WorkerClient(relay_redis_cfg, master_redis_cfg)
     exp = worker.get_experiment()
     config, env, policy = setup(exp, engine=engine)
     engine = policy.engine
@@ -109,27 +130,78 @@ def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2,
     rs = np.random.RandomState(seed)
     worker_id = rs.randint(2 ** 31)
     assert policy.needs_ob_stat == (config.calc_obstat_prob != 0)
-    n = max(config.episodes_per_batch, 1)
-    done_tasks, last_task = 0, None
-    while max_tasks is None or done_tasks < max_tasks:
-        task_id, task_data = worker.get_current_task()
-        if task_id == last_task:
-            time.sleep(0.001)
-            continue
-        last_task = task_id
+    n = len(shard_children(max(config.episodes_per_batch, 1), rank, world))
+    pacer = TaskPacer(worker, max_tasks, reeval_after)
+    while True:
+        nxt = pacer.next_task()
+        if nxt is None:
+            break
+        task_id, task_data = nxt
         assert isinstance(task_id, int) and isinstance(task_data, GATask)
         tslimit = task_data.timestep_limit
         tslimit = _lib.ENV_MAX_EPISODE_STEPS if tslimit is None else min(tslimit, _lib.ENV_MAX_EPISODE_STEPS)
-        chains = []
-        for _ in range(n):   # ga.py:251-254
-            if len(task_data.population) > 0:
-                seeds = list(task_data.population[rs.randint(len(task_data.population))]) + [noise.sample_index(rs, policy.num_params)]
-            else:
-                seeds = [noise.sample_index(rs, policy.num_params)]
-            chains.append(seeds)
+        if rs.rand() < config.eval_prob:
+            # ga.py:226-245: one episode of the current elite (task_data.params), no task timestep limit, reported apart.
+            # (The reference unpacks policy.rollout's three return values into two names there and would raise; this is
+            # the branch as intended -- SURVEY Q2.)
+            policy.set_trainable_flat(task_data.params)
+            engine.set_members(np.zeros(1, np.int32), np.zeros(1, np.int64), np.zeros(1, np.float32))
+            er, _, el = engine.eval_members(1, _lib.ENV_MAX_EPISODE_STEPS, rs.randint(0, 2 ** 32, size=1, dtype=np.uint64).astype(np.uint32))
+            worker.push_result(task_id, Result(worker_id=worker_id, noise_inds_n=None, returns_n2=None, signreturns_n2=None,
+                                               lengths_n2=None, eval_return=float(er[0]), eval_length=int(el[0]),
+                                               ob_sum=None, ob_sumsq=None, ob_count=None))
+        chains = make_children(task_data.population, n, noise, rs, policy.num_params)
         env_seeds = rs.randint(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
         returns, signreturns, lengths = engine.ga_eval(chains, config.noise_stdev, tslimit, env_seeds)
         worker.push_result(task_id, Result(
             worker_id=worker_id, noise_inds_n=chains, returns_n2=returns, signreturns_n2=signreturns,
             lengths_n2=lengths, eval_return=None, eval_length=None, ob_sum=None, ob_sumsq=None, ob_count=0))
-        done_tasks += 1
+        pacer.pushed(task_id)
+
+
+# ---------------------------------------------------------------------------------------------- co-located GPUs
+# (the GA counterpart of es.es_generation: no broker, every rank keeps the whole population and runs the identical
+#  truncation, so the elites agree on every GPU without a second exchange)
+CHILD_RECORD = np.dtype([('parent', '<i4'), ('len', '<i4'), ('seed', '<i8'), ('ret', '<f4'), ('aux', '<f4'), ('pad', '<i8')])
+assert CHILD_RECORD.itemsize == 32
+
+
+def ga_generation_inputs(noise_len, num_params, n_children, n_parents, generation, rank, world):
+    """Seeded stand-ins for the worker's unseeded stream (ga.py:216,251-254): parent picks and fresh indices from
+    RandomState(generation * world + rank), env seeds from RandomState(1000 + generation) by global child id."""
+    mine = shard_children(n_children, rank, world)
+    rs = np.random.RandomState(generation * world + rank)
+    parent = rs.randint(0, max(n_parents, 1), size=len(mine)).astype(np.int32) if n_parents > 0 else np.full(len(mine), -1, np.int32)
+    fresh = rs.randint(0, noise_len - num_params + 1, size=len(mine)).astype(np.int64)
+    all_seeds = np.random.RandomState(1000 + generation).randint(0, 2 ** 32, size=n_children, dtype=np.uint64).astype(np.uint32)
+    return mine, parent, fresh, all_seeds[mine]
+
+
+def ga_generation(engine, noise_len, sigma, population, scores, n_children, population_size, num_elites, generation, tslimit,
+                  rank=0, world=1, transport=None):
+    """One Deep-GA generation on this rank's share of the children + the redundant truncation (ga.py:251-271 + 136-149).
+    Exchange: 32-byte child records (parent index, fresh seed, return, length), all-gathered over RCCL
+    (engine.comm_allgather) or by `transport` (gloo in the CPU tests).  Returns (population, scores, lengths)."""
+    mine, parent, fresh, env_seeds = ga_generation_inputs(noise_len, engine.P, n_children, len(population), generation, rank, world)
+    chains = [(list(population[p]) if p >= 0 else []) + [int(f)] for p, f in zip(parent, fresh)]
+    ret, sg, ln = engine.ga_eval(chains, sigma, tslimit, env_seeds)
+    rec = np.zeros(len(mine), CHILD_RECORD)
+    rec['parent'], rec['seed'], rec['ret'], rec['len'], rec['aux'] = parent, fresh, ret, ln, sg
+    if world > 1:
+        per = (n_children + world - 1) // world
+        buf = np.zeros(per, CHILD_RECORD)
+        buf[:len(rec)] = rec
+        gathered = (engine.comm_allgather(buf) if transport is None else transport(buf, world)).reshape(world, per)
+        full = np.zeros(n_children, CHILD_RECORD)
+        for r in range(world):
+            ids = shard_children(n_children, r, world)
+            full[ids] = gathered[r, :len(ids)]
+        rec = full
+    # ga.py:136-149: elites keep their old score and are not re-evaluated (Q6); children follow in global child order
+    cand = [list(c) for c in population[:num_elites]]
+    cand_ret = list(scores[:num_elites])
+    for r in rec:
+        cand.append((list(population[r['parent']]) if r['parent'] >= 0 else []) + [int(r['seed'])])
+        cand_ret.append(r['ret'])
+    new_pop, new_scores = truncate(engine, cand, np.array(cand_ret, np.float32), population_size)
+    return new_pop, new_scores, rec['len']

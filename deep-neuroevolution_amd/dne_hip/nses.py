@@ -13,8 +13,8 @@ import numpy as np
 
 from . import _lib
 from .dist import MasterClient, WorkerClient
-from .es import (Config, Result, SharedNoiseTable, Task, collect_batch, get_ref_batch, log_generation, optimizer_args,
-                 parse_cutoff, shard_pairs)
+from .es import (Config, Result, SharedNoiseTable, Task, TaskPacer, collect_batch, get_ref_batch, log_generation,
+                 optimizer_args, parse_cutoff, shard_pairs)
 
 logger = logging.getLogger(__name__)
 
@@ -33,7 +33,14 @@ def get_mean_bc(engine, tslimit, seed, num_rollouts=1):
     return bc[0, :ln[0]].copy()
 
 
+def bc_capacity(tslimit_max):
+    """Steps of RAM trajectory to keep per member.  episode_cutoff_mode 'env_default' has no task limit (es.py:184-185):
+    the environment's own limit (400k raw frames = 100k skip-4 steps) bounds the trajectory."""
+    return int(tslimit_max) if tslimit_max is not None else _lib.ENV_MAX_EPISODE_STEPS // 4
+
+
 def make_engine(exp, n_pairs, tslimit_max, n_actions=18, device_id=0, ref_count=128):
+    tslimit_max = bc_capacity(tslimit_max)
     return _lib.Engine(_lib.KIND_ES, n_actions, max_members=max(2 * n_pairs, 2), ref_count=ref_count, device_id=device_id,
                        record_bc=True, bc_max_steps=int(tslimit_max))
 
@@ -64,7 +71,7 @@ def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_i
     for p in range(pop_size):   # nses.py:95-117
         theta = policies.xavier_flat(policy.num_actions, seed + p)
         policy.set_trainable_flat(theta)
-        master.add_to_novelty_archive(get_mean_bc(engine, int(tslimit_max), rs.randint(2 ** 31), num_rollouts))
+        master.add_to_novelty_archive(get_mean_bc(engine, bc_capacity(tslimit_max), rs.randint(2 ** 31), num_rollouts))
         theta_dict[p] = theta
         optimizer_dict[p] = (np.zeros(P, np.float32), np.zeros(P, np.float32), 0)
     master.declare_experiment(exp)
@@ -96,10 +103,10 @@ def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_i
             proc = ((rew_ranks + proc) / 2.0).astype(np.float32)
         engine.weighted_sum(noise_inds_n, proc[:, 0] - proc[:, 1], float(returns_n2.size), copy_out=False)   # nses.py:231-236
         update_ratio = engine.optimizer_step(opt['type'], config.l2coeff, *optimizer_args(opt))
-        mean_bc = get_mean_bc(engine, int(tslimit_max), rs.randint(2 ** 31), num_rollouts)   # nses.py:246-247
+        mean_bc = get_mean_bc(engine, bc_capacity(tslimit_max), rs.randint(2 ** 31), num_rollouts)   # nses.py:246-247
         master.add_to_novelty_archive(mean_bc)
         if adaptive_tslimit and (lengths_n2 == tslimit).mean() >= incr_tslimit_threshold:
-            tslimit = min(int(tslimit_incr_ratio * tslimit), tslimit_max)
+            tslimit = min(int(tslimit_incr_ratio * tslimit), int(tslimit_max))
         dt = time.time() - step_tstart
         log_generation(tlogger, [
             ("ParentId", curr_parent), ("EpRewMean", returns_n2.mean()), ("EpLenMean", lengths_n2.mean()),
@@ -113,7 +120,7 @@ def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_i
             novelty_probs = []
             for p in range(pop_size):
                 policy.set_trainable_flat(theta_dict[p])
-                bc = get_mean_bc(engine, int(tslimit_max), rs.randint(2 ** 31), num_rollouts)
+                bc = get_mean_bc(engine, bc_capacity(tslimit_max), rs.randint(2 ** 31), num_rollouts)
                 novelty_probs.append(compute_novelty_vs_archive(engine, archive, bc, ns['k']))
             novelty_probs = np.array(novelty_probs) / float(np.sum(novelty_probs))
             curr_parent = rs.choice(range(pop_size), 1, p=novelty_probs)[0]
@@ -125,7 +132,7 @@ def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_i
 
 
 def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2, engine=None, max_tasks=None, seed=None,
-               rank=0, world=1):
+               rank=0, world=1, reeval_after=1.0):
     """nses.py:318-400 for one GPU (see es.run_worker); the novelty of both rollouts of every pair is computed on
     the device from the recorded RAM trajectories and shipped in signreturns_n2."""
     from . import policies
@@ -143,17 +150,17 @@ def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2,
     rs = np.random.RandomState(seed)
     worker_id = rs.randint(2 ** 31)
     k = exp['novelty_search']['k']
-    done_tasks, last_task, archive = 0, None, None
-    while max_tasks is None or done_tasks < max_tasks:
-        task_id, task_data = worker.get_current_task()
-        if task_id == last_task:
-            time.sleep(0.001)
-            continue
-        last_task = task_id
+    pacer = TaskPacer(worker, max_tasks, reeval_after)
+    cap = bc_capacity(tslimit_max)
+    while True:
+        nxt = pacer.next_task()
+        if nxt is None:
+            break
+        task_id, task_data = nxt
         archive = worker.get_archive()                                 # nses.py:342-344
         policy.set_ref_batch(task_data.ref_batch)
         policy.set_trainable_flat(task_data.params)
-        tslimit = min(task_data.timestep_limit, _lib.ENV_MAX_EPISODE_STEPS)
+        tslimit = cap if task_data.timestep_limit is None else min(task_data.timestep_limit, cap)
         mine = shard_pairs(n_pairs, rank, world)
         noise_inds = np.array([noise.sample_index(rs, policy.num_params) for _ in range(len(mine))], dtype=np.int64)
         seeds = rs.randint(0, 2 ** 32, size=2 * len(mine), dtype=np.uint64).astype(np.uint32)
@@ -162,4 +169,4 @@ def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2,
         worker.push_result(task_id, Result(
             worker_id=worker_id, noise_inds_n=noise_inds, returns_n2=returns, signreturns_n2=novelty,
             lengths_n2=lengths, eval_return=None, eval_length=None, ob_sum=None, ob_sumsq=None, ob_count=0))
-        done_tasks += 1
+        pacer.pushed(task_id)

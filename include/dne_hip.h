@@ -41,7 +41,7 @@ typedef struct {
     int32_t policy_kind;  /* DNE_KIND_* */
     int32_t n_actions;    /* env.action_space.n (18 for Frostbite) */
     int32_t max_members;  /* episode slots evaluated concurrently (ES: 2 * pairs per call) */
-    int32_t ref_count;    /* size of the virtual-batch-norm reference batch (es.py:160-162: 128); multiple of 16 */
+    int32_t ref_count;    /* size of the virtual-batch-norm reference batch (es.py:160-162: 128); multiple of 8 */
     int32_t ref_chunk;    /* members per reference-pass chunk (bounds scratch memory); 0 = default */
     int32_t record_bc;    /* 1: keep behaviour characterisations (ES: RAM per step, GA: final RAM) */
     int32_t bc_max_steps; /* ES BC capacity in steps per member (<= timestep limit) */
@@ -73,9 +73,17 @@ void dne_destroy(dne_handle *h);
 const char *dne_last_error(dne_handle *h); /* h may be NULL: error of the last failed dne_create */
 int dne_num_params(int policy_kind, int n_actions); /* Policy.num_params, policies.py:22 */
 int dne_get_profile(dne_handle *h, dne_profile *out);
+/* Debugging aid with no reference counterpart: every device buffer of the handle lies between two poisoned 4 KiB zones;
+ * returns the number of damaged zones (0 = no kernel wrote outside its buffer), <0 on a HIP error.  Also run by
+ * dne_destroy.  Environment knobs: DNE_REDZONE=0 (off), DNE_TRACE=1 (stage breadcrumbs on stderr), DNE_DEBUG_SYNC=1
+ * (synchronise and check after every launch set of an evaluation, naming the lock-step that failed). */
+int dne_check_redzones(dne_handle *h);
 
 /* ---- SharedNoiseTable (es.py:51-67) as one device buffer --------------------------------------------- */
 int dne_noise_upload(dne_handle *h, const float *host, size_t count);          /* es.py:57-60 */
+/* the same in pieces, so the table can be uploaded while it is being sampled (es.py:59 draws 250M numbers): */
+int dne_noise_alloc(dne_handle *h, size_t count);
+int dne_noise_write(dne_handle *h, size_t offset, const float *host, size_t count);
 int dne_noise_get(dne_handle *h, int64_t idx, int dim, float *out_host);        /* es.py:63-64 get(i, dim) */
 
 /* ---- flat parameters (tf_util.py:224-246 SetFromFlat/GetFlat; policies.py:99-103) -------------------- */
@@ -141,6 +149,29 @@ int dne_optimizer_set_state(dne_handle *h, const float *m, const float *v, int32
 int dne_es_update(dne_handle *h, const int64_t *idx, const float *returns_n2, const float *signreturns_n2,
                   int n, int proc_mode, int opt_kind, float l2coeff, double stepsize, double beta1_or_momentum,
                   double beta2, double epsilon, double *update_ratio);
+
+/* ---- (e) the exchange step between GPUs: the master's Result collection es.py:226-277 for co-located GPU workers ----
+ * A pair's wire record is 32 bytes, little-endian: int64 noise_idx, float ret[2], int32 len[2], float signret[2]
+ * (the per-pair fields of Result, es.py:18-23).  Pair i of the N-pair population is evaluated by rank i % nranks.
+ * dne_comm_unique_id (rank 0) + dne_comm_init (every rank, same 128 bytes) build an RCCL communicator over xGMI;
+ * librccl.so.1 is opened on demand, single-GPU use never touches it. */
+int dne_comm_unique_id(void *out128);
+int dne_comm_init(dne_handle *h, int rank, int nranks, const void *unique_id128);
+/* sum (op 0) / max (op 1) of n <= 64 doubles over all ranks, then a device synchronise; n = 0: barrier */
+int dne_comm_allreduce(dne_handle *h, double *inout, int n, int op);
+/* generic all-gather of `bytes` host bytes per rank (the GA's 32-byte child records: parent index, fresh seed, return,
+ * length -- the per-child content of a GA Result, ga.py:266-271); recv holds nranks * bytes in rank order */
+int dne_comm_allgather(dne_handle *h, const void *send, size_t bytes, void *recv);
+/* all-gather of the records of the n_local pairs this rank evaluated in its last dne_es_eval, taken from the device
+ * accumulators; the gathered set stays on the device in global pair order.  records_out: [n_global] records or NULL */
+int dne_allgather_results(dne_handle *h, int n_local, int n_global, void *records_out);
+/* other transports (the redis Result path, gloo in the CPU tests): this rank's shard out / the gathered set in */
+int dne_records_pack(dne_handle *h, int n_local, void *records_out /*[n_local]*/);
+int dne_records_set(dne_handle *h, const void *records /*[n_global], global pair order*/, int n_global);
+/* es.py:281-298 on the gathered device-resident records (identical on every rank -> bit-identical theta) */
+int dne_es_update_gathered(dne_handle *h, int proc_mode, int opt_kind, float l2coeff, double stepsize,
+                           double beta1_or_momentum, double beta2, double epsilon, double *update_ratio);
+
 /* ga.py:145: indices of the top-T returns, ordered by (-return, arrival index) */
 int dne_ga_select(dne_handle *h, const float *returns, int m, int t, int32_t *out_idx);
 

@@ -49,7 +49,9 @@ class OracleEngine:
     def es_eval(self, idx, sigma, tslimit, seeds, want_bc=False):
         self.calls.append(("es_eval", len(idx)))
         if not self.bc_max_steps:
-            return O.es_eval(self.L, self.theta, self.noise, idx, sigma, tslimit, self.ref, seeds)
+            out = O.es_eval(self.L, self.theta, self.noise, idx, sigma, tslimit, self.ref, seeds)
+            self._last = (np.asarray(idx, np.int64),) + tuple(out)
+            return out
         n = len(idx)
         ret = np.zeros((n, 2), np.float32); sg = np.zeros((n, 2), np.float32); ln = np.zeros((n, 2), np.int32)
         self.bcs = []
@@ -142,6 +144,28 @@ class OracleEngine:
         ratio, th = self.opt.update(g, l2coeff)
         self.theta = th.copy()
         return ratio
+
+    # exchange surface (one rank: the all-gather is the identity)
+    def records_pack(self, n_local):
+        from dne_hip import _lib
+        idx, ret, sg, ln = self._last
+        assert len(idx) == n_local
+        rec = np.zeros(n_local, _lib.RECORD)
+        rec["noise_idx"], rec["ret"], rec["len"], rec["aux"] = idx, ret, ln, sg
+        return rec
+
+    def records_set(self, rec):
+        self._rec = np.array(rec)
+
+    def allgather_results(self, n_local, n_global):
+        assert n_local == n_global
+        self._rec = self.records_pack(n_local)
+        return self._rec
+
+    def es_update_gathered(self, proc_mode, opt_kind, l2coeff, stepsize, beta1_or_momentum=0.9, beta2=0.999, epsilon=1e-8):
+        r = self._rec
+        return self.es_update(r["noise_idx"], r["ret"], r["aux"], proc_mode, opt_kind, l2coeff, stepsize, beta1_or_momentum,
+                              beta2, epsilon)
 
     # single-env ABI (slot 0) used by HipAtariEnv / Policy.rollout
     def env_reset(self, seeds):

@@ -42,7 +42,7 @@ def _rank_main(rank, world, port, q):
     eng = _make_engine()
     recs = []
     for g in range(GENS):
-        rec, ratio = es.es_generation(eng, NOISE, _config(), N_PAIRS, g, TSLIMIT, OPT, rank, world)
+        rec, ratio = es.es_generation(eng, NOISE, _config(), N_PAIRS, g, TSLIMIT, OPT, rank, world, transport=es.allgather_records)
         recs.append(rec.tobytes())
     q.put((rank, eng.get_theta().tobytes(), recs))
     dist.barrier()

@@ -105,3 +105,87 @@ def test_population_eval_properties(full, oracle):
     for i in (0, 1249, 1250, 2499, 777):
         oret, osg, oln = oracle.es_eval(L, th, noise.noise, idx[i:i + 1], 0.02, tslimit, ref, seeds[2 * i:2 * i + 2])
         assert np.array_equal(oret[0], ret[i]) and np.array_equal(oln[0], ln[i]) and np.array_equal(osg[0], sg[i]), i
+
+
+BENCH_CONFIG = dict(l2coeff=0.005, noise_stdev=0.02, episodes_per_batch=5000, timesteps_per_batch=10000, calc_obstat_prob=0.0,
+                    eval_prob=0.0, snapshot_freq=0, return_proc_mode="centered_rank", episode_cutoff_mode=5000)
+BENCH_OPT = {"type": "adam", "args": {"stepsize": 0.01}}
+
+
+def test_bench_config_soak(full):
+    """bench.py's exact path (pop 5000, tslimit 5000, events on, device-resident exchange + update) for six consecutive
+    generations in one process: the profile's invariants hold, no kernel writes outside its buffer, and generation 0 equals
+    the same generation on the engine without events (the profiled and unprofiled launch sequences give the same bits)."""
+    from dne_hip import _lib, es
+    e0, noise, th, ref = full
+    cfg = es.Config(**BENCH_CONFIG)
+    e = _lib.Engine(_lib.KIND_ES, NACT, max_members=2 * N_PAIRS, ref_count=128, profile_events=True)
+    try:
+        noise.attach(e)
+        assert np.array_equal(e.noise_get(249_000_000, 4096), noise.noise[249_000_000:249_004_096])   # staged upload, far end
+        e.set_theta(th); e.set_ref_batch(ref); e.optimizer_reset()
+        first = None
+        for gen in range(6):
+            rec, ratio = es.es_generation(e, noise.noise.size, cfg, N_PAIRS, gen, 5000, BENCH_OPT)
+            p = e.profile()
+            assert rec["len"].min() >= 1 and rec["len"].max() <= 5000
+            assert p["env_steps"] == rec["len"].sum()
+            assert 0 < p["fc_full_units"] <= p["env_steps"]                        # profiled launches cover a subset of the steps
+            assert 0 < p["fc_full_union_ms"] <= p["eval_ms"] * 1.001 and p["fc_full_union_ms"] <= p["fc_full_ms"] * 1.001
+            assert 0 < p["ref_ms"] < p["eval_ms"] and p["fc_full_kind"] == 2
+            assert p["fc_full_launches"] >= 3 and np.isfinite(ratio) and ratio > 0
+            if first is None:
+                first = rec.copy()
+        assert np.isfinite(e.get_theta()).all()
+        assert e.check_redzones() == 0
+        # generation 0 again on the unprofiled engine, through the host-array update entry point
+        e0.set_theta(th); e0.optimizer_reset()
+        _, idx, seeds = es.generation_inputs(noise.noise.size, e0.P, N_PAIRS, 0, 0, 1)
+        ret, sg, ln = e0.es_eval(idx, 0.02, 5000, seeds)
+        assert np.array_equal(first["noise_idx"], idx) and np.array_equal(first["ret"], ret)
+        assert np.array_equal(first["len"], ln) and np.array_equal(first["aux"], sg)
+        e0.set_theta(th)
+        assert e0.check_redzones() == 0
+    finally:
+        e.close()
+
+
+def _oracle_pair(i):
+    import oracle as O
+    noise, th, ref, idx, seeds = _ORACLE_BASE
+    L = O.layout(O.KIND_ES, NACT)
+    return O.es_eval(L, th, noise, idx[i:i + 1], 0.02, 5000, ref, seeds[2 * i:2 * i + 2])
+
+
+@pytest.mark.slow
+@pytest.mark.timeout(1500)
+def test_full_generation_bit_exact(full, oracle):
+    """Generation 0 of config 2 in full -- all 2500 x 2 returns, sign-returns and lengths, and theta after the update --
+    against the CPU oracle run over every host core (about a minute on the GPU box's 256 cores; es.py:246-248, 297)."""
+    import multiprocessing as mp
+    from dne_hip import es
+    global _ORACLE_BASE
+    e, noise, th, ref = full
+    _, idx, seeds = es.generation_inputs(noise.noise.size, e.P, N_PAIRS, 0, 0, 1)
+    e.set_theta(th); e.optimizer_reset()
+    ret, sg, ln = e.es_eval(idx, 0.02, 5000, seeds)
+    rec = e.allgather_results(N_PAIRS, N_PAIRS)
+    assert np.array_equal(rec["noise_idx"], idx) and np.array_equal(rec["ret"], ret) and np.array_equal(rec["len"], ln)
+    e.es_update_gathered("centered_rank", "adam", 0.005, 0.01)
+    theta_gpu = e.get_theta()
+    e.set_theta(th); e.optimizer_reset()
+    _ORACLE_BASE = (noise.noise, th, ref, idx, seeds)
+    cores = min(os.cpu_count() or 1, 256)
+    budget = 40 * cores            # pairs the oracle can do in roughly ten minutes at one pair per ~15 core-seconds
+    sel = np.arange(N_PAIRS) if budget >= N_PAIRS else np.random.RandomState(9).choice(N_PAIRS, budget, replace=False)
+    with mp.get_context("fork").Pool(cores) as pool:
+        out = pool.map(_oracle_pair, [int(i) for i in sel], chunksize=1)
+    oret = np.concatenate([o[0] for o in out]); osg = np.concatenate([o[1] for o in out]); oln = np.concatenate([o[2] for o in out])
+    assert np.array_equal(ln[sel], oln)
+    assert np.array_equal(ret[sel], oret) and np.array_equal(sg[sel], osg)
+    assert ret.shape == ln.shape == (N_PAIRS, 2) and ret.dtype == np.float32                      # es.py:246-248
+    if len(sel) == N_PAIRS:        # the whole population was checked: the update must match too
+        g = oracle.es_gradient(noise.noise, idx, oret, e.P)
+        assert g.shape == (e.P,) and g.dtype == np.float32                                          # es.py:297
+        _, oth = oracle.Adam(th, 0.01).update(g, 0.005)
+        assert np.array_equal(theta_gpu, oth)

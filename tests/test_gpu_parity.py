@@ -443,3 +443,145 @@ def test_nses_driver_on_device(hip, oracle, small_noise, tmp_path):
             assert r == res.returns_n2[i, s] and l == res.lengths_n2[i, s]
             assert np.float32(oracle.novelty(arch, bc, 2)) == res.signreturns_n2[i, s]
     me.close(); we.close()
+
+
+def test_fourteen_actions_bit_exact(hip, oracle, small_noise):
+    """Asteroids has 14 actions (gym_tensorflow/atari/tf_atari.py:158): the out layer's width moves every offset behind it in
+    the flat vector.  ES evaluation + update and a GA evaluation at n_actions = 14, bit-exact against the oracle."""
+    O, nact = oracle, 14
+    L = O.layout(O.KIND_ES, nact)
+    assert L.P == hip.num_params(hip.KIND_ES, nact) == 1009058 - 4 * 257
+    ref = O.get_ref_batch(seed=0, batch_size=NREF, nact=nact)
+    e = hip.Engine(hip.KIND_ES, nact, max_members=16, ref_count=NREF)
+    try:
+        e.noise_upload(small_noise)
+        th = O.es_init_theta(L, 0)
+        e.set_theta(th); e.set_ref_batch(ref)
+        n, tslimit = 7, 150
+        idx = np.random.RandomState(2).randint(0, small_noise.size - L.P + 1, n).astype(np.int64)
+        seeds = np.random.RandomState(3).randint(0, 2 ** 31, 2 * n).astype(np.uint32)
+        ret, sg, ln = e.es_eval(idx, 0.02, tslimit, seeds)
+        oret, osg, oln = O.es_eval(L, th, small_noise, idx, 0.02, tslimit, ref, seeds)
+        assert np.array_equal(ln, oln) and np.array_equal(ret, oret) and np.array_equal(sg, osg)
+        rec = e.allgather_results(n, n)
+        assert np.array_equal(rec["ret"], oret) and np.array_equal(rec["aux"], osg) and np.array_equal(rec["noise_idx"], idx)
+        e.es_update_gathered("centered_rank", "adam", 0.005, 0.01)
+        _, oth = O.Adam(th, 0.01).update(O.es_gradient(small_noise, idx, oret, L.P), 0.005)
+        assert np.array_equal(e.get_theta(), oth)
+        # explicit members: logits of the 14-wide head
+        e.set_theta(th)
+        e.set_members(np.zeros(3, np.int32), idx[:3], np.array([0.02, -0.02, 0.0], np.float32))
+        obs = np.random.RandomState(4).randint(0, 256, (3, 84, 84, 4)).astype(np.uint8)
+        e.env_set_observation(obs)
+        e.ref_pass(3)
+        acts, logits = e.act(3)
+        assert logits.shape == (3, 14)
+        for i, sc in enumerate((0.02, -0.02, 0.0)):
+            thi = th + np.float32(sc) * small_noise[idx[i]:idx[i] + L.P]
+            bn = O.es_ref_pass(L, thi, ref)
+            a, lg = O.act(L, thi, bn, obs[i])
+            assert np.array_equal(logits[i], lg) and acts[i] == a
+        assert e.check_redzones() == 0
+    finally:
+        e.close()
+    Lg = O.layout(O.KIND_GA, nact)
+    g = hip.Engine(hip.KIND_GA, nact, max_members=8)
+    try:
+        g.noise_upload(small_noise)
+        chains = [[5], [77, 123_456], [2_000_000, 9, 31]]
+        seeds = np.array([11, 12, 13], np.uint32)
+        ret, sg, ln = g.ga_eval(chains, 0.005, 80, seeds)
+        for i, c in enumerate(chains):
+            r = O.rollout(Lg, O.ga_rebuild(Lg, small_noise, c, 0.005), None, seeds[i], 80)
+            assert (ret[i], sg[i], ln[i]) == r[:3], i
+        assert g.check_redzones() == 0
+    finally:
+        g.close()
+
+
+def test_exchange_records_roundtrip(es_engine, oracle, small_noise, ref_batch):
+    """The exchange surface on one GPU: pack (this rank's shard as 32-byte wire records) -> set (gathered records from the
+    host) -> update equals the all-in-one device path and the host-array entry point, bit for bit; a one-rank RCCL
+    communicator built through dne_comm_* runs the same all-gather through librccl."""
+    e, O = es_engine, oracle
+    L = O.layout(O.KIND_ES, NACT)
+    th = O.es_init_theta(L, 0)
+    e.set_ref_batch(ref_batch)
+    n = 6
+    idx = np.random.RandomState(5).randint(0, small_noise.size - L.P + 1, n).astype(np.int64)
+    seeds = np.random.RandomState(6).randint(0, 2 ** 31, 2 * n).astype(np.uint32)
+    thetas = []
+    for path in ("gathered", "pack_set", "host"):
+        e.set_theta(th); e.optimizer_reset()
+        ret, sg, ln = e.es_eval(idx, 0.02, 30, seeds)
+        if path == "gathered":
+            rec = e.allgather_results(n, n)
+            assert rec.dtype.itemsize == 32
+            assert np.array_equal(rec["noise_idx"], idx) and np.array_equal(rec["ret"], ret)
+            assert np.array_equal(rec["len"], ln) and np.array_equal(rec["aux"], sg)
+            e.es_update_gathered("centered_rank", "adam", 0.005, 0.01)
+        elif path == "pack_set":
+            rec2 = e.records_pack(n)
+            assert rec2.tobytes() == rec.tobytes()
+            e.records_set(rec2)
+            e.es_update_gathered("centered_rank", "adam", 0.005, 0.01)
+        else:
+            e.es_update(idx, ret, sg, "centered_rank", "adam", 0.005, 0.01)
+        thetas.append(e.get_theta())
+    assert np.array_equal(thetas[0], thetas[1]) and np.array_equal(thetas[0], thetas[2])
+    _, oth = O.Adam(th, 0.01).update(O.es_gradient(small_noise, idx, ret, L.P), 0.005)
+    assert np.array_equal(thetas[0], oth)
+    with pytest.raises(Exception):
+        e.allgather_results(n - 1, n)          # a shard that does not match the population / rank layout
+    bad = rec.copy(); bad["noise_idx"][2] = small_noise.size
+    with pytest.raises(Exception):
+        e.records_set(bad)                     # a noise index outside the table never reaches the aggregate kernel
+
+
+def test_rccl_single_rank_comm(hip, oracle, small_noise, ref_batch):
+    O = oracle
+    L = O.layout(O.KIND_ES, NACT)
+    e = hip.Engine(hip.KIND_ES, NACT, max_members=16, ref_count=NREF)
+    try:
+        uid = hip.comm_unique_id()
+        assert len(uid) == 128
+        e.comm_init(0, 1, uid)
+        e.barrier()
+        assert e.comm_allreduce([1.5, 2.0], "sum").tolist() == [1.5, 2.0]
+        assert e.comm_allreduce([3.0], "max").tolist() == [3.0]
+        e.noise_upload(small_noise)
+        th = O.es_init_theta(L, 0)
+        e.set_theta(th); e.set_ref_batch(ref_batch)
+        n = 5
+        idx = np.random.RandomState(8).randint(0, small_noise.size - L.P + 1, n).astype(np.int64)
+        seeds = np.arange(2 * n, dtype=np.uint32) + 50
+        ret, sg, ln = e.es_eval(idx, 0.02, 20, seeds)
+        rec = e.allgather_results(n, n)
+        assert np.array_equal(rec["ret"], ret) and np.array_equal(rec["len"], ln) and np.array_equal(rec["noise_idx"], idx)
+        e.es_update_gathered("centered_rank", "adam", 0.005, 0.01)
+        _, oth = O.Adam(th, 0.01).update(O.es_gradient(small_noise, idx, ret, L.P), 0.005)
+        assert np.array_equal(e.get_theta(), oth)
+    finally:
+        e.close()
+
+
+def test_debug_sync_and_trace_knobs(hip, oracle, small_noise, ref_batch, monkeypatch, capfd):
+    """DNE_DEBUG_SYNC=1 / DNE_TRACE=1: same results, with a synchronise + error check after every launch set and stage
+    breadcrumbs on stderr (what one turns on to localise a device fault)."""
+    O = oracle
+    L = O.layout(O.KIND_ES, NACT)
+    monkeypatch.setenv("DNE_DEBUG_SYNC", "1"); monkeypatch.setenv("DNE_TRACE", "1")
+    e = hip.Engine(hip.KIND_ES, NACT, max_members=16, ref_count=NREF)
+    try:
+        e.noise_upload(small_noise)
+        th = O.es_init_theta(L, 0)
+        e.set_theta(th); e.set_ref_batch(ref_batch)
+        idx = np.array([9, 99_999, 1_234_567], np.int64)
+        seeds = np.arange(6, dtype=np.uint32) + 7
+        ret, sg, ln = e.es_eval(idx, 0.02, 25, seeds)
+        oret, osg, oln = O.es_eval(L, th, small_noise, idx, 0.02, 25, ref_batch, seeds)
+        assert np.array_equal(ret, oret) and np.array_equal(ln, oln)
+    finally:
+        e.close()
+    err = capfd.readouterr().err
+    assert "engine created" in err and "reference pass done" in err and "lock-step" in err

@@ -3,11 +3,14 @@ against an independent torch-CPU fp32 formulation: SAME padding asymmetry, HWIO 
 order, batch-norm with biased batch variance, first-max argmax.  Tolerance 1e-4 (summation order)."""
 import numpy as np
 import pytest
-import torch
-import torch.nn.functional as F
+
+# torch is imported inside the function: pytest imports every test module at collection, and a process that has torch loaded
+# resolves libamdhip64.so.7 to torch's bundled ROCm 7.0 runtime -- the GPU tests must run on /opt/rocm's, like bench.py
 
 
 def _torch_forward(L, th, obs_u8, kind, ref_u8=None):
+    import torch
+    import torch.nn.functional as F
     th = torch.from_numpy(th)
     A = L.nact
 
