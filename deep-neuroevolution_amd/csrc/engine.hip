@@ -303,6 +303,7 @@ struct dne_handle {
     uint32_t *seeds = nullptr;
     float *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *y3t = nullptr;   // step mode: one row per member (y3t: 4 k-slice partials)
     float *y1r[2] = {nullptr, nullptr}, *y2r[2] = {nullptr, nullptr}, *y3pr[2] = {nullptr, nullptr};   // reference pass scratch, two ways
+    float *fr1[2] = {nullptr, nullptr}, *fr2[2] = {nullptr, nullptr};   // per-frame batch-norm moments of conv1 / conv2 ([rows][2][C])
     hipEvent_t ev_ref[2] = {nullptr, nullptr};
     int *list_a = nullptr, *list_b = nullptr, *count_dev = nullptr;
     uint8_t *bc = nullptr; size_t bc_bytes = 0;
@@ -331,6 +332,7 @@ struct dne_handle {
     int64_t *rec_idx = nullptr; float *rec_ret = nullptr, *rec_sign = nullptr; int32_t *rec_len = nullptr;
     uint8_t *rec_send = nullptr, *rec_recv = nullptr; size_t rec_cap = 0, rec_wire_cap = 0; int rec_n = 0;
     std::vector<int64_t> rec_idx_host;
+    int64_t *chain_offs = nullptr; size_t chain_cap = 0;   // GA: the seed offsets of the chain being rebuilt
     // RCCL communicator (dne_comm_init); the library is opened on demand
     void *rccl_lib = nullptr; void *comm = nullptr; int comm_rank = 0, comm_size = 1;
     double *comm_scratch = nullptr;
@@ -618,6 +620,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
         const size_t rr = (size_t)h->ref_chunk * h->F;
         for (int w = 0; w < 2; w++) {
             CH(h->alloc(&h->y1r[w], rr * 7056, "y1r[w]")); CH(h->alloc(&h->y2r[w], rr * 3872, "y2r[w]")); CH(h->alloc(&h->y3pr[w], rr * 4 * 256, "y3pr[w]"));
+            CH(h->alloc(&h->fr1[w], rr * 2 * 16, "fr1[w]")); CH(h->alloc(&h->fr2[w], rr * 2 * 32, "fr2[w]"));
             CH(hipEventCreateWithFlags(&h->ev_ref[w], hipEventDisableTiming));
         }
     }
@@ -965,17 +968,18 @@ static int ref_pass(dne_handle *h, int n) {
         const int nc = std::min(h->ref_chunk, n - m0), w = c % nways;
         hipStream_t st = h->sub_streams[w];
         float *y1 = h->y1r[w], *y2 = h->y2r[w], *y3p = h->y3pr[w];
-        if (h->conv1_fpw == 8 && F % 8 == 0) hipLaunchKernelGGL(k_conv1_ref<8>, dim3(nc * F / 8), dim3(256), 0, st, A, F, m0, (const uint8_t *)h->ref, y1);
-        else if (h->conv1_fpw == 4 && F % 4 == 0) hipLaunchKernelGGL(k_conv1_ref<4>, dim3(nc * F / 4), dim3(256), 0, st, A, F, m0, (const uint8_t *)h->ref, y1);
-        else if (h->conv1_fpw == 2 && F % 2 == 0) hipLaunchKernelGGL(k_conv1_ref<2>, dim3(nc * F / 2), dim3(256), 0, st, A, F, m0, (const uint8_t *)h->ref, y1);
-        else hipLaunchKernelGGL(k_conv1, dim3(nc * F), dim3(256), 0, st, A, (const int *)nullptr, 1, F, m0,
-                                (const uint8_t *)h->stacks, (const uint8_t *)h->ref, y1, 1);
-        hipLaunchKernelGGL((k_bn_stats<16, 441>), dim3(nc), dim3(256), F * 16 * sizeof(float), st, A, m0, F,
-                           (const float *)y1, 0, h->L.bn1b, h->L.bn1g);
+        float *fr1 = h->fr1[w], *fr2 = h->fr2[w];
+        const int fpw = h->conv1_fpw >= 8 ? 8 : h->conv1_fpw >= 4 ? 4 : h->conv1_fpw >= 2 ? 2 : 1;   // F is a multiple of 8
+#define C1R(FPW) hipLaunchKernelGGL(k_conv1_ref<FPW>, dim3(nc * F / FPW), dim3(256), 0, st, A, F, m0, (const uint8_t *)h->ref, y1, fr1)
+        if (fpw == 8) C1R(8); else if (fpw == 4) C1R(4); else if (fpw == 2) C1R(2); else C1R(1);
+#undef C1R
+        // the convolutions leave per-frame moments behind; scale / shift per member is a 128-term sum per channel
+        hipLaunchKernelGGL((k_bn_finalize<16>), dim3((nc * 16 + 255) / 256), dim3(256), 0, st, A, m0, nc, F, (const float *)fr1, 441, 0,
+                           h->L.c1b, h->L.bn1b, h->L.bn1g);
         hipLaunchKernelGGL((k_conv2<true>), dim3(nc * F), dim3(256), 0, st, A, (const int *)nullptr, 1, F, m0,
-                           (const float *)y1, y2, 1);
-        hipLaunchKernelGGL((k_bn_stats<32, 121>), dim3(nc), dim3(256), F * 32 * sizeof(float), st, A, m0, F,
-                           (const float *)y2, 32, h->L.bn2b, h->L.bn2g);
+                           (const float *)y1, y2, 1, fr2);
+        hipLaunchKernelGGL((k_bn_finalize<32>), dim3((nc * 32 + 255) / 256), dim3(256), 0, st, A, m0, nc, F, (const float *)fr2, 121, 32,
+                           h->L.c2b, h->L.bn2b, h->L.bn2g);
         if (F == 16 || F == 32 || F == 64 || F == 128) {   // matrix-core path
             const int grid = (nc + 7) / 8 * 8 * 16;
 #define FCREF(MT) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid), dim3(256), 0, st, A, nc, m0, (const float *)y2, y3p)
@@ -1028,8 +1032,8 @@ static void launch_forward(dne_handle *h, const int *list, int count, int gsize,
     hipLaunchKernelGGL(k_conv1, dim3(items * s1), dim3(256), 0, st, A, list, gsize, 1, 0,
                        (const uint8_t *)h->stacks, (const uint8_t *)nullptr, h->y1, s1);
     if (h->dbg_skip & 2) return;
-    if (es) hipLaunchKernelGGL((k_conv2<true>), dim3(items * s2), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2, s2);
-    else hipLaunchKernelGGL((k_conv2<false>), dim3(items * s2), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2, s2);
+    if (es) hipLaunchKernelGGL((k_conv2<true>), dim3(items * s2), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2, s2, (float *)nullptr);
+    else hipLaunchKernelGGL((k_conv2<false>), dim3(items * s2), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2, s2, (float *)nullptr);
 }
 
 static void launch_fc(dne_handle *h, const int *list, int count, int gsize, float *logits, hipStream_t st = nullptr,
@@ -1312,9 +1316,19 @@ static int build_chain(dne_handle *h, int slot, const int64_t *seeds, int nseeds
         hipLaunchKernelGGL(k_copy_noise, dim3(nb), dim3(256), 0, h->stream, (const float *)h->noise, seeds[0], P, dst);   // ga.py:256
         launch_normc(h, dst);                                                                                                // ga.py:258-260
     }
-    for (int s = start; s < nseeds; s++) {   // ga.py:262-263
-        hipLaunchKernelGGL(k_axpy_noise, dim3(nb), dim3(256), 0, h->stream, (const float *)h->noise, seeds[s], P, sigma, src, dst);
-        src = dst;
+    if (start < nseeds) {   // ga.py:262-263: all remaining mutations in one streaming pass
+        const int n = nseeds - start;
+        if ((size_t)n > h->chain_cap) {
+            HCHECK(h, hipStreamSynchronize(h->stream));
+            HCHECK(h, h->release(h->chain_offs));
+            h->chain_cap = std::max<size_t>(2 * (size_t)n, 1024);
+            HCHECK(h, h->alloc(&h->chain_offs, h->chain_cap, "chain_offs"));
+        }
+        // pageable source: the copy is staged before hipMemcpyAsync returns, so the caller's array may go away; successive
+        // chains are ordered on the stream
+        HCHECK(h, hipMemcpyAsync(h->chain_offs, seeds + start, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_chain_sum, dim3(nb), dim3(256), 0, h->stream, (const float *)h->noise, (const int64_t *)h->chain_offs, n, P,
+                           sigma, src, dst);
     }
     return 0;
 }

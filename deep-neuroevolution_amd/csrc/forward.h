@@ -157,14 +157,38 @@ __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict_
     }
 }
 
+// Batch-norm moments of the reference pass, formed in the convolution epilogue (the oracle's bn_finish_tiles order): one
+// 16-position MFMA tile gives, per output channel, T = (s_0 + s_1) + (s_2 + s_3) over its four row groups, with
+// s_g = ((a0 + a1) + a2) + a3 of the PRE-BIAS accumulators (positions past the layer's end count as zeros) and the same
+// tree over q_g = fma(a3,a3, fma(a2,a2, fma(a1,a1, a0*a0))).  Lane (col = l & 15, g = l >> 4) holds rows 4g..4g+3 of
+// column col; the row groups are combined with two xor-shuffles (fp add is commutative, so every lane ends with T).
+__device__ __forceinline__ void tile_moments(const f32x4 &acc, int first_pos, int npos, float &Ws, float &Wq) {
+    float a[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) a[r] = first_pos + r < npos ? acc[r] : 0.0f;
+    float s = a[0] + a[1];
+    s = s + a[2];
+    s = s + a[3];
+    float q = a[0] * a[0];
+    q = __builtin_fmaf(a[1], a[1], q);
+    q = __builtin_fmaf(a[2], a[2], q);
+    q = __builtin_fmaf(a[3], a[3], q);
+    const float s1 = s + __shfl_xor(s, 16), q1 = q + __shfl_xor(q, 16);
+    const float Ts = s1 + __shfl_xor(s1, 32), Tq = q1 + __shfl_xor(q1, 32);
+    Ws = Ws + Ts;
+    Wq = Wq + Tq;
+}
+
 // Reference-pass conv1 (policies.py:399: 128 reference frames through every member's perturbed net): one workgroup takes
 // FPW consecutive frames of ONE member, so the perturbed weights are formed once per FPW frames, and the next frame's
 // pixels are fetched into registers while the matrix cores work on the current one.  Same tiles, same MFMA order as k_conv1.
 template <int FPW>
 __global__ __launch_bounds__(256) void k_conv1_ref(FwdArgs A, int F, int member0, const uint8_t *__restrict__ ref,
-                                                   float *__restrict__ y1 /*[n_local * F][441][16]*/) {
+                                                   float *__restrict__ y1 /*[n_local * F][441][16]*/,
+                                                   float *__restrict__ fr /*[n_local * F][2][16] per-frame moments*/) {
     __shared__ float lut[256];
     __shared__ uint32_t img[88 * 88];
+    __shared__ float wsum[4][2][16];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, ci = lane >> 4;
     const int gpm = F / FPW;                         // frame groups per member
     const int mloc = blockIdx.x / gpm, f0 = (blockIdx.x % gpm) * FPW;
@@ -209,6 +233,7 @@ __global__ __launch_bounds__(256) void k_conv1_ref(FwdArgs A, int F, int member0
     for (int fi = 0; fi < FPW; fi++) {
         if (fi + 1 < FPW) fetch(f0 + fi + 1);        // in flight under the MFMAs below
         float *out = y1 + ((size_t)mloc * F + f0 + fi) * 7056;
+        float Ws = 0.0f, Wq = 0.0f;                  // this wave's tiles (wv, wv + 4, ...) of this frame, in tile order
         auto run = [&](int j, auto has_b) {
             constexpr bool HASB = decltype(has_b)::value;
             const int tA = wv + 4 * j, tB = wv + 4 * (j + 1);
@@ -233,13 +258,21 @@ __global__ __launch_bounds__(256) void k_conv1_ref(FwdArgs A, int F, int member0
                 if (posA < 441) out[posA * 16 + lp] = accA[r] + bias;
                 if (HASB && posB < 441) out[posB * 16 + lp] = accB[r] + bias;
             }
+            tile_moments(accA, tA * 16 + ci * 4, 441, Ws, Wq);
+            if (HASB) tile_moments(accB, tB * 16 + ci * 4, 441, Ws, Wq);
         };
         run(0, std::true_type{});
         run(2, std::true_type{});
         run(4, std::true_type{});
         run(6, std::false_type{});
+        if (ci == 0) { wsum[wv][0][lp] = Ws; wsum[wv][1][lp] = Wq; }
+        __syncthreads();                             // every wave is done reading this frame; its moments are in LDS
+        if (tid < 32) {                              // frame moments: (W0 + W1) + (W2 + W3) per channel
+            const int k = tid >> 4, c = tid & 15;
+            const float lo = wsum[0][k][c] + wsum[1][k][c], hi = wsum[2][k][c] + wsum[3][k][c];
+            fr[(((size_t)mloc * F + f0 + fi) * 2 + k) * 16 + c] = lo + hi;
+        }
         if (fi + 1 < FPW) {
-            __syncthreads();                         // every wave is done reading this frame
             stage();
             __syncthreads();
         }
@@ -253,12 +286,14 @@ __global__ __launch_bounds__(256) void k_conv1_ref(FwdArgs A, int F, int member0
 // perturbed weights of 16 output channels) live in 64 VGPRs, A comes from the padded activation image in LDS.
 template <bool HAS_BN>
 __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict__ list, int gsize, int F, int member0,
-                                               const float *__restrict__ y1, float *__restrict__ y2, int nsplit) {
+                                               const float *__restrict__ y1, float *__restrict__ y2, int nsplit,
+                                               float *__restrict__ fr /*reference pass: [rows][2][32] per-frame moments, else null*/) {
     const int part = blockIdx.x % nsplit;   // nsplit = 2 / 4: two / four workgroups share one member's position tiles
     const Item it = decode_item(blockIdx.x / nsplit, list, gsize, F, member0, nullptr, nullptr, A.done);
     if (it.skip) return;
     constexpr int PS = 17;   // LDS pixel stride (16 channels + 1 pad)
     __shared__ float a_s[24 * 24 * PS];
+    __shared__ float wsum[4][2][16];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
     const int nt = wv & 1, mt0 = 4 * (wv >> 1);
     const float *base = A.bases + (size_t)A.m_slot[it.member] * A.base_stride + A.L.c2w;
@@ -337,6 +372,17 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
                 const int pos = (mtb + m) * 16 + lk * 4 + r;
                 if (pos < 121) o[pos * 32 + nt * 16 + lp] = acc[m][r] + bias;
             }
+        if (NTL == 4 && fr) {   // reference pass: this wave's four tiles in tile order, then (tiles 0-3) + (tiles 4-7)
+            float Ws = 0.0f, Wq = 0.0f;
+#pragma unroll
+            for (int m = 0; m < NTL; m++) tile_moments(acc[m], (mtb + m) * 16 + lk * 4, 121, Ws, Wq);
+            if (lk == 0) { wsum[wv][0][lp] = Ws; wsum[wv][1][lp] = Wq; }
+            __syncthreads();
+            if (tid < 64) {
+                const int k = tid >> 5, c = tid & 31, h = c >> 4, l = c & 15;
+                fr[((size_t)it.row * 2 + k) * 32 + c] = wsum[h][k][l] + wsum[h + 2][k][l];
+            }
+        }
     };
     if (nsplit == 4) run(std::integral_constant<int, 1>{});
     else if (nsplit == 2) run(std::integral_constant<int, 2>{});
@@ -1142,6 +1188,44 @@ __global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ 
         if (logits_out)
             for (int a = 0; a < nact; a++) logits_out[(size_t)m * nact + a] = lg[v][a];
     }
+}
+
+// Per-member batch-norm scale / shift of a convolution layer from the per-frame moments the convolutions left behind
+// (oracle: bn_finish_tiles): S, Q = frame moments summed in frame order; m = S / count; mean = bias + m;
+// var = max(Q / count - m*m, 0).  One thread per (member, channel).
+template <int C>
+__global__ __launch_bounds__(256) void k_bn_finalize(FwdArgs A, int member0, int n_local, int F, const float *__restrict__ fr,
+                                                     int npos, int bn_off, int bias_off, int beta_off, int gamma_off) {
+    const int i = blockIdx.x * 256 + threadIdx.x, mloc = i / C, c = i % C;
+    if (mloc >= n_local) return;
+    const int member = member0 + mloc;
+    const float *p = fr + (size_t)mloc * F * 2 * C + c;
+    float S = 0.0f, Q = 0.0f;
+    for (int n = 0; n < F; n++) {
+        S = S + p[(size_t)n * 2 * C];
+        Q = Q + p[(size_t)n * 2 * C + C];
+    }
+    const float count = (float)(F * npos);
+    const float *base = A.bases + (size_t)A.m_slot[member] * A.base_stride;
+    const float *eps = A.noise + A.m_off[member];
+    const float sc = A.m_scale[member];
+    float pbias = sc * eps[bias_off + c];
+    const float bias = base[bias_off + c] + pbias;
+    const float m = S / count;
+    const float mean = bias + m;
+    const float q1 = Q / count;
+    const float mm = m * m;
+    float var = q1 - mm;
+    var = var > 0.0f ? var : 0.0f;
+    float pb = sc * eps[beta_off + c];
+    const float beta = base[beta_off + c] + pb;
+    float pg = sc * eps[gamma_off + c];
+    const float gamma = base[gamma_off + c] + pg;
+    const float inv = 1.0f / sqrtf(var + 1e-3f);
+    const float s = inv * gamma;
+    const float ms = mean * s;
+    A.bn[(size_t)member * 608 + bn_off + c] = s;
+    A.bn[(size_t)member * 608 + bn_off + C + c] = beta - ms;
 }
 
 // -------------------------------------------------------------- virtual batch norm statistics

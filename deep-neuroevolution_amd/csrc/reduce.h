@@ -183,16 +183,54 @@ __global__ __launch_bounds__(256) void k_axpy_noise(const float *__restrict__ no
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p < P) { float v = sigma * noise[off + p]; dst[p] = src[p] + v; }
 }
+// ga.py:262-263 for a whole chain in one pass: dst[p] = (...((src[p] + sigma*noise[s_1 + p]) + sigma*noise[s_2 + p])...),
+// the same additions in the same order as one k_axpy_noise per seed, but theta stays in a register and the n noise
+// slices stream through once (4 (n + 2) P bytes instead of 12 n P).  Eight slices are in flight per thread.
+__global__ __launch_bounds__(256) void k_chain_sum(const float *__restrict__ noise, const int64_t *__restrict__ offs, int n, int P,
+                                                   float sigma, const float *__restrict__ src, float *__restrict__ dst) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    float v = src[p];
+    int s = 0;
+    for (; s + 8 <= n; s += 8) {
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) e[j] = noise[offs[s + j] + p];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { float t = sigma * e[j]; v = v + t; }
+    }
+    for (; s < n; s++) { float t = sigma * noise[offs[s] + p]; v = v + t; }
+    dst[p] = v;
+}
+
 // tf_util.py:122-130 _normalize on a [K][C] view: out *= std / sqrt(square(out).sum(axis=0)); the axis-0
 // sum is sequential in k (numpy adds row by row).  One thread per column; bias tensors are zeroed.
+// (the column sum is a dependent chain, but its operands are not: 16 rows are loaded ahead of the adds, K % 16 == 0)
+__device__ __forceinline__ void normc_column(float *__restrict__ w, int K, int C, int c, float std) {
+    float ss = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        float x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = k0 + j < K ? w[(size_t)(k0 + j) * C + c] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (k0 + j < K) { float sq = x[j] * x[j]; ss = ss + sq; }
+    }
+    const float rt = sqrtf(ss);
+    const float sc = std / rt;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        float x[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) x[j] = k0 + j < K ? w[(size_t)(k0 + j) * C + c] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (k0 + j < K) w[(size_t)(k0 + j) * C + c] = x[j] * sc;
+    }
+}
 __global__ __launch_bounds__(64) void k_normc(float *__restrict__ w, int K, int C, float std) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;
-    float ss = 0.0f;
-    for (int k = 0; k < K; k++) { float x = w[(size_t)k * C + c]; float sq = x * x; ss = ss + sq; }
-    const float rt = sqrtf(ss);
-    const float sc = std / rt;
-    for (int k = 0; k < K; k++) w[(size_t)k * C + c] = w[(size_t)k * C + c] * sc;
+    normc_column(w, K, C, c, std);
 }
 // batched forms for a whole generation of fresh genomes (generation 0 of the GA: every child is its own
 // normc(noise[s0])): blockIdx.y = genome, written into base slot slots[genome]
@@ -206,12 +244,7 @@ __global__ __launch_bounds__(64) void k_normc_batch(float *__restrict__ bases, c
                                                     int off, int K, int C, float std) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= C) return;
-    float *w = bases + (size_t)slots[blockIdx.y] * stride + off;
-    float ss = 0.0f;
-    for (int k = 0; k < K; k++) { float x = w[(size_t)k * C + c]; float sq = x * x; ss = ss + sq; }
-    const float rt = sqrtf(ss);
-    const float sc = std / rt;
-    for (int k = 0; k < K; k++) w[(size_t)k * C + c] = w[(size_t)k * C + c] * sc;
+    normc_column(bases + (size_t)slots[blockIdx.y] * stride + off, K, C, c, std);
 }
 __global__ void k_zero_batch(float *__restrict__ bases, const int32_t *__restrict__ slots, size_t stride, int off, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -79,7 +79,7 @@ static void ob_lut_init(void) {
 }
 
 /* conv1: 8x8 stride 4, SAME (pad 2/2), HWIO weights, NHWC input. policies.py:321 / 451 */
-static void conv1_raw(const float *w, const float *b, const uint8_t *ob, float *y1) {
+static void conv1_raw_acc(const float *w, const float *b, const uint8_t *ob, float *y1, float *raw /* may be NULL: pre-bias sums */) {
     ob_lut_init();
     for (int oy = 0; oy < 21; oy++)
         for (int ox = 0; ox < 21; ox++) {
@@ -100,8 +100,11 @@ static void conv1_raw(const float *w, const float *b, const uint8_t *ob, float *
             }
             float *o = y1 + (oy * 21 + ox) * 16;
             for (int co = 0; co < 16; co++) o[co] = acc[co] + b[co];
+            if (raw)
+                for (int co = 0; co < 16; co++) raw[(oy * 21 + ox) * 16 + co] = acc[co];
         }
 }
+static void conv1_raw(const float *w, const float *b, const uint8_t *ob, float *y1) { conv1_raw_acc(w, b, ob, y1, NULL); }
 
 /* tf.nn.batch_normalization(x, mean, var, beta, gamma, eps) followed by relu:
  *   inv = rsqrt(var + eps) * gamma ; y = x * inv + (beta - mean * inv)       [external: TF semantics]
@@ -116,7 +119,7 @@ static inline float bn_relu(float x, const float *scale, const float *shift, int
 }
 
 /* conv2: 4x4 stride 2, SAME (pad 1 top/left, 2 bottom/right). policies.py:323 / 452 */
-static void conv2_raw(const float *w, const float *b, const float *a1 /*[21][21][16]*/, float *y2) {
+static void conv2_raw_acc(const float *w, const float *b, const float *a1 /*[21][21][16]*/, float *y2, float *raw) {
     for (int oy = 0; oy < 11; oy++)
         for (int ox = 0; ox < 11; ox++) {
             float acc[32];
@@ -136,8 +139,11 @@ static void conv2_raw(const float *w, const float *b, const float *a1 /*[21][21]
             }
             float *o = y2 + (oy * 11 + ox) * 32;
             for (int co = 0; co < 32; co++) o[co] = acc[co] + b[co];
+            if (raw)
+                for (int co = 0; co < 32; co++) raw[(oy * 11 + ox) * 32 + co] = acc[co];
         }
 }
+static void conv2_raw(const float *w, const float *b, const float *a1, float *y2) { conv2_raw_acc(w, b, a1, y2, NULL); }
 
 /* fc 3872 -> 256 (policies.py:327 / 455): 4 k-slices of 968, ((s0+s1)+(s2+s3)) + bias */
 static void fc_raw(const float *w, const float *b, const float *a2, float *y3) {
@@ -233,25 +239,97 @@ static void bn_finish(const float *y, int nref, int npos, int C, const float *be
     }
 }
 
+/* Batch moments of a convolution layer, in one pass over the pre-bias sums a = y - bias (the bias is the shift of
+ * tf.nn.moments' sufficient statistics [external: TF computes shifted sums and mean = shift + m_ss / count,
+ * var = v_ss / count - (m_ss / count)^2]; TF's own shift and summation order are unknowable).
+ * The summation order is a fixed tree over the 16-position tiles of the matrix-core convolution, so that the GPU
+ * forms the sums in the convolution's epilogue instead of re-reading the activations:
+ *   tile t = positions 16t .. 16t+15 (positions >= npos count as exact zeros);
+ *   row group g = 4 consecutive positions:  s_g = ((a0 + a1) + a2) + a3,  q_g = fma(a3,a3, fma(a2,a2, fma(a1,a1, a0*a0)));
+ *   tile:   T = (s_0 + s_1) + (s_2 + s_3)                                  (same for q);
+ *   frame:  ngroups interleaved (conv1: 4, tile t in group t % 4) or blocked (conv2: 2, tile t in group t / 4) tile
+ *           groups, each summed sequentially in tile order from 0; conv1: Fr = (W0 + W1) + (W2 + W3), conv2: Fr = W0 + W1;
+ *   batch:  S = sum over frames in order, from 0.
+ * raw: [nref][npos][C] pre-bias sums. */
+static void bn_finish_tiles(const float *raw, int nref, int npos, int C, int interleaved, const float *bias,
+                            const float *beta, const float *gamma, float *scale, float *shift) {
+    const int ntile = (npos + 15) / 16, ngroups = interleaved ? 4 : 2;
+    const float count = (float)(nref * npos);
+    for (int c = 0; c < C; c++) {
+        float S = 0.0f, Q = 0.0f;
+        for (int n = 0; n < nref; n++) {
+            const float *yn = raw + (size_t)n * npos * C + c;
+            float Ws[4] = {0.0f, 0.0f, 0.0f, 0.0f}, Wq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int t = 0; t < ntile; t++) {
+                float sg[4], qg[4];
+                for (int g = 0; g < 4; g++) {
+                    float a[4];
+                    for (int r = 0; r < 4; r++) {
+                        int p = t * 16 + g * 4 + r;
+                        a[r] = p < npos ? yn[(size_t)p * C] : 0.0f;
+                    }
+                    float s01 = a[0] + a[1];
+                    float s012 = s01 + a[2];
+                    sg[g] = s012 + a[3];
+                    float q = a[0] * a[0];
+                    q = fmaf(a[1], a[1], q);
+                    q = fmaf(a[2], a[2], q);
+                    qg[g] = fmaf(a[3], a[3], q);
+                }
+                float s_lo = sg[0] + sg[1], s_hi = sg[2] + sg[3];
+                float q_lo = qg[0] + qg[1], q_hi = qg[2] + qg[3];
+                float Ts = s_lo + s_hi, Tq = q_lo + q_hi;
+                int grp = interleaved ? (t & 3) : (t >> 2);
+                Ws[grp] = Ws[grp] + Ts;
+                Wq[grp] = Wq[grp] + Tq;
+            }
+            float Fs, Fq;
+            if (ngroups == 4) {
+                float a = Ws[0] + Ws[1], b = Ws[2] + Ws[3];
+                Fs = a + b;
+                float cq = Wq[0] + Wq[1], dq = Wq[2] + Wq[3];
+                Fq = cq + dq;
+            } else {
+                Fs = Ws[0] + Ws[1];
+                Fq = Wq[0] + Wq[1];
+            }
+            S = S + Fs;
+            Q = Q + Fq;
+        }
+        float m = S / count;
+        float mean = bias[c] + m;
+        float q1 = Q / count;
+        float mm = m * m;
+        float var = q1 - mm;
+        var = var > 0.0f ? var : 0.0f;
+        float inv = 1.0f / sqrtf(var + 1e-3f);
+        float sc = inv * gamma[c];
+        float ms = mean * sc;
+        scale[c] = sc;
+        shift[c] = beta[c] - ms;
+    }
+}
+
 void orc_es_ref_pass(const orc_layout *L, const float *th, const uint8_t *ref, int nref, float *bn) {
     float *y1 = (float *)malloc(sizeof(float) * (size_t)nref * 7056);
     float *y2 = (float *)malloc(sizeof(float) * (size_t)nref * 3872);
     float *y3 = (float *)malloc(sizeof(float) * (size_t)nref * 256);
+    float *raw = (float *)malloc(sizeof(float) * (size_t)nref * 7056);
     float *a = (float *)malloc(sizeof(float) * 7056);
     for (int n = 0; n < nref; n++)
-        conv1_raw(th + L->c1w, th + L->c1b, ref + (size_t)n * ORC_OB_BYTES, y1 + (size_t)n * 7056);
-    bn_finish(y1, nref, 441, 16, th + L->bn1b, th + L->bn1g, bn, bn + 16);
+        conv1_raw_acc(th + L->c1w, th + L->c1b, ref + (size_t)n * ORC_OB_BYTES, y1 + (size_t)n * 7056, raw + (size_t)n * 7056);
+    bn_finish_tiles(raw, nref, 441, 16, 1, th + L->c1b, th + L->bn1b, th + L->bn1g, bn, bn + 16);
     for (int n = 0; n < nref; n++) {
         for (int i = 0; i < 7056; i++) a[i] = bn_relu(y1[(size_t)n * 7056 + i], bn, bn + 16, i & 15);
-        conv2_raw(th + L->c2w, th + L->c2b, a, y2 + (size_t)n * 3872);
+        conv2_raw_acc(th + L->c2w, th + L->c2b, a, y2 + (size_t)n * 3872, raw + (size_t)n * 3872);
     }
-    bn_finish(y2, nref, 121, 32, th + L->bn2b, th + L->bn2g, bn + 32, bn + 64);
+    bn_finish_tiles(raw, nref, 121, 32, 0, th + L->c2b, th + L->bn2b, th + L->bn2g, bn + 32, bn + 64);
     for (int n = 0; n < nref; n++) {
         for (int i = 0; i < 3872; i++) a[i] = bn_relu(y2[(size_t)n * 3872 + i], bn + 32, bn + 64, i & 31);
         fc_raw(th + L->fcw, th + L->fcb, a, y3 + (size_t)n * 256);
     }
-    bn_finish(y3, nref, 1, 256, th + L->bn3b, th + L->bn3g, bn + 96, bn + 352);
-    free(y1); free(y2); free(y3); free(a);
+    bn_finish(y3, nref, 1, 256, th + L->bn3b, th + L->bn3g, bn + 96, bn + 352);   /* fc: 128 values per column, two passes */
+    free(y1); free(y2); free(y3); free(a); free(raw);
 }
 
 /* ----------------------------------------------------- SynthAtari (fixture) */

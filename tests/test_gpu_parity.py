@@ -44,6 +44,16 @@ def test_library_loaded_is_in_tree(hip):
     assert hip.LIB_PATH.endswith(os.path.join("deep-neuroevolution_amd", "csrc", "libdne_hip.so"))
 
 
+def test_hip_runtime_is_the_system_one(hip, es_engine):
+    """The process that runs the GPU tests must be on /opt/rocm's HIP runtime -- the one libdne_hip.so was built against and
+    the one bench.py runs on -- not on the ROCm 7.0 copy bundled with torch (which wins if torch is imported first)."""
+    import sys
+    maps = open("/proc/self/maps").read()
+    hip_libs = sorted({line.split()[-1] for line in maps.splitlines() if "libamdhip64" in line})
+    assert hip_libs and all(p.startswith("/opt/rocm") for p in hip_libs), hip_libs
+    assert "torch" not in sys.modules, "a test module imported torch at collection time"
+
+
 def test_noise_get_and_materialize(es_engine, oracle, small_noise):
     e = es_engine
     L = oracle.layout(oracle.KIND_ES, NACT)
