@@ -1,14 +1,104 @@
-"""In-process stand-in for es_distributed/dist.py (Redis transport, dist.py:62-192).
+"""Transport of es_distributed/dist.py (dist.py:62-192) for the HIP drivers: same classes (MasterClient, RelayClient,
+WorkerClient), same Redis keys, same pickled payloads, so HIP workers can serve a reference master and a HIP master
+can drive reference CPU workers.
 
-Redis is out of scope for the hot path and not installed here, so MasterClient / WorkerClient
-keep the reference's method names and task/result semantics over a thread-safe in-memory broker: the master
-and the GPU worker(s) run as threads of one process.  Keys mirror dist.py:12-17; payloads are the same
-namedtuples (not pickled -- nothing crosses a socket).  A maintainer who wants the real Redis path keeps
-the reference's dist.py: the Task / Result wire types in es.py are unchanged.
+Two carriers behind the same methods:
+  * Redis -- the reference's own deployment.  The `redis` package is used when importable; otherwise the small RESP
+    client in resp.py speaks to the server directly (this image has neither the package nor a server).
+  * an in-process broker -- master and GPU worker(s) as threads of one process, no server, nothing pickled.
+    Chosen with redis_cfg['transport'] = 'inprocess', or automatically when no Redis answers at the address
+    (transport 'auto', the default; 'redis' insists and retries like dist.py:27-43).
 """
+import logging
+import os
+import pickle
 import threading
 import time
 from collections import deque
+
+logger = logging.getLogger(__name__)
+
+# dist.py:12-17
+EXP_KEY = 'es:exp'
+TASK_ID_KEY = 'es:task_id'
+TASK_DATA_KEY = 'es:task_data'
+TASK_CHANNEL = 'es:task_channel'
+RESULTS_KEY = 'es:results'
+ARCHIVE_KEY = 'es:archive'
+
+
+def serialize(x):      # dist.py:19-20
+    return pickle.dumps(x, protocol=-1)
+
+
+def deserialize(x):    # dist.py:23-24
+    return pickle.loads(x)
+
+
+# ---------------------------------------------------------------------------------------------- carriers
+def _redis_module():
+    try:
+        import redis
+        return redis.StrictRedis, redis.ConnectionError
+    except ImportError:
+        from . import resp
+        return resp.Client, resp.ConnectionError
+
+
+def _server_cfg(redis_cfg):
+    return {k: v for k, v in redis_cfg.items() if k != 'transport'}
+
+
+def retry_connect(redis_cfg, tries=300, base_delay=4., connect_timeout=None):
+    """dist.py:27-43"""
+    cls, conn_err = _redis_module()
+    kw = _server_cfg(redis_cfg)
+    if connect_timeout is not None:
+        kw['socket_connect_timeout'] = connect_timeout
+    for i in range(tries):
+        try:
+            r = cls(**kw)
+            r.ping()
+            return r
+        except conn_err as e:
+            if i == tries - 1:
+                raise
+            delay = base_delay * (1 + (os.getpid() % 10) / 9)
+            logger.warning('Could not connect to {}. Retrying after {:.2f} sec ({}/{}). Error: {}'.format(redis_cfg, delay, i + 2, tries, e))
+            time.sleep(delay)
+
+
+def retry_get(r, key, tries=300, base_delay=4.):
+    """dist.py:46-64"""
+    for i in range(tries):
+        if isinstance(key, (list, tuple)):
+            vals = r.mget(key)
+            if all(v is not None for v in vals):
+                return vals
+        else:
+            val = r.get(key)
+            if val is not None:
+                return val
+        if i != tries - 1:
+            delay = base_delay * (1 + (os.getpid() % 10) / 9)
+            logger.warning('{} not set. Retrying after {:.2f} sec ({}/{})'.format(key, delay, i + 2, tries))
+            time.sleep(delay)
+    raise RuntimeError('{} not set'.format(key))
+
+
+def _carrier(redis_cfg):
+    """-> ('redis', connection) or ('inprocess', broker)"""
+    mode = redis_cfg.get('transport', 'auto') if isinstance(redis_cfg, dict) else 'inprocess'
+    if mode == 'inprocess':
+        return 'inprocess', _broker(redis_cfg)
+    if mode == 'redis':
+        return 'redis', retry_connect(redis_cfg)
+    try:                                  # auto: one attempt, then the in-process broker
+        return 'redis', retry_connect(redis_cfg, tries=1, connect_timeout=2.0)
+    except Exception as e:
+        logger.info('no Redis at {} ({}): using the in-process broker'.format(redis_cfg, e))
+        return 'inprocess', _broker(redis_cfg)
+
 
 _brokers = {}
 _brokers_lock = threading.Lock()
@@ -25,7 +115,7 @@ class _Broker:
 
 
 def _broker(redis_cfg):
-    key = repr(sorted(redis_cfg.items())) if isinstance(redis_cfg, dict) else repr(redis_cfg)
+    key = repr(sorted(_server_cfg(redis_cfg).items())) if isinstance(redis_cfg, dict) else repr(redis_cfg)
     with _brokers_lock:
         if key not in _brokers:
             _brokers[key] = _Broker()
@@ -37,70 +127,165 @@ def reset_brokers():
         _brokers.clear()
 
 
+# ---------------------------------------------------------------------------------------------- clients
 class MasterClient:
     """dist.py:62-98"""
 
     def __init__(self, master_redis_cfg):
         self.task_counter = 0
-        self.b = _broker(master_redis_cfg)
+        self.kind, self.r = _carrier(master_redis_cfg)
+        logger.info('[master] transport: {}'.format(self.kind))
 
     def declare_experiment(self, exp):
-        with self.b.cv:
-            self.b.exp = exp
-            self.b.cv.notify_all()
+        if self.kind == 'redis':
+            self.r.set(EXP_KEY, serialize(exp))
+            return
+        with self.r.cv:
+            self.r.exp = exp
+            self.r.cv.notify_all()
 
     def declare_task(self, task_data):
         task_id = self.task_counter
         self.task_counter += 1
-        with self.b.cv:
-            self.b.task_id, self.b.task_data = task_id, task_data
-            self.b.cv.notify_all()
+        if self.kind == 'redis':   # dist.py:76-80 (the reference pipelines the two commands; order is what matters)
+            blob = serialize(task_data)
+            self.r.mset({TASK_ID_KEY: task_id, TASK_DATA_KEY: blob})
+            self.r.publish(TASK_CHANNEL, serialize((task_id, blob)))
+            return task_id
+        with self.r.cv:
+            self.r.task_id, self.r.task_data = task_id, task_data
+            self.r.cv.notify_all()
         return task_id
 
     def pop_result(self):
-        with self.b.cv:
-            while not self.b.results:
-                self.b.cv.wait()
-            return self.b.results.popleft()
+        if self.kind == 'redis':
+            task_id, result = deserialize(self.r.blpop(RESULTS_KEY)[1])
+            return task_id, result
+        with self.r.cv:
+            while not self.r.results:
+                self.r.cv.wait()
+            return self.r.results.popleft()
 
     def flush_results(self):
-        with self.b.cv:
-            n = len(self.b.results)
-            self.b.results.clear()
+        if self.kind == 'redis':   # dist.py:90-91: everything but the newest entry
+            n = self.r.llen(RESULTS_KEY)
+            self.r.ltrim(RESULTS_KEY, -1, -1)
+            return max(n - 1, 0)
+        with self.r.cv:
+            n = len(self.r.results)
+            self.r.results.clear()
             return n
 
     def add_to_novelty_archive(self, novelty_vector):
-        with self.b.cv:
-            self.b.archive.append(novelty_vector)
+        if self.kind == 'redis':
+            self.r.rpush(ARCHIVE_KEY, serialize(novelty_vector))
+            return
+        with self.r.cv:
+            self.r.archive.append(novelty_vector)
 
     def get_archive(self):
-        with self.b.cv:
-            return list(self.b.archive)
+        if self.kind == 'redis':
+            return [deserialize(v) for v in self.r.lrange(ARCHIVE_KEY, 0, -1)]
+        with self.r.cv:
+            return list(self.r.archive)
+
+
+class RelayClient:
+    """dist.py:101-151: one per worker machine -- mirrors the master's experiment and task into the local Redis and
+    forwards the workers' results in batches.  Redis only (the in-process broker needs no relay)."""
+
+    def __init__(self, master_redis_cfg, relay_redis_cfg):
+        self.master_redis = retry_connect(master_redis_cfg)
+        self.local_redis = retry_connect(relay_redis_cfg)
+        self.results_published = 0
+        self._stop = threading.Event()
+
+    def run(self, max_batches=None):
+        self.local_redis.set(EXP_KEY, retry_get(self.master_redis, EXP_KEY))
+        self._declare_task_local(*retry_get(self.master_redis, (TASK_ID_KEY, TASK_DATA_KEY)))
+        handler = lambda data: self._declare_task_local(*deserialize(data))   # noqa: E731
+        if hasattr(self.master_redis, 'subscribe_loop'):
+            t = threading.Thread(target=self.master_redis.subscribe_loop, args=(TASK_CHANNEL, handler, self._stop), daemon=True)
+            t.start()
+        else:                                                                  # the real redis package
+            p = self.master_redis.pubsub(ignore_subscribe_messages=True)
+            p.subscribe(**{TASK_CHANNEL: lambda msg: handler(msg['data'])})
+            p.run_in_thread(sleep_time=0.001)
+        batches = 0
+        while max_batches is None or batches < max_batches:
+            results = []
+            start_time = curr_time = time.time()
+            while curr_time - start_time < 0.001:
+                results.append(self.local_redis.blpop(RESULTS_KEY)[1])
+                curr_time = time.time()
+            self.results_published += len(results)
+            self.master_redis.rpush(RESULTS_KEY, *results)
+            batches += 1
+
+    def flush_results(self):
+        for r in (self.local_redis, self.master_redis):
+            r.llen(RESULTS_KEY)
+            r.ltrim(RESULTS_KEY, -1, -1)
+
+    def _declare_task_local(self, task_id, task_data):
+        if isinstance(task_id, bytes):
+            task_id = int(task_id)
+        logger.info('[relay] Received task {}'.format(task_id))
+        self.results_published = 0
+        self.local_redis.mset({TASK_ID_KEY: task_id, TASK_DATA_KEY: task_data})
+        self.flush_results()
 
 
 class WorkerClient:
     """dist.py:153-192.  Argument order as in the reference class: (relay_redis_cfg, master_redis_cfg)."""
 
     def __init__(self, relay_redis_cfg, master_redis_cfg):
-        self.b = _broker(master_redis_cfg)
+        # a GPU worker shares the master's host more often than not: with the in-process broker, and whenever no relay
+        # is running, both names mean the master's carrier
+        self.kind, self.master = _carrier(master_redis_cfg)
+        if self.kind == 'redis':
+            try:
+                self.local = retry_connect(relay_redis_cfg, tries=1, connect_timeout=2.0) if relay_redis_cfg != master_redis_cfg else self.master
+            except Exception:
+                logger.warning('[worker] no relay at {}: talking to the master directly'.format(relay_redis_cfg))
+                self.local = self.master
+        else:
+            self.local = self.master
+        self.cached_task_id, self.cached_task_data = None, None
 
     def get_experiment(self):
-        with self.b.cv:
-            while self.b.exp is None:
-                self.b.cv.wait()
-            return self.b.exp
-
-    def get_current_task(self):
-        with self.b.cv:
-            while self.b.task_data is None:
-                self.b.cv.wait()
-            return self.b.task_id, self.b.task_data
-
-    def push_result(self, task_id, result):
-        with self.b.cv:
-            self.b.results.append((task_id, result))
-            self.b.cv.notify_all()
+        if self.kind == 'redis':
+            return deserialize(retry_get(self.local, EXP_KEY))
+        with self.master.cv:
+            while self.master.exp is None:
+                self.master.cv.wait()
+            return self.master.exp
 
     def get_archive(self):
-        with self.b.cv:
-            return list(self.b.archive)
+        if self.kind == 'redis':
+            return [deserialize(v) for v in self.master.lrange(ARCHIVE_KEY, 0, -1)]
+        with self.master.cv:
+            return list(self.master.archive)
+
+    def get_current_task(self):
+        if self.kind == 'redis':
+            # dist.py:172-188 reads the id under WATCH and fetches the data only when it changed; MGET returns both keys
+            # atomically, so one extra check of the id is enough
+            task_id = int(retry_get(self.local, TASK_ID_KEY))
+            while task_id != self.cached_task_id:
+                tid, blob = retry_get(self.local, (TASK_ID_KEY, TASK_DATA_KEY))
+                self.cached_task_id, self.cached_task_data = int(tid), deserialize(blob)
+                task_id = int(retry_get(self.local, TASK_ID_KEY))
+            return self.cached_task_id, self.cached_task_data
+        with self.master.cv:
+            while self.master.task_data is None:
+                self.master.cv.wait()
+            return self.master.task_id, self.master.task_data
+
+    def push_result(self, task_id, result):
+        if self.kind == 'redis':
+            self.local.rpush(RESULTS_KEY, serialize((task_id, result)))
+            return
+        with self.master.cv:
+            self.master.results.append((task_id, result))
+            self.master.cv.notify_all()

@@ -18,19 +18,8 @@ from .dist import MasterClient, WorkerClient
 
 logger = logging.getLogger(__name__)
 
-# wire types, es.py:12-23
-Config = namedtuple('Config', [
-    'l2coeff', 'noise_stdev', 'episodes_per_batch', 'timesteps_per_batch',
-    'calc_obstat_prob', 'eval_prob', 'snapshot_freq',
-    'return_proc_mode', 'episode_cutoff_mode'
-])
-Task = namedtuple('Task', ['params', 'ob_mean', 'ob_std', 'ref_batch', 'timestep_limit'])
-Result = namedtuple('Result', [
-    'worker_id',
-    'noise_inds_n', 'returns_n2', 'signreturns_n2', 'lengths_n2',
-    'eval_return', 'eval_length',
-    'ob_sum', 'ob_sumsq', 'ob_count'
-])
+# wire types, es.py:12-23 (compat.py names them so that their pickles are the reference's)
+from .compat import Config, Result, Task   # noqa: E402,F401
 
 # one (noise_idx, returns, lengths, sign-returns) record per antithetic pair -- what travels between GPUs
 RECORD = _lib.RECORD

@@ -18,7 +18,7 @@ from .es import Config, Result, SharedNoiseTable, TaskPacer, collect_batch, log_
 
 logger = logging.getLogger(__name__)
 
-GATask = namedtuple('GATask', ['params', 'population', 'ob_mean', 'ob_std', 'timestep_limit'])  # ga.py:4
+from .compat import GATask  # ga.py:4  # noqa: E402
 
 
 def setup(exp, engine=None, n_children=None, device_id=0):

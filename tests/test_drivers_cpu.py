@@ -25,7 +25,7 @@ def test_ga_master_worker(oracle, tmp_path):
     out = {}
     tm = threading.Thread(target=lambda: out.update(r=ga.run_master(cfg, str(tmp_path), exp, engine=me, noise=noise, max_iters=3)), daemon=True)
     tm.start()
-    ga.run_worker(cfg, cfg, noise, engine=we, max_tasks=3, seed=11)
+    ga.run_worker(cfg, cfg, noise, engine=we, max_tasks=3, seed=11, reeval_after=1e9)
     tm.join(timeout=300)
     assert not tm.is_alive()
     policy, population, score = out["r"]
@@ -56,7 +56,7 @@ def test_nses_master_worker(oracle, tmp_path):
     out = {}
     tm = threading.Thread(target=lambda: out.update(r=nses.run_master(cfg, str(tmp_path), exp, engine=me, noise=noise, max_iters=2)), daemon=True)
     tm.start()
-    nses.run_worker(cfg, cfg, noise, engine=we, max_tasks=2, seed=5)
+    nses.run_worker(cfg, cfg, noise, engine=we, max_tasks=2, seed=5, reeval_after=1e9)
     tm.join(timeout=300)
     assert not tm.is_alive()
     theta_dict, archive = out["r"]

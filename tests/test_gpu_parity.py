@@ -359,7 +359,7 @@ def test_ga_driver_on_device(hip, oracle, small_noise, tmp_path):
     out = {}
     tm = threading.Thread(target=lambda: out.update(r=ga.run_master(cfg, str(tmp_path), exp, engine=me, noise=noise, max_iters=2)), daemon=True)
     tm.start()
-    ga.run_worker(cfg, cfg, noise, engine=we, max_tasks=2, seed=3)
+    ga.run_worker(cfg, cfg, noise, engine=we, max_tasks=2, seed=3, reeval_after=1e9)
     tm.join(timeout=120)
     assert not tm.is_alive()
     policy, population, score = out["r"]
@@ -427,7 +427,7 @@ def test_nses_driver_on_device(hip, oracle, small_noise, tmp_path):
     try:
         tm = threading.Thread(target=lambda: out.update(r=nses.run_master(cfg, str(tmp_path), exp, engine=me, noise=noise, max_iters=2)), daemon=True)
         tm.start()
-        nses.run_worker(cfg, cfg, noise, engine=we, max_tasks=2, seed=9)
+        nses.run_worker(cfg, cfg, noise, engine=we, max_tasks=2, seed=9, reeval_after=1e9)
         tm.join(timeout=120)
     finally:
         dist.WorkerClient.push_result = orig_push

@@ -112,7 +112,7 @@ def test_run_master_run_worker_in_process(oracle, small_noise, tmp_path):
 
     tm = threading.Thread(target=master, daemon=True)
     tm.start()
-    es.run_worker(cfg, cfg, noise, engine=worker_engine, max_tasks=2, seed=7)
+    es.run_worker(cfg, cfg, noise, engine=worker_engine, max_tasks=2, seed=7, reeval_after=1e9)
     tm.join(timeout=120)
     assert not tm.is_alive()
     theta = out["policy"].get_trainable_flat()
@@ -168,3 +168,26 @@ def test_parse_cutoff():
     assert es.parse_cutoff("env_default")[0] is None
     with pytest.raises(NotImplementedError):
         es.parse_cutoff("bogus")
+
+
+def test_worker_reevaluates_when_the_master_needs_more(oracle, tmp_path):
+    """Liveness (es.py:230-265 collects until episodes_per_batch AND timesteps_per_batch): with an odd episodes_per_batch a
+    GPU worker's one shard of 2 * (9 // 2) = 8 episodes is not enough; the worker must deliver another shard for the same
+    task instead of waiting forever for a new one -- and the master and worker configurations differ, as in a real launch."""
+    from oracle_engine import OracleEngine
+    from dne_hip import dist, es
+    dist.reset_brokers()
+    exp = _exp(pop=9, tslimit=6)
+    noise = es.SharedNoiseTable(count=2_500_000)
+    me, we = OracleEngine(0, ref_count=16), OracleEngine(0, ref_count=16)
+    mcfg, rcfg = {"host": "127.0.0.1", "port": 1, "transport": "inprocess"}, {"unix_socket_path": "/tmp/dne_relay_x.sock"}
+    out = {}
+    tm = threading.Thread(target=lambda: out.update(p=es.run_master(mcfg, str(tmp_path), exp, engine=me, noise=noise, max_iters=1, seed=0)),
+                          daemon=True)
+    tm.start()
+    tw = threading.Thread(target=lambda: es.run_worker(mcfg, rcfg, noise, engine=we, seed=7, reeval_after=0.05), daemon=True)   # max_tasks=None: loops like a reference worker
+    tw.start()
+    tm.join(timeout=120)
+    assert not tm.is_alive(), "master still waiting: the worker never delivered a second shard"
+    assert [c[0] for c in we.calls].count("es_eval") >= 2
+    assert [c for c in me.calls if c[0] == "es_update"][0][1] >= 8       # the update saw both shards' pairs
