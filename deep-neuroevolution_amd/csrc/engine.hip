@@ -294,7 +294,7 @@ struct dne_handle {
     double *partial = nullptr;
     uint8_t *ref = nullptr; bool ref_set = false;
     int32_t *m_slot = nullptr; int64_t *m_off = nullptr; float *m_scale = nullptr;
-    float *bn = nullptr;
+    float *bn = nullptr, *bn_mom = nullptr;
     uint8_t *ram_prev = nullptr, *ram_cur = nullptr, *stacks = nullptr;
     ResizeLds *tables = nullptr;
     float *ret = nullptr, *sign = nullptr, *step_reward = nullptr, *logits = nullptr;
@@ -384,7 +384,7 @@ struct dne_handle {
     FwdArgs fwd(bool use_done) const {
         FwdArgs A;
         A.noise = noise; A.bases = bases; A.base_stride = base_stride;
-        A.m_slot = m_slot; A.m_off = m_off; A.m_scale = m_scale; A.bn = bn;
+        A.m_slot = m_slot; A.m_off = m_off; A.m_scale = m_scale; A.bn = bn; A.bn_mom = bn_mom;
         A.done = use_done ? done : nullptr; A.L = L;
         return A;
     }
@@ -602,7 +602,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(h->alloc(&h->m_slot, M, "m_slot")); CH(h->alloc(&h->m_off, M, "m_off")); CH(h->alloc(&h->m_scale, M, "m_scale"));
     CH(hipMemset(h->m_slot, 0, M * sizeof(int32_t))); CH(hipMemset(h->m_off, 0, M * sizeof(int64_t)));
     CH(hipMemset(h->m_scale, 0, M * sizeof(float)));
-    CH(h->alloc(&h->bn, M * 608, "bn"));
+    CH(h->alloc(&h->bn, M * 608, "bn")); CH(h->alloc(&h->bn_mom, M * 608, "bn_mom"));
     CH(h->alloc(&h->ram_prev, M * 128, "ram_prev")); CH(h->alloc(&h->ram_cur, M * 128, "ram_cur")); CH(h->alloc(&h->stacks, M * OB_BYTES, "stacks"));
     CH(hipMemset(h->stacks, 0, M * OB_BYTES));
     CH(h->alloc(&h->tables, 1, "tables"));
@@ -1017,6 +1017,17 @@ extern "C" int dne_get_bn(dne_handle *h, int n, float *out) {
     if (check_n(h, n)) return -1;
     HCHECK(h, hipStreamSynchronize(h->stream));
     HCHECK(h, hipMemcpy(out, h->bn, (size_t)n * 608 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// the batch moments of the last reference pass (tf.contrib.layers.batch_norm with decay = 0 leaves exactly these in
+// moving_mean / moving_variance, policies.py:322-328): [n][608] = mean1[16] var1[16] mean2[32] var2[32] mean3[256] var3[256]
+extern "C" int dne_get_bn_moments(dne_handle *h, int n, float *out) {
+    DeviceGuard dg(h);
+    if (check_n(h, n)) return -1;
+    if (h->L.kind != DNE_KIND_ES) return h->fail("dne_get_bn_moments: GAAtariPolicy has no batch norm");
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    HCHECK(h, hipMemcpy(out, h->bn_mom, (size_t)n * 608 * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -33,6 +33,7 @@ struct FwdArgs {
     const int64_t *m_off;
     const float *m_scale;
     float *bn;               // [members][608]: s1[16] h1[16] s2[32] h2[32] s3[256] h3[256]
+    float *bn_mom;           // [members][608]: the batch moments behind them, mean / variance in the same layout (snapshots)
     const int32_t *done;     // per member, step mode only
     Layout L;
 };
@@ -877,6 +878,8 @@ __global__ __launch_bounds__(256) void k_bn3_partials(FwdArgs A, int member0, in
     const float ms = mean * s;
     A.bn[(size_t)member * 608 + 96 + j] = s;
     A.bn[(size_t)member * 608 + 352 + j] = beta - ms;
+    A.bn_mom[(size_t)member * 608 + 96 + j] = mean;
+    A.bn_mom[(size_t)member * 608 + 352 + j] = var;
 }
 
 // ------------------------------------------------------------ fc for small active counts (the tail)
@@ -1226,6 +1229,8 @@ __global__ __launch_bounds__(256) void k_bn_finalize(FwdArgs A, int member0, int
     const float ms = mean * s;
     A.bn[(size_t)member * 608 + bn_off + c] = s;
     A.bn[(size_t)member * 608 + bn_off + C + c] = beta - ms;
+    A.bn_mom[(size_t)member * 608 + bn_off + c] = mean;
+    A.bn_mom[(size_t)member * 608 + bn_off + C + c] = var;
 }
 
 // -------------------------------------------------------------- virtual batch norm statistics
@@ -1293,6 +1298,8 @@ __global__ __launch_bounds__(256) void k_bn_stats(FwdArgs A, int member0, int F,
         const float ms = mean * s;
         A.bn[(size_t)member * 608 + bn_off + tid] = s;
         A.bn[(size_t)member * 608 + bn_off + C + tid] = beta - ms;
+        A.bn_mom[(size_t)member * 608 + bn_off + tid] = mean;
+        A.bn_mom[(size_t)member * 608 + bn_off + C + tid] = var;
     }
 }
 

@@ -219,6 +219,11 @@ class Engine:
         self._ck(self.lib.dne_get_bn(self.h, int(n), _ptr(out, C.c_float)))
         return out
 
+    def get_bn_moments(self, n):
+        out = np.empty((n, BN_FLOATS), np.float32)
+        self._ck(self.lib.dne_get_bn_moments(self.h, int(n), _ptr(out, C.c_float)))
+        return out
+
     def act(self, n):
         actions = np.empty(n, np.int32); logits = np.empty((n, self.n_actions), np.float32)
         self._ck(self.lib.dne_act(self.h, int(n), _ptr(actions, C.c_int32), _ptr(logits, C.c_float)))

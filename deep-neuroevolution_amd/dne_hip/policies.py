@@ -173,26 +173,92 @@ class Policy:
             return rews, len(rews), np.array(obs), nov
         return rews, len(rews), nov
 
-    # policies.py:49-67 (h5py is not available here: same content in an .npz container)
-    def save(self, filename):
+    # ---- snapshots, policies.py:49-67
+    def variable_arrays(self):
+        """{TF variable name: array} for every variable the reference's Policy.save writes (policies.py:52-53:
+        `for v in self.all_variables: f[v.name] = v.eval()`), e.g. 'ESAtariPolicy/conv1/weights:0'."""
         flat = self.get_trainable_flat()
-        arrays = {name: flat[off:off + int(np.prod(shape))].reshape(shape) for name, (off, shape) in self.spec.items()}
-        np.savez(filename, __name__=type(self).__name__,
-                 __args_and_kwargs__=np.void(pickle.dumps(((tuple(self.ob_space_shape), self.num_actions), self.kwargs), protocol=-1)),
-                 **{k.replace("/", "__"): v for k, v in arrays.items()})
+        scope = type(self).__name__
+        out = OrderedDict()
+        for name, (off, shape) in self.spec.items():
+            out['%s/%s:0' % (scope, name)] = flat[off:off + int(np.prod(shape))].reshape(shape).copy()
+        out.update(self.extra_variable_arrays(scope))
+        return out
+
+    def extra_variable_arrays(self, scope):
+        return {}
+
+    def save(self, filename):
+        """policies.py:49-57.  '.h5': the reference's HDF5 layout -- a dataset per TF variable name, attrs 'name' and
+        'args_and_kwargs' -- written through h5py when it is installed (it is not in this image); any other name (the
+        drivers use '.npz'): the same arrays, names and attributes in a numpy container, which tools/npz_to_h5.py
+        turns into the .h5 on a machine that has h5py."""
+        arrays = self.variable_arrays()
+        blob = pickle.dumps((((tuple(self.ob_space_shape), self.num_actions)), self.kwargs), protocol=-1)
+        if filename.endswith('.h5'):
+            try:
+                import h5py
+            except ImportError:
+                raise RuntimeError("writing '.h5' snapshots needs h5py (absent here): save to '.npz' and run "
+                                   "tools/npz_to_h5.py where h5py exists") from None
+            with h5py.File(filename, 'w', libver='latest') as f:
+                for k, v in arrays.items():
+                    f[k] = v
+                f.attrs['name'] = type(self).__name__
+                f.attrs['args_and_kwargs'] = np.void(blob)
+            return
+        np.savez(filename, __name__=type(self).__name__, __args_and_kwargs__=np.void(blob),
+                 __variables__=np.array(list(arrays.keys())), **{'var%03d' % i: v for i, v in enumerate(arrays.values())})
+
+    @staticmethod
+    def _read_snapshot(filename):
+        """-> (class name, (ob_shape, nact), kwargs, {variable name: array})"""
+        if filename.endswith('.h5'):
+            import h5py
+            with h5py.File(filename, 'r') as f:
+                args, kwargs = pickle.loads(f.attrs['args_and_kwargs'].tobytes())
+                arrays = {}
+                f.visititems(lambda n, o: arrays.__setitem__(n, o[...]) if isinstance(o, h5py.Dataset) else None)
+                name = f.attrs['name']
+            ob, ac = args[0], args[1]     # the reference pickles gym spaces; ours are (shape, n)
+            return name, (tuple(getattr(ob, 'shape', ob)), int(getattr(ac, 'n', ac))), kwargs, arrays
+        with np.load(filename, allow_pickle=False) as f:
+            (ob_shape, nact), kwargs = pickle.loads(f['__args_and_kwargs__'].tobytes())
+            names = [str(n) for n in f['__variables__']]
+            arrays = {n: f['var%03d' % i] for i, n in enumerate(names)}
+            return str(f['__name__']), (tuple(ob_shape), int(nact)), kwargs, arrays
 
     @classmethod
     def Load(cls, filename, engine=None, extra_kwargs=None):
-        with np.load(filename, allow_pickle=False) as f:
-            (ob_shape, nact), kwargs = pickle.loads(f["__args_and_kwargs__"].tobytes())
-            if extra_kwargs:
-                kwargs.update(extra_kwargs)
-            pol = cls(_Space(shape=ob_shape), _Space(n=nact), engine=engine, **kwargs)
-            flat = np.zeros(pol.num_params, np.float32)
-            for name, (off, shape) in pol.spec.items():
-                flat[off:off + int(np.prod(shape))] = f[name.replace("/", "__")].reshape(-1)
-        pol.set_trainable_flat(flat)
+        """policies.py:59-67"""
+        _, (ob_shape, nact), kwargs, arrays = cls._read_snapshot(filename)
+        if extra_kwargs:
+            kwargs.update(extra_kwargs)
+        pol = cls(_Space(shape=ob_shape), _Space(n=nact), engine=engine, **kwargs)
+        pol._set_from_arrays(arrays, exact=True)
         return pol
+
+    def _set_from_arrays(self, arrays, exact):
+        scope = type(self).__name__
+        flat = self.get_trainable_flat() if not exact else np.zeros(self.num_params, np.float32)
+        for name, (off, shape) in self.spec.items():
+            a = np.asarray(arrays['%s/%s:0' % (scope, name)], np.float32)
+            if exact:
+                assert a.shape == shape, (name, a.shape, shape)
+            else:   # policies.py:355-369: the loaded arrays may be smaller; they fill the leading sub-array
+                assert a.ndim == len(shape) and all(x >= y for x, y in zip(shape, a.shape)), \
+                    'This policy must have more weights than the policy to load'
+            view = flat[off:off + int(np.prod(shape))].reshape(shape)
+            view[tuple(slice(0, n) for n in a.shape)] = a
+        self.set_trainable_flat(flat)
+
+    def initialize_from(self, filename):
+        """policies.py:345-372: weights from another policy of the same architecture (variable names), whose arrays may
+        be smaller than this policy's."""
+        _, _, _, arrays = self._read_snapshot(filename)
+        mine = set(self.variable_arrays().keys())
+        assert mine == set(arrays.keys()), 'Variable names do not match'
+        self._set_from_arrays(arrays, exact=False)
 
 
 class ESAtariPolicy(Policy):
@@ -216,6 +282,25 @@ class ESAtariPolicy(Policy):
 
     def initialize(self, seed=0):
         self.set_trainable_flat(xavier_flat(self.num_actions, seed))
+
+    def extra_variable_arrays(self, scope):
+        """BatchNorm*/moving_mean, moving_variance (policies.py:322-328: batch_norm(decay=0., updates_collections=None)
+        overwrites them with the batch moments of every is_training pass, i.e. of the reference batch).  The engine
+        computes those moments in its reference pass for the unperturbed theta; without an engine or a reference
+        batch they are TF's initial values (zeros / ones)."""
+        n = {'BatchNorm': 16, 'BatchNorm_1': 32, 'BatchNorm_2': 256}
+        mom = None
+        if self.engine is not None and getattr(self, 'ref_batch', None) is not None and hasattr(self.engine, 'get_bn_moments'):
+            e = self.engine
+            e.set_members(np.zeros(1, np.int32), np.zeros(1, np.int64), np.zeros(1, np.float32))
+            e.ref_pass(1)
+            mom = e.get_bn_moments(1)[0]
+        out, off = OrderedDict(), 0
+        for bn, c in n.items():
+            out['%s/%s/moving_mean:0' % (scope, bn)] = mom[off:off + c].copy() if mom is not None else np.zeros(c, np.float32)
+            out['%s/%s/moving_variance:0' % (scope, bn)] = mom[off + c:off + 2 * c].copy() if mom is not None else np.ones(c, np.float32)
+            off += 2 * c
+        return out
 
 
 class GAAtariPolicy(Policy):

@@ -112,6 +112,9 @@ int dne_env_set_ram(dne_handle *h, int n, const uint8_t *ram_prev /*[n][128]*/, 
 int dne_set_members(dne_handle *h, int n, const int32_t *base_slot, const int64_t *noise_off, const float *scale);
 int dne_ref_pass(dne_handle *h, int n);                                   /* policies.py:399 (ES only) */
 int dne_get_bn(dne_handle *h, int n, float *out /*[n][608] scale,shift per layer*/);
+/* the batch moments behind them: what batch_norm(decay=0) leaves in moving_mean / moving_variance (policies.py:322-328),
+ * i.e. the moving_mean / moving_variance datasets of a snapshot (policies.py:49-57); [n][608] mean,variance per layer */
+int dne_get_bn_moments(dne_handle *h, int n, float *out);
 int dne_act(dne_handle *h, int n, int32_t *actions, float *logits /*[n][n_actions] or NULL*/);
 int dne_debug_activations(dne_handle *h, int member, float *y1 /*7056*/, float *y2 /*3872*/, float *y3 /*256*/);
 

@@ -209,7 +209,7 @@ int orc_act(const orc_layout *L, const float *th, const float *bn, const uint8_t
  * summation order fixed as: per frame a sequential sum over positions, then a
  * sequential sum over frames.  y: [nref][npos][C].  decay=0 => moving stats := batch stats. */
 static void bn_finish(const float *y, int nref, int npos, int C, const float *beta, const float *gamma,
-                      float *scale, float *shift) {
+                      float *scale, float *shift, float *mean_out, float *var_out) {
     const float count = (float)(nref * npos);
     for (int c = 0; c < C; c++) {
         float tot = 0.0f;
@@ -236,6 +236,7 @@ static void bn_finish(const float *y, int nref, int npos, int C, const float *be
         float ms = mean * sc;
         scale[c] = sc;
         shift[c] = beta[c] - ms;
+        if (mean_out) { mean_out[c] = mean; var_out[c] = var; }
     }
 }
 
@@ -252,7 +253,7 @@ static void bn_finish(const float *y, int nref, int npos, int C, const float *be
  *   batch:  S = sum over frames in order, from 0.
  * raw: [nref][npos][C] pre-bias sums. */
 static void bn_finish_tiles(const float *raw, int nref, int npos, int C, int interleaved, const float *bias,
-                            const float *beta, const float *gamma, float *scale, float *shift) {
+                            const float *beta, const float *gamma, float *scale, float *shift, float *mean_out, float *var_out) {
     const int ntile = (npos + 15) / 16, ngroups = interleaved ? 4 : 2;
     const float count = (float)(nref * npos);
     for (int c = 0; c < C; c++) {
@@ -307,10 +308,13 @@ static void bn_finish_tiles(const float *raw, int nref, int npos, int C, int int
         float ms = mean * sc;
         scale[c] = sc;
         shift[c] = beta[c] - ms;
+        if (mean_out) { mean_out[c] = mean; var_out[c] = var; }
     }
 }
 
-void orc_es_ref_pass(const orc_layout *L, const float *th, const uint8_t *ref, int nref, float *bn) {
+/* mom (may be NULL): the batch moments themselves, mean / variance in bn's layout -- what batch_norm(decay=0)
+ * leaves in moving_mean / moving_variance (policies.py:322-328) */
+void orc_es_ref_pass_moments(const orc_layout *L, const float *th, const uint8_t *ref, int nref, float *bn, float *mom) {
     float *y1 = (float *)malloc(sizeof(float) * (size_t)nref * 7056);
     float *y2 = (float *)malloc(sizeof(float) * (size_t)nref * 3872);
     float *y3 = (float *)malloc(sizeof(float) * (size_t)nref * 256);
@@ -318,18 +322,22 @@ void orc_es_ref_pass(const orc_layout *L, const float *th, const uint8_t *ref, i
     float *a = (float *)malloc(sizeof(float) * 7056);
     for (int n = 0; n < nref; n++)
         conv1_raw_acc(th + L->c1w, th + L->c1b, ref + (size_t)n * ORC_OB_BYTES, y1 + (size_t)n * 7056, raw + (size_t)n * 7056);
-    bn_finish_tiles(raw, nref, 441, 16, 1, th + L->c1b, th + L->bn1b, th + L->bn1g, bn, bn + 16);
+    bn_finish_tiles(raw, nref, 441, 16, 1, th + L->c1b, th + L->bn1b, th + L->bn1g, bn, bn + 16, mom, mom ? mom + 16 : NULL);
     for (int n = 0; n < nref; n++) {
         for (int i = 0; i < 7056; i++) a[i] = bn_relu(y1[(size_t)n * 7056 + i], bn, bn + 16, i & 15);
         conv2_raw_acc(th + L->c2w, th + L->c2b, a, y2 + (size_t)n * 3872, raw + (size_t)n * 3872);
     }
-    bn_finish_tiles(raw, nref, 121, 32, 0, th + L->c2b, th + L->bn2b, th + L->bn2g, bn + 32, bn + 64);
+    bn_finish_tiles(raw, nref, 121, 32, 0, th + L->c2b, th + L->bn2b, th + L->bn2g, bn + 32, bn + 64, mom ? mom + 32 : NULL, mom ? mom + 64 : NULL);
     for (int n = 0; n < nref; n++) {
         for (int i = 0; i < 3872; i++) a[i] = bn_relu(y2[(size_t)n * 3872 + i], bn + 32, bn + 64, i & 31);
         fc_raw(th + L->fcw, th + L->fcb, a, y3 + (size_t)n * 256);
     }
-    bn_finish(y3, nref, 1, 256, th + L->bn3b, th + L->bn3g, bn + 96, bn + 352);   /* fc: 128 values per column, two passes */
+    bn_finish(y3, nref, 1, 256, th + L->bn3b, th + L->bn3g, bn + 96, bn + 352, mom ? mom + 96 : NULL, mom ? mom + 352 : NULL);   /* fc: 128 values per column, two passes */
     free(y1); free(y2); free(y3); free(a); free(raw);
+}
+
+void orc_es_ref_pass(const orc_layout *L, const float *th, const uint8_t *ref, int nref, float *bn) {
+    orc_es_ref_pass_moments(L, th, ref, nref, bn, NULL);
 }
 
 /* ----------------------------------------------------- SynthAtari (fixture) */

@@ -56,6 +56,7 @@ void orc_perturb(const float *theta, const float *noise, int64_t idx, float sigm
 
 /* A3  policies.py:319-330 (is_ref=True): batch moments of the reference batch -> per-channel scale/shift */
 void orc_es_ref_pass(const orc_layout *L, const float *theta, const uint8_t *ref, int nref, float *bn);
+void orc_es_ref_pass_moments(const orc_layout *L, const float *theta, const uint8_t *ref, int nref, float *bn, float *mom /*608 or NULL*/);
 /* A3/A4  single-observation act: returns argmax action; logits (nact floats) optional */
 int orc_act(const orc_layout *L, const float *theta, const float *bn, const uint8_t *ob, float *logits);
 /* intermediate activations for kernel-level parity tests (raw = pre-BN/pre-ReLU) */

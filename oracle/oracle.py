@@ -91,6 +91,15 @@ def es_ref_pass(L, theta, ref):
     return bn
 
 
+def es_ref_pass_moments(L, theta, ref):
+    """(bn scale/shift, batch mean/variance) of the reference pass"""
+    theta = _f32(theta)
+    ref = np.ascontiguousarray(ref, dtype=np.uint8)
+    bn = np.empty(BN_FLOATS, np.float32); mom = np.empty(BN_FLOATS, np.float32)
+    lib().orc_es_ref_pass_moments(C.byref(L), _p(theta, C.c_float), _p(ref, C.c_uint8), ref.shape[0], _p(bn, C.c_float), _p(mom, C.c_float))
+    return bn, mom
+
+
 def act(L, theta, bn, ob):
     theta = _f32(theta)
     ob = np.ascontiguousarray(ob, dtype=np.uint8)

@@ -186,7 +186,14 @@ class OracleEngine:
         self._obs = np.asarray(obs, np.uint8)
 
     def ref_pass(self, n):
-        self._bn = [O.es_ref_pass(self.L, self._member_theta(i), self.ref) for i in range(n)] if self.kind == O.KIND_ES else [None] * n
+        if self.kind != O.KIND_ES:
+            self._bn = [None] * n
+            return
+        both = [O.es_ref_pass_moments(self.L, self._member_theta(i), self.ref) for i in range(n)]
+        self._bn, self._mom = [b for b, _ in both], [m for _, m in both]
+
+    def get_bn_moments(self, n):
+        return np.stack(self._mom[:n])
 
     def act(self, n):
         acts, lgs = [], []

@@ -146,11 +146,13 @@ def test_forward_es_bit_exact(es_engine, oracle, small_noise, ref_batch):
     e.env_set_observation(obs)
     e.ref_pass(n)
     bn = e.get_bn(n)
+    mom = e.get_bn_moments(n)
     acts, logits = e.act(n)
     for i in range(n):
         thi = th + np.float32(scale[i]) * small_noise[off[i]:off[i] + L.P]
-        obn = O.es_ref_pass(L, thi, ref_batch)
+        obn, omom = O.es_ref_pass_moments(L, thi, ref_batch)
         assert np.array_equal(bn[i], obn), i
+        assert np.array_equal(mom[i], omom), i          # the moving_mean / moving_variance of a snapshot
         y1, y2, y3, lg = O.forward_debug(L, thi, obn, obs[i])
         g1, g2, g3 = e.debug_activations(i)
         assert np.array_equal(g1, y1), i

@@ -155,6 +155,35 @@ def test_policy_surface(oracle, small_noise, tmp_path):
     pol.save(fn)
     pol2 = policies.ESAtariPolicy.Load(fn, engine=OracleEngine(0, ref_count=16))
     assert np.array_equal(pol2.get_trainable_flat(), pol.get_trainable_flat())
+    # the snapshot holds exactly the reference's variables (policies.py:52-53 over tf.contrib.layers' names, policies.py:319-330)
+    arrays = pol.variable_arrays()
+    want = ["ESAtariPolicy/" + n + ":0" for n in (
+        "conv1/weights", "conv1/biases", "BatchNorm/beta", "BatchNorm/gamma", "BatchNorm/moving_mean", "BatchNorm/moving_variance",
+        "conv2/weights", "conv2/biases", "BatchNorm_1/beta", "BatchNorm_1/gamma", "BatchNorm_1/moving_mean", "BatchNorm_1/moving_variance",
+        "fc/weights", "fc/biases", "BatchNorm_2/beta", "BatchNorm_2/gamma", "BatchNorm_2/moving_mean", "BatchNorm_2/moving_variance",
+        "out/weights", "out/biases")]
+    assert sorted(arrays) == sorted(want)
+    assert arrays["ESAtariPolicy/conv1/weights:0"].shape == (8, 8, 4, 16) and arrays["ESAtariPolicy/out/weights:0"].shape == (256, 18)
+    _, mom = oracle.es_ref_pass_moments(oracle.layout(0, 18), pol.get_trainable_flat(), ref)
+    assert np.array_equal(arrays["ESAtariPolicy/BatchNorm/moving_mean:0"], mom[0:16])
+    assert np.array_equal(arrays["ESAtariPolicy/BatchNorm_1/moving_variance:0"], mom[64:96])
+    assert np.array_equal(arrays["ESAtariPolicy/BatchNorm_2/moving_mean:0"], mom[96:352])
+    assert (arrays["ESAtariPolicy/BatchNorm_2/moving_variance:0"] >= 0).all()
+    with np.load(fn) as f:
+        assert sorted(str(n) for n in f["__variables__"]) == sorted(want) and str(f["__name__"]) == "ESAtariPolicy"
+    with pytest.raises(RuntimeError):
+        pol.save(str(tmp_path / "snap.h5"))        # no h5py in this image: the error names the converter
+    # initialize_from (policies.py:345-372): a 14-action snapshot seeds the leading columns of an 18-action policy
+    small = policies.ESAtariPolicy(env.observation_space, policies._Space(n=14))
+    small.initialize(1)
+    small.save(str(tmp_path / "small.npz"))
+    before = pol.get_trainable_flat()
+    pol.initialize_from(str(tmp_path / "small.npz"))
+    after, sf = pol.get_trainable_flat(), small.get_trainable_flat()
+    o18, o14 = pol.spec["out/weights"][0], small.spec["out/weights"][0]
+    assert np.array_equal(after[:o18], sf[:o14])                                       # every layer before the head: taken over
+    assert np.array_equal(after[o18:o18 + 256 * 18].reshape(256, 18)[:, :14], sf[o14:o14 + 256 * 14].reshape(256, 14))
+    assert np.array_equal(after[o18:o18 + 256 * 18].reshape(256, 18)[:, 14:], before[o18:o18 + 256 * 18].reshape(256, 18)[:, 14:])
     ga = policies.GAAtariPolicy(env.observation_space, env.action_space, nonlin_type="relu", engine=OracleEngine(1))
     assert ga.num_params == 1008450 and not ga.needs_ref_batch
     with pytest.raises(NotImplementedError):
