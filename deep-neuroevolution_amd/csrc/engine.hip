@@ -626,7 +626,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     }
     CH(h->alloc(&h->list_a, M, "list_a")); CH(h->alloc(&h->list_b, M, "list_b")); CH(h->alloc(&h->count_dev, 8, "count_dev"));
     if (cfg->record_bc) {
-        h->bc_bytes = cfg->policy_kind == DNE_KIND_ES ? M * (size_t)std::max(cfg->bc_max_steps, 1) * 128 : M * 128;
+        h->bc_bytes = cfg->policy_kind == DNE_KIND_ES && !cfg->bc_final_only ? M * (size_t)std::max(cfg->bc_max_steps, 1) * 128 : M * 128;
         CH(h->alloc(&h->bc, h->bc_bytes, "bc"));
         CH(hipMemset(h->bc, 0, h->bc_bytes));   // the emulator writes the RAM_LIVE bytes of a row; the other bytes of the 128 stay zero for good
     }
@@ -1116,7 +1116,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     if (bc_out && !h->bc) return h->fail("behaviour characterisations requested but the engine was created with record_bc = 0");
     const bool prof = h->cfg.profile_events != 0;
     // record_bc engines always record (the trajectories feed dne_novelty_batch on the device); bc_out only controls the download
-    const int bc_mode = h->bc ? (h->L.kind == DNE_KIND_ES ? 1 : 2) : 0;
+    const int bc_mode = h->bc ? (h->L.kind == DNE_KIND_ES && !h->cfg.bc_final_only ? 1 : 2) : 0;
     // rows past an episode's length are never read on the device (dne_novelty_batch takes the lengths); zero them only
     // when the whole buffer is about to be downloaded
     if (bc_mode == 1 && bc_out) HCHECK(h, hipMemsetAsync(h->bc, 0, (size_t)n * h->cfg.bc_max_steps * 128, h->stream));
@@ -1818,7 +1818,7 @@ extern "C" int dne_novelty(dne_handle *h, const uint8_t *archive, const int32_t 
 extern "C" int dne_novelty_batch(dne_handle *h, const uint8_t *archive, const int32_t *alen, int narch, int n,
                                  const int32_t *lengths, int k, double *out) {
     DeviceGuard dg(h);
-    if (h->L.kind != DNE_KIND_ES || !h->bc) return h->fail("dne_novelty_batch needs an ES engine created with record_bc = 1");
+    if (h->L.kind != DNE_KIND_ES || !h->bc || h->cfg.bc_final_only) return h->fail("dne_novelty_batch needs an ES engine created with record_bc = 1 (full trajectories)");
     if (check_n(h, n)) return -1;
     if (narch < 1 || k < 1) return h->fail("dne_novelty_batch: bad sizes");
     std::vector<int64_t> row0(narch);

@@ -42,8 +42,8 @@ def comm_unique_id():
 
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("device_id", "policy_kind", "n_actions", "max_members", "ref_count",
-                                         "ref_chunk", "record_bc", "bc_max_steps", "profile_events")] + \
-               [("reserved", C.c_int32 * 7)]
+                                         "ref_chunk", "record_bc", "bc_max_steps", "profile_events", "bc_final_only")] + \
+               [("reserved", C.c_int32 * 6)]
 
 
 class Profile(C.Structure):
@@ -96,14 +96,16 @@ class Engine:
     """One engine = one GPU.  Thin, typed wrapper; every method maps 1:1 onto a dne_* entry point."""
 
     def __init__(self, kind, n_actions=18, max_members=256, ref_count=128, device_id=0, ref_chunk=0,
-                 record_bc=False, bc_max_steps=0, profile_events=False):
+                 record_bc=False, bc_max_steps=0, profile_events=False, bc_final_only=False):
         self.lib = load()
         self.kind, self.n_actions, self.max_members = int(kind), int(n_actions), int(max_members)
         self.ref_count = int(ref_count) if kind == KIND_ES else 0
         self.bc_max_steps = int(bc_max_steps)
         cfg = Config(device_id=device_id, policy_kind=self.kind, n_actions=self.n_actions, max_members=self.max_members,
                      ref_count=self.ref_count, ref_chunk=ref_chunk, record_bc=int(bool(record_bc)),
-                     bc_max_steps=self.bc_max_steps, profile_events=int(bool(profile_events)))
+                     bc_max_steps=self.bc_max_steps, profile_events=int(bool(profile_events)),
+                     bc_final_only=int(bool(bc_final_only)))
+        self.bc_final_only = bool(bc_final_only)
         self.h = C.c_void_p()
         rc = self.lib.dne_create(C.byref(cfg), C.byref(self.h))
         if rc != 0:
@@ -238,7 +240,7 @@ class Engine:
     def _bc_buf(self, n, want):
         if not want:
             return None
-        if self.kind == KIND_ES:
+        if self.kind == KIND_ES and not self.bc_final_only:
             return np.zeros((n, self.bc_max_steps, RAM_BYTES), np.uint8)
         return np.zeros((n, RAM_BYTES), np.uint8)
 

@@ -25,6 +25,9 @@ _FIELDS = {
     ('es_distributed.es', 'Result'): ['worker_id', 'noise_inds_n', 'returns_n2', 'signreturns_n2', 'lengths_n2',
                                       'eval_return', 'eval_length', 'ob_sum', 'ob_sumsq', 'ob_count'],
     ('es_distributed.ga', 'GATask'): ['params', 'population', 'ob_mean', 'ob_std', 'timestep_limit'],
+    # es_modified.py:18-23: the VINE variant's Result carries the behaviour characterisations
+    ('es_distributed.es_modified', 'Result'): ['worker_id', 'noise_inds_n', 'returns_n2', 'signreturns_n2', 'lengths_n2',
+                                               'eval_return', 'eval_length', 'ob_sum', 'ob_sumsq', 'ob_count', 'bc_vectors'],
 }
 
 
@@ -76,3 +79,4 @@ Config = _wire_type('es_distributed.es', 'Config')
 Task = _wire_type('es_distributed.es', 'Task')
 Result = _wire_type('es_distributed.es', 'Result')
 GATask = _wire_type('es_distributed.ga', 'GATask')
+ModifiedResult = _wire_type('es_distributed.es_modified', 'Result')

@@ -172,7 +172,7 @@ class Batch:
     and the bookkeeping counters the reference logs (es.py:226-277)."""
 
     def __init__(self):
-        self.results, self.eval_rets, self.eval_lens, self.worker_ids = [], [], [], []
+        self.results, self.eval_rets, self.eval_lens, self.worker_ids, self.eval_results = [], [], [], [], []
         self.skipped = self.episodes = self.timesteps = 0
         self.all_episodes = self.all_timesteps = 0   # including stale tasks and eval jobs (EpisodesSoFar / TimestepsSoFar)
 
@@ -184,13 +184,13 @@ class Batch:
         return self.skipped / max(self.skipped + len(self.results), 1)
 
 
-def collect_batch(master, config, task_id, check_pairs=True):
+def collect_batch(master, config, task_id, check_pairs=True, result_type=None):
     """Pop Results until both episodes_per_batch and timesteps_per_batch are met (es.py:230-265): results of
     older tasks are counted but dropped, eval jobs are kept apart, shapes/dtypes asserted like the reference."""
     b = Batch()
     while b.episodes < config.episodes_per_batch or b.timesteps < config.timesteps_per_batch:
         tid, res = master.pop_result()
-        assert isinstance(tid, int) and isinstance(res, Result)
+        assert isinstance(tid, int) and isinstance(res, result_type or Result)
         assert (res.eval_return is None) == (res.eval_length is None)
         b.worker_ids.append(res.worker_id)
         if res.eval_length is not None:                   # an evaluation episode of the unperturbed theta
@@ -199,6 +199,7 @@ def collect_batch(master, config, task_id, check_pairs=True):
             if tid == task_id:
                 b.eval_rets.append(res.eval_return)
                 b.eval_lens.append(res.eval_length)
+                b.eval_results.append(res)
             continue
         if check_pairs:                                   # es.py:246-248
             assert res.noise_inds_n.ndim == 1
@@ -229,10 +230,12 @@ def log_generation(tlogger, rows):
     tlogger.dump_tabular()
 
 
-def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_iters=None, seed=0):
+def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_iters=None, seed=0, result_type=None,
+               on_generation=None):
     """es.py:141-353.  Same protocol: declare a task -> collect Results -> process returns -> aggregate ->
     optimizer step, with the reduce running on the device (dne_es_update).  max_iters (extension) lets tests
-    stop the otherwise endless loop."""
+    stop the otherwise endless loop.  result_type / on_generation(task_id, batch, policy) are the seams es_modified.py
+    uses (a Result with bc_vectors; the per-generation dumps)."""
     from . import tabular_logger as tlogger
     logger.info('run_master: {}'.format(locals()))
     tlogger.start(log_dir)
@@ -260,7 +263,9 @@ def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_i
         task_id = master.declare_task(Task(params=theta, ob_mean=None, ob_std=None, timestep_limit=tslimit,
                                            ref_batch=policy.ref_batch if policy.needs_ref_batch else None))
         tlogger.log('********** Iteration {} **********'.format(task_id))
-        batch = collect_batch(master, config, task_id)
+        batch = collect_batch(master, config, task_id, result_type=result_type)
+        if on_generation is not None:      # es_modified.py:332-333 dumps before the update
+            on_generation(task_id, batch, policy)
         episodes_so_far += batch.all_episodes
         timesteps_so_far += batch.all_timesteps
         noise_inds_n, returns_n2 = batch.cat('noise_inds_n'), batch.cat('returns_n2')

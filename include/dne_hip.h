@@ -46,7 +46,9 @@ typedef struct {
     int32_t record_bc;    /* 1: keep behaviour characterisations (ES: RAM per step, GA: final RAM) */
     int32_t bc_max_steps; /* ES BC capacity in steps per member (<= timestep limit) */
     int32_t profile_events; /* 1: bracket hot kernels with HIP events (dne_get_profile) */
-    int32_t reserved[7];
+    int32_t bc_final_only;  /* ES with record_bc: keep only each member's final RAM ([members][128], what es_modified.py's
+                               dumps use: bc_vec[-1], es_modified.py:176,197) instead of the whole trajectory */
+    int32_t reserved[6];
 } dne_config;
 
 typedef struct { /* filled by dne_get_profile; times from HIP events on the engine's stream */

@@ -12,6 +12,7 @@ class OracleEngine:
         self.L = O.layout(kind, n_actions)
         self.P = self.L.P
         self.bc_max_steps = kw.get("bc_max_steps", 0)
+        self.bc_final_only = kw.get("bc_final_only", False)
         self.theta = np.zeros(self.P, np.float32)
         self.noise = None
         self.ref = None
@@ -48,6 +49,17 @@ class OracleEngine:
 
     def es_eval(self, idx, sigma, tslimit, seeds, want_bc=False):
         self.calls.append(("es_eval", len(idx)))
+        if self.bc_final_only and want_bc:
+            n = len(idx)
+            ret = np.zeros((n, 2), np.float32); sg = np.zeros((n, 2), np.float32); ln = np.zeros((n, 2), np.int32)
+            bc = np.zeros((2 * n, 128), np.uint8)
+            for i in range(n):
+                for s in range(2):
+                    th = O.perturb(self.theta, self.noise, idx[i], sigma, 1 if s == 0 else -1)
+                    ret[i, s], sg[i, s], ln[i, s], traj = O.rollout(self.L, th, self.ref, seeds[2 * i + s], tslimit, want_bc=True)
+                    bc[2 * i + s] = traj[-1]
+            self._last = (np.asarray(idx, np.int64), ret, sg, ln)
+            return ret, sg, ln, bc
         if not self.bc_max_steps:
             out = O.es_eval(self.L, self.theta, self.noise, idx, sigma, tslimit, self.ref, seeds)
             self._last = (np.asarray(idx, np.int64),) + tuple(out)
@@ -69,6 +81,8 @@ class OracleEngine:
         l = np.array([o[2] for o in out], np.int32)
         if not want_bc:
             return r, s, l
+        if self.kind == O.KIND_ES and self.bc_final_only:
+            return r, s, l, np.stack([o[3][-1] for o in out])
         if self.kind == O.KIND_ES:
             bc = np.zeros((n, max(self.bc_max_steps, int(l.max())), 128), np.uint8)
             for i, o in enumerate(out):

@@ -1,5 +1,6 @@
 """CPU: the GA and NS-ES driver mirrors (dne_hip/ga.py, dne_hip/nses.py) over the in-process transport with the
 oracle standing in for the GPU engine -- protocol, chain bookkeeping, truncation, novelty plumbing."""
+import os
 import threading
 
 import numpy as np
@@ -63,3 +64,47 @@ def test_nses_master_worker(oracle, tmp_path):
     assert len(theta_dict) == 2 and len(archive) == 2 + 2      # pop_size initial BCs + one per iteration (nses.py:112,247)
     assert all(a.dtype == np.uint8 and a.shape[1] == 128 and 1 <= a.shape[0] <= 10 for a in archive)
     assert any(not np.array_equal(theta_dict[p], __import__("dne_hip.policies", fromlist=["x"]).xavier_flat(18, p)) for p in (0, 1))
+
+
+def test_es_modified_vine_dumps(oracle, tmp_path):
+    """es_modified.py:140-199: per generation the parent snapshot + reference batch, the parent point and the offspring cloud
+    in the reference's row format; every row is reproducible from its (noise_idx, policy_seed, sign) -- the point of the
+    policy seeds (policies.py:392-396)."""
+    import pickle
+    from oracle_engine import OracleEngine
+    from dne_hip import dist, es, es_modified, policies
+    dist.reset_brokers()
+    exp = {"config": {"calc_obstat_prob": 0.0, "episodes_per_batch": 6, "eval_prob": 1.0, "l2coeff": 0.005, "noise_stdev": 0.02,
+                      "snapshot_freq": 0, "timesteps_per_batch": 10, "return_proc_mode": "centered_rank", "episode_cutoff_mode": 14},
+           "env_id": "FrostbiteNoFrameskip-v4", "optimizer": {"args": {"stepsize": 0.01}, "type": "adam"},
+           "policy": {"args": {}, "type": "ESAtariPolicy"}}
+    noise = es.SharedNoiseTable(count=2_500_000)
+    me, we = OracleEngine(0, ref_count=16), OracleEngine(0, ref_count=16, bc_final_only=True)
+    cfg = {"unix_socket_path": "/tmp/test_vine.sock", "transport": "inprocess"}
+    root = str(tmp_path / "snapshots")
+    out = {}
+    tm = threading.Thread(target=lambda: out.update(p=es_modified.run_master(cfg, str(tmp_path), exp, engine=me, noise=noise, max_iters=2,
+                                                                            seed=0, snapshot_root=root)), daemon=True)
+    tm.start()
+    es_modified.run_worker(cfg, cfg, noise, engine=we, max_tasks=2, seed=4, reeval_after=1e9)
+    tm.join(timeout=300)
+    assert not tm.is_alive()
+    L = oracle.layout(0, 18)
+    theta0 = policies.xavier_flat(18, 0)
+    for gen in range(2):
+        d = os.path.join(root, "snapshot_gen_%04d" % gen)
+        assert os.path.exists(os.path.join(d, "snapshot_parent_%04d.npz" % gen))
+        ref = np.asarray(pickle.load(open(os.path.join(d, "snapshot_parent_%04d_rb.p" % gen), "rb")))
+        assert ref.shape == (16, 84, 84, 4)
+        cloud = np.loadtxt(os.path.join(d, "snapshot_offspring_%04d.dat" % gen))
+        assert cloud.shape == (6, 128 + 5)                                    # 3 pairs x 2 rollouts; RAM, fitness, length, idx, seed, sign
+        assert set(cloud[:, -1]) == {1.0, -1.0} and len(set(cloud[cloud[:, -1] == 1, -2])) == 1   # one + seed, one - seed per iteration
+        parent = np.loadtxt(os.path.join(d, "snapshot_parent_%04d.dat" % gen))
+        assert parent.shape == (128 + 4,) and parent[-1] == 0.02
+        if gen == 0:   # replay two offspring rows and the parent row with the oracle
+            for row in (cloud[0], cloud[3]):
+                th = oracle.perturb(theta0, noise.noise, int(row[-3]), 0.02, int(row[-1]))
+                r, s, l, traj = oracle.rollout(L, th, me.ref, int(row[-2]), 14, want_bc=True)
+                assert r == row[128] and l == row[129] and np.array_equal(traj[-1], row[:128].astype(np.uint8))
+            r, s, l, traj = oracle.rollout(L, theta0, me.ref, int(parent[-2]), 14, want_bc=True)
+            assert r == parent[128] and l == parent[129] and np.array_equal(traj[-1], parent[:128].astype(np.uint8))

@@ -597,3 +597,30 @@ def test_debug_sync_and_trace_knobs(hip, oracle, small_noise, ref_batch, monkeyp
         e.close()
     err = capfd.readouterr().err
     assert "engine created" in err and "reference pass done" in err and "lock-step" in err
+
+
+def test_es_final_ram_only(hip, oracle, small_noise, ref_batch):
+    """bc_final_only engines (es_modified.py's dumps use bc_vec[-1]): the final RAM of every member, policy-seeded rollouts."""
+    O = oracle
+    L = O.layout(O.KIND_ES, NACT)
+    e = hip.Engine(hip.KIND_ES, NACT, max_members=16, ref_count=NREF, record_bc=True, bc_final_only=True)
+    try:
+        e.noise_upload(small_noise)
+        th = O.es_init_theta(L, 0)
+        e.set_theta(th); e.set_ref_batch(ref_batch)
+        idx = np.array([3, 500_000, 2_000_000], np.int64)
+        seeds = np.tile(np.array([777, 888], np.uint32), 3)          # one policy seed for all + rollouts, one for all -
+        ret, sg, ln, bc = e.es_eval(idx, 0.02, 60, seeds, want_bc=True)
+        assert bc.shape == (6, 128)
+        for i in range(3):
+            for s, sign in enumerate((1, -1)):
+                r, q, l, traj = O.rollout(L, O.perturb(th, small_noise, idx[i], 0.02, sign), ref_batch, seeds[2 * i + s], 60, want_bc=True)
+                assert (r, q, l) == (ret[i, s], sg[i, s], ln[i, s]) and np.array_equal(bc[2 * i + s], traj[-1])
+        e.set_members(np.zeros(1, np.int32), np.zeros(1, np.int64), np.zeros(1, np.float32))
+        r1, _, l1, b1 = e.eval_members(1, 60, np.array([4242], np.uint32), want_bc=True)
+        r2, _, l2, b2 = e.eval_members(1, 60, np.array([4242], np.uint32), want_bc=True)
+        assert (r1, l1) == (r2, l2) and np.array_equal(b1, b2) and b1.shape == (1, 128)      # same policy seed -> same episode
+        with pytest.raises(Exception):
+            e.novelty_batch([np.zeros((3, 128), np.uint8)], ln, 1)                           # needs full trajectories
+    finally:
+        e.close()
