@@ -981,7 +981,7 @@ static int ref_pass(dne_handle *h, int n) {
         hipLaunchKernelGGL((k_bn_finalize<32>), dim3((nc * 32 + 255) / 256), dim3(256), 0, st, A, m0, nc, F, (const float *)fr2, 121, 32,
                            h->L.c2b, h->L.bn2b, h->L.bn2g);
         if (F == 16 || F == 32 || F == 64 || F == 128) {   // matrix-core path
-            const int grid = (nc + 7) / 8 * 8 * 16;
+            const int grid = (nc + 7) / 8 * 8 * 4;   // (member, k-slice) workgroups, the four of a member on one XCD
 #define FCREF(MT) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid), dim3(256), 0, st, A, nc, m0, (const float *)y2, y3p)
             if (F == 16) FCREF(1); else if (F == 32) FCREF(2); else if (F == 64) FCREF(4); else FCREF(8);
 #undef FCREF

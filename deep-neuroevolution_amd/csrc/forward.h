@@ -293,7 +293,9 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
     const Item it = decode_item(blockIdx.x / nsplit, list, gsize, F, member0, nullptr, nullptr, A.done);
     if (it.skip) return;
     constexpr int PS = 17;   // LDS pixel stride (16 channels + 1 pad)
-    __shared__ float a_s[24 * 24 * PS];
+    constexpr int RW = 27;   // LDS row width in pixels (24 used): 2 * RW * PS = 22 mod 32 continues the 2-per-position bank
+                             // sequence across output rows, so the 16 positions of an MFMA tile never share a bank
+    __shared__ float a_s[24 * RW * PS];
     __shared__ float wsum[4][2][16];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
     const int nt = wv & 1, mt0 = 4 * (wv >> 1);
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
         const int y = pix / 24, x = pix % 24;
         if (y < 1 || y > 21 || x < 1 || x > 21)
 #pragma unroll
-            for (int c = 0; c < 16; c++) a_s[pix * PS + c] = 0.0f;
+            for (int c = 0; c < 16; c++) a_s[(y * RW + x) * PS + c] = 0.0f;
     }
 #pragma unroll
     for (int j = 0; j < 28; j++) {
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
                 t = t + h1;
             }
             t = t > 0.0f ? t : 0.0f;
-            a_s[((pix / 21 + 1) * 24 + pix % 21 + 1) * PS + c] = t;
+            a_s[((pix / 21 + 1) * RW + pix % 21 + 1) * PS + c] = t;
         }
     }
     __syncthreads();
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
 #pragma unroll
         for (int m = 0; m < NTL; m++) {
             const int p = min((mtb + m) * 16 + lp, 120);
-            off[m] = ((p / 11) * 2 * 24 + (p % 11) * 2) * PS + lk;
+            off[m] = ((p / 11) * 2 * RW + (p % 11) * 2) * PS + lk;
             acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
                     const int kk = (kh * 4 + kw) * 4 + c4;
 #pragma unroll
                     for (int m = 0; m < NTL; m++) {
-                        const float x = a_s[off[m] + (kh * 24 + kw) * PS + c4 * 4];
+                        const float x = a_s[off[m] + (kh * RW + kw) * PS + c4 * 4];
                         acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, b[kk], acc[m], 0, 0, 0);
                     }
                 }
@@ -760,23 +762,28 @@ __global__ __launch_bounds__(256) void k_fc2(FwdArgs A, const int *__restrict__ 
 template <int MT>
 __global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int member0, const float *__restrict__ y2,
                                                 float *__restrict__ y3p /*[n_local][4][F][256]*/) {
-    constexpr int F = MT * 16, KC = 44, XS = KC + 1, NST = 968 / KC, KK = KC / 4;
+    // One workgroup per (member, k-slice); wave w owns columns 64w .. 64w+63 as four interleaved 16-column MFMA tiles
+    // (tile c = columns 64w + 4*lane + c), so a lane's four B operands of a k-row are one 16-byte load and the member's
+    // activations and weights each cross the memory system once.  8-row stages through a double-buffered LDS tile.
+    constexpr int F = MT * 16, KC = 8, XS = KC + 2, NST = 968 / KC, KK = KC / 4;   // XS = 10: lanes (frame, k) of a half-wave hit 32 distinct banks
     constexpr int LD = (F * KC + 255) / 256;
     __shared__ float xs[2][F * XS];
     __shared__ float bn2[64];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
     const Layout &L = A.L;
-    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int mloc = (q >> 4) * 8 + x, sub = q & 15, sl = sub >> 2, cs = sub & 3;
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;          // the four slices of a member stay on one XCD (block b -> XCD b % 8)
+    const int mloc = (q >> 2) * 8 + x, sl = q & 3;
     if (mloc >= n_local) return;
     const int member = member0 + mloc;
     const float sc = A.m_scale[member];
-    const int kbeg = 968 * sl, col = cs * 64 + wv * 16 + lp;
-    const float *eps = A.noise + A.m_off[member] + L.fcw + (size_t)(kbeg + lk) * 256 + col;
-    const float *th = A.bases + (size_t)A.m_slot[member] * A.base_stride + L.fcw + (size_t)(kbeg + lk) * 256 + col;
+    const int kbeg = 968 * sl, col0 = 64 * wv + 4 * lp;
+    const float *eps = A.noise + A.m_off[member] + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
+    const float *th = A.bases + (size_t)A.m_slot[member] * A.base_stride + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
     const float *ysrc = y2 + (size_t)mloc * F * 3872 + kbeg;
     if (tid < 64) bn2[tid] = A.bn[(size_t)member * 608 + 32 + tid];   // scale[32] then shift[32]
-    float yr[LD], er[KK], tr[KK];
+    float yr[LD];
+    f4u er[KK];
+    f4a tr[KK];
     auto load_stage = [&](int st) {
 #pragma unroll
         for (int j = 0; j < LD; j++) {
@@ -786,8 +793,8 @@ __global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int memb
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
             const size_t ro = (size_t)(st * KC + 4 * kk) * 256;
-            er[kk] = eps[ro];
-            tr[kk] = th[ro];
+            er[kk] = *(const f4u *)(eps + ro);
+            tr[kk] = *(const f4a *)(th + ro);
         }
     };
     auto store_stage = [&](int st, int buf) {
@@ -802,15 +809,22 @@ __global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int memb
             }
         }
     };
-    f32x4 acc[MT];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int m = 0; m < MT; m++) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float w[KK][4];
+    auto form_w = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) { float pv = sc * er[kk][c]; w[kk][c] = tr[kk][c] + pv; }
+    };
     load_stage(0);
     __syncthreads();          // bn2 visible
     store_stage(0, 0);
-    float w[KK];
-#pragma unroll
-    for (int kk = 0; kk < KK; kk++) { float pv = sc * er[kk]; w[kk] = tr[kk] + pv; }
+    form_w();
     __syncthreads();
     for (int st = 0; st < NST; st++) {
         const int buf = st & 1;
@@ -820,21 +834,22 @@ __global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int memb
 #pragma unroll
             for (int m = 0; m < MT; m++) {
                 const float a = xs[buf][(m * 16 + lp) * XS + 4 * kk + lk];
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[kk], acc[m], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[kk][c], acc[m][c], 0, 0, 0);
             }
         }
         if (st + 1 < NST) {
             store_stage(st + 1, buf ^ 1);
-#pragma unroll
-            for (int kk = 0; kk < KK; kk++) { float pv = sc * er[kk]; w[kk] = tr[kk] + pv; }
+            form_w();
         }
         __syncthreads();
     }
-    float *out = y3p + ((size_t)(mloc * 4 + sl) * F) * 256 + col;
+    float *out = y3p + ((size_t)(mloc * 4 + sl) * F) * 256 + col0;
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) out[(size_t)(m * 16 + lk * 4 + r) * 256] = acc[m][r];
+        for (int r = 0; r < 4; r++)   // D[row = 4*(l>>4) + r][col = l&15] of tile c -> frame m*16 + 4*lk + r, column col0 + c
+            *(f32x4 *)(out + (size_t)(m * 16 + lk * 4 + r) * 256) = f32x4{acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
 }
 
 // bn3 statistics from the four k-slice partials: y3 = ((p0+p1)+(p2+p3)) + bias per frame, then the batch
