@@ -332,7 +332,12 @@ struct dne_handle {
     int64_t *rec_idx = nullptr; float *rec_ret = nullptr, *rec_sign = nullptr; int32_t *rec_len = nullptr;
     uint8_t *rec_send = nullptr, *rec_recv = nullptr; size_t rec_cap = 0, rec_wire_cap = 0; int rec_n = 0;
     std::vector<int64_t> rec_idx_host;
-    int64_t *chain_offs = nullptr; size_t chain_cap = 0;   // GA: the seed offsets of the chain being rebuilt
+    int64_t *chain_offs = nullptr; size_t chain_cap = 0;
+    // novelty archive resident on the device (dne_archive_append): rows of all entries back to back
+    uint8_t *arch = nullptr; size_t arch_cap = 0, arch_rows = 0; int arch_dim = 0;
+    int64_t *arch_row0 = nullptr; int32_t *arch_len = nullptr; size_t arch_ent_cap = 0;
+    std::vector<int64_t> arch_row0_host; std::vector<int32_t> arch_len_host;
+    long long *nov_out = nullptr; size_t nov_out_cap = 0; int32_t *nov_len = nullptr; size_t nov_len_cap = 0;   // GA: the seed offsets of the chain being rebuilt
     // RCCL communicator (dne_comm_init); the library is opened on demand
     void *rccl_lib = nullptr; void *comm = nullptr; int comm_rank = 0, comm_size = 1;
     double *comm_scratch = nullptr;
@@ -1782,25 +1787,105 @@ extern "C" int dne_ga_select(dne_handle *h, const float *returns, int m, int t, 
     return 0;
 }
 
+// ---- the novelty archive lives on the device: the master's archive only ever grows (nses.py:246-247 appends one BC per
+// iteration), so a worker uploads each entry once instead of the whole archive on every call
+static int archive_reserve(dne_handle *h, size_t rows, size_t entries, int dim) {
+    if (rows * dim > h->arch_cap) {
+        uint8_t *nb = nullptr;
+        const size_t cap = std::max<size_t>(2 * rows * dim, 1u << 20);
+        HCHECK(h, h->alloc(&nb, cap, "novelty_archive"));
+        if (h->arch && h->arch_rows) HCHECK(h, hipMemcpy(nb, h->arch, h->arch_rows * h->arch_dim, hipMemcpyDeviceToDevice));
+        HCHECK(h, h->release(h->arch));
+        h->arch = nb; h->arch_cap = cap;
+    }
+    if (entries > h->arch_ent_cap) {
+        const size_t cap = std::max<size_t>(2 * entries, 256);
+        HCHECK(h, h->release(h->arch_row0)); HCHECK(h, h->release(h->arch_len));
+        HCHECK(h, h->alloc(&h->arch_row0, cap, "novelty_row0")); HCHECK(h, h->alloc(&h->arch_len, cap, "novelty_len"));
+        h->arch_ent_cap = cap;
+        if (!h->arch_len_host.empty()) {
+            HCHECK(h, hipMemcpy(h->arch_row0, h->arch_row0_host.data(), h->arch_row0_host.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+            HCHECK(h, hipMemcpy(h->arch_len, h->arch_len_host.data(), h->arch_len_host.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+    }
+    return 0;
+}
+
+extern "C" int dne_archive_clear(dne_handle *h) {
+    DeviceGuard dg(h);
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    h->arch_rows = 0; h->arch_dim = 0;
+    h->arch_row0_host.clear(); h->arch_len_host.clear();
+    return 0;
+}
+
+extern "C" int dne_archive_append(dne_handle *h, const uint8_t *bc, int bc_len, int dim) {
+    DeviceGuard dg(h);
+    if (bc_len < 1 || dim < 1) return h->fail("dne_archive_append: empty entry");
+    if (h->arch_dim && dim != h->arch_dim) return h->fail("dne_archive_append: entry width %d, archive holds %d", dim, h->arch_dim);
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    const size_t n = h->arch_len_host.size();
+    if (archive_reserve(h, h->arch_rows + bc_len, n + 1, dim)) return -1;
+    h->arch_dim = dim;
+    if (copy_h2d(h, h->arch + h->arch_rows * dim, bc, (size_t)bc_len * dim)) return -1;
+    const int64_t row0 = (int64_t)h->arch_rows; const int32_t len = bc_len;
+    HCHECK(h, hipMemcpy(h->arch_row0 + n, &row0, sizeof(row0), hipMemcpyHostToDevice));
+    HCHECK(h, hipMemcpy(h->arch_len + n, &len, sizeof(len), hipMemcpyHostToDevice));
+    h->arch_row0_host.push_back(row0); h->arch_len_host.push_back(len);
+    h->arch_rows += bc_len;
+    return 0;
+}
+
+extern "C" int dne_archive_size(dne_handle *h) { return (int)h->arch_len_host.size(); }
+
+// a caller-supplied archive replaces the resident one (the one-shot form of the two novelty calls)
+static int archive_load(dne_handle *h, const uint8_t *archive, const int32_t *alen, int narch, int dim) {
+    if (narch < 1) return h->fail("empty archive");
+    if (dne_archive_clear(h)) return -1;
+    size_t rows = 0;
+    for (int a = 0; a < narch; a++) { if (alen[a] < 1) return h->fail("empty archive entry"); rows += alen[a]; }
+    if (archive_reserve(h, rows, narch, dim)) return -1;
+    h->arch_dim = dim;
+    if (copy_h2d(h, h->arch, archive, rows * dim)) return -1;
+    int64_t r0 = 0;
+    for (int a = 0; a < narch; a++) { h->arch_row0_host.push_back(r0); h->arch_len_host.push_back(alen[a]); r0 += alen[a]; }
+    HCHECK(h, hipMemcpy(h->arch_row0, h->arch_row0_host.data(), narch * sizeof(int64_t), hipMemcpyHostToDevice));
+    HCHECK(h, hipMemcpy(h->arch_len, h->arch_len_host.data(), narch * sizeof(int32_t), hipMemcpyHostToDevice));
+    h->arch_rows = rows;
+    return 0;
+}
+
+static int novelty_scratch(dne_handle *h, size_t out_words, size_t len_words) {
+    if (out_words > h->nov_out_cap) {
+        HCHECK(h, h->release(h->nov_out));
+        h->nov_out_cap = std::max<size_t>(2 * out_words, 4096);
+        HCHECK(h, h->alloc(&h->nov_out, h->nov_out_cap, "novelty_out"));
+    }
+    if (len_words > h->nov_len_cap) {
+        HCHECK(h, h->release(h->nov_len));
+        h->nov_len_cap = std::max<size_t>(2 * len_words, 4096);
+        HCHECK(h, h->alloc(&h->nov_len, h->nov_len_cap, "novelty_len_in"));
+    }
+    return 0;
+}
+
+// nses.py:12-32.  archive == NULL: score against the device-resident archive (dne_archive_append)
 extern "C" int dne_novelty(dne_handle *h, const uint8_t *archive, const int32_t *alen, int narch, const uint8_t *bc,
                            int bc_len, int dim, int k, double *out) {
     DeviceGuard dg(h);
-    if (narch < 1 || bc_len < 1 || dim < 1 || k < 1) return h->fail("dne_novelty: bad sizes");
-    std::vector<int64_t> row0(narch);
-    int64_t rows = 0;
-    for (int a = 0; a < narch; a++) { if (alen[a] < 1) return h->fail("empty archive entry"); row0[a] = rows; rows += alen[a]; }
-    DevBuf<uint8_t> d_arch, d_bc; DevBuf<int64_t> d_row0; DevBuf<int32_t> d_len; DevBuf<long long> d_out;
-    HCHECK(h, d_arch.alloc((size_t)rows * dim)); HCHECK(h, d_bc.alloc((size_t)bc_len * dim));
-    HCHECK(h, d_row0.alloc(narch)); HCHECK(h, d_len.alloc(narch)); HCHECK(h, d_out.alloc(2 * (size_t)narch));
-    HCHECK(h, hipMemcpyAsync(d_arch, archive, (size_t)rows * dim, hipMemcpyHostToDevice, h->stream));
+    if (bc_len < 1 || dim < 1 || k < 1) return h->fail("dne_novelty: bad sizes");
+    if (archive && archive_load(h, archive, alen, narch, dim)) return -1;
+    narch = (int)h->arch_len_host.size();
+    if (narch < 1) return h->fail("dne_novelty: the archive is empty");
+    if (dim != h->arch_dim) return h->fail("dne_novelty: characterisation width %d, archive holds %d", dim, h->arch_dim);
+    if (novelty_scratch(h, 2 * (size_t)narch, ((size_t)bc_len * dim + 3) / 4)) return -1;
+    uint8_t *d_bc = (uint8_t *)h->nov_len;
     HCHECK(h, hipMemcpyAsync(d_bc, bc, (size_t)bc_len * dim, hipMemcpyHostToDevice, h->stream));
-    HCHECK(h, hipMemcpyAsync(d_row0, row0.data(), narch * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    HCHECK(h, hipMemcpyAsync(d_len, alen, narch * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_bc_sqdist, dim3(narch), dim3(256), 0, h->stream, (const uint8_t *)d_arch.p, (const int64_t *)d_row0.p,
-                       (const int32_t *)d_len.p, (const uint8_t *)d_bc.p, bc_len, dim, d_out.p);
+    hipLaunchKernelGGL(k_bc_sqdist, dim3(narch), dim3(256), 0, h->stream, (const uint8_t *)h->arch, (const int64_t *)h->arch_row0,
+                       (const int32_t *)h->arch_len, (const uint8_t *)d_bc, bc_len, dim, h->nov_out);
     HCHECK(h, hipGetLastError());
     std::vector<long long> ab(2 * (size_t)narch);
-    HCHECK(h, hipMemcpyAsync(ab.data(), d_out, ab.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipMemcpyAsync(ab.data(), h->nov_out, ab.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
     HCHECK(h, hipStreamSynchronize(h->stream));
     std::vector<double> d(narch);
     for (int a = 0; a < narch; a++) {   // nses.py:20 sqrt(a**2 + b**2) with a, b = the two Frobenius norms
@@ -1820,24 +1905,20 @@ extern "C" int dne_novelty_batch(dne_handle *h, const uint8_t *archive, const in
     DeviceGuard dg(h);
     if (h->L.kind != DNE_KIND_ES || !h->bc || h->cfg.bc_final_only) return h->fail("dne_novelty_batch needs an ES engine created with record_bc = 1 (full trajectories)");
     if (check_n(h, n)) return -1;
-    if (narch < 1 || k < 1) return h->fail("dne_novelty_batch: bad sizes");
-    std::vector<int64_t> row0(narch);
-    int64_t rows = 0;
-    for (int a = 0; a < narch; a++) { if (alen[a] < 1) return h->fail("empty archive entry"); row0[a] = rows; rows += alen[a]; }
+    if (k < 1) return h->fail("dne_novelty_batch: bad sizes");
+    if (archive && archive_load(h, archive, alen, narch, 128)) return -1;
+    narch = (int)h->arch_len_host.size();
+    if (narch < 1) return h->fail("dne_novelty_batch: the archive is empty");
+    if (h->arch_dim != 128) return h->fail("dne_novelty_batch: the archive must hold 128-byte RAM rows");
     for (int i = 0; i < n; i++)
         if (lengths[i] < 1 || lengths[i] > h->cfg.bc_max_steps) return h->fail("member %d: trajectory length %d outside the recorded capacity %d", i, lengths[i], h->cfg.bc_max_steps);
-    DevBuf<uint8_t> d_arch; DevBuf<int64_t> d_row0; DevBuf<int32_t> d_alen, d_len; DevBuf<long long> d_out;
-    HCHECK(h, d_arch.alloc((size_t)rows * 128)); HCHECK(h, d_row0.alloc(narch)); HCHECK(h, d_alen.alloc(narch));
-    HCHECK(h, d_len.alloc(n)); HCHECK(h, d_out.alloc((size_t)n * narch * 2));
-    HCHECK(h, hipMemcpyAsync(d_arch, archive, (size_t)rows * 128, hipMemcpyHostToDevice, h->stream));
-    HCHECK(h, hipMemcpyAsync(d_row0, row0.data(), narch * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-    HCHECK(h, hipMemcpyAsync(d_alen, alen, narch * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    HCHECK(h, hipMemcpyAsync(d_len, lengths, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_bc_sqdist_batch, dim3(narch, n), dim3(256), 0, h->stream, (const uint8_t *)d_arch.p, (const int64_t *)d_row0.p,
-                       (const int32_t *)d_alen.p, (const uint8_t *)h->bc, (const int32_t *)d_len.p, h->cfg.bc_max_steps, narch, d_out.p);
+    if (novelty_scratch(h, (size_t)n * narch * 2, n)) return -1;
+    HCHECK(h, hipMemcpyAsync(h->nov_len, lengths, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_bc_sqdist_batch, dim3(narch, n), dim3(256), 0, h->stream, (const uint8_t *)h->arch, (const int64_t *)h->arch_row0,
+                       (const int32_t *)h->arch_len, (const uint8_t *)h->bc, (const int32_t *)h->nov_len, h->cfg.bc_max_steps, narch, h->nov_out);
     HCHECK(h, hipGetLastError());
     std::vector<long long> ab((size_t)n * narch * 2);
-    HCHECK(h, hipMemcpyAsync(ab.data(), d_out, ab.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipMemcpyAsync(ab.data(), h->nov_out, ab.size() * sizeof(long long), hipMemcpyDeviceToHost, h->stream));
     HCHECK(h, hipStreamSynchronize(h->stream));
     std::vector<double> d(narch);
     const int kk = std::min(k, narch);

@@ -375,26 +375,34 @@ class Engine:
         self._ck(self.lib.dne_ga_select(self.h, _ptr(r, C.c_float), int(r.size), int(t), _ptr(out, C.c_int32)))
         return out
 
+    def _sync_archive(self, archive):
+        """Bring the device-resident archive up to `archive`.  The master's archive only grows (dist.py:93-98) and the
+        transport hands back the same entry objects on every call, so entries are recognised by identity and only new ones
+        are uploaded; any other list (fresh arrays, a shorter archive) is uploaded from scratch."""
+        have = getattr(self, "_arch_objs", [])
+        if len(have) > len(archive) or any(a is not b for a, b in zip(have, archive)):
+            self._ck(self.lib.dne_archive_clear(self.h))
+            have = []
+        for a in archive[len(have):]:
+            u = _arr(a, np.uint8)
+            u = u.reshape(-1, u.shape[-1])
+            self._ck(self.lib.dne_archive_append(self.h, _ptr(u, C.c_uint8), int(u.shape[0]), int(u.shape[1])))
+        self._arch_objs = list(archive)      # references keep the identities from being recycled
+
     def novelty(self, archive, bc, k):
         bc = _arr(bc, np.uint8).reshape(-1, np.asarray(bc).shape[-1])
-        dim = bc.shape[1]
-        arch = [_arr(a, np.uint8).reshape(-1, dim) for a in archive]
-        lens = _arr([a.shape[0] for a in arch], np.int32)
-        cat = _arr(np.concatenate(arch), np.uint8)
+        self._sync_archive(archive)
         out = C.c_double()
-        self._ck(self.lib.dne_novelty(self.h, _ptr(cat, C.c_uint8), _ptr(lens, C.c_int32), len(arch), _ptr(bc, C.c_uint8),
-                                      int(bc.shape[0]), int(dim), int(k), C.byref(out)))
+        self._ck(self.lib.dne_novelty(self.h, None, None, 0, _ptr(bc, C.c_uint8), int(bc.shape[0]), int(bc.shape[1]), int(k),
+                                      C.byref(out)))
         return out.value
 
     def novelty_batch(self, archive, lengths, k):
         """novelty of every member's RAM trajectory recorded by the last es_eval (kept on the device)"""
-        arch = [_arr(a, np.uint8).reshape(-1, RAM_BYTES) for a in archive]
-        lens = _arr([a.shape[0] for a in arch], np.int32)
-        cat = _arr(np.concatenate(arch), np.uint8)
+        self._sync_archive(archive)
         ln = _arr(np.asarray(lengths).reshape(-1), np.int32)
         out = np.empty(ln.size, np.float64)
-        self._ck(self.lib.dne_novelty_batch(self.h, _ptr(cat, C.c_uint8), _ptr(lens, C.c_int32), len(arch), int(ln.size),
-                                            _ptr(ln, C.c_int32), int(k), _ptr(out, C.c_double)))
+        self._ck(self.lib.dne_novelty_batch(self.h, None, None, 0, int(ln.size), _ptr(ln, C.c_int32), int(k), _ptr(out, C.c_double)))
         return out
 
     def profile(self):

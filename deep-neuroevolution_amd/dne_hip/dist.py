@@ -262,8 +262,11 @@ class WorkerClient:
             return self.master.exp
 
     def get_archive(self):
-        if self.kind == 'redis':
-            return [deserialize(v) for v in self.master.lrange(ARCHIVE_KEY, 0, -1)]
+        if self.kind == 'redis':   # append-only list (dist.py:93-95): fetch and unpickle only what is new
+            if not hasattr(self, '_archive'):
+                self._archive = []
+            self._archive += [deserialize(v) for v in self.master.lrange(ARCHIVE_KEY, len(self._archive), -1)]
+            return list(self._archive)
         with self.master.cv:
             return list(self.master.archive)
 

@@ -180,7 +180,13 @@ int dne_es_update_gathered(dne_handle *h, int proc_mode, int opt_kind, float l2c
 /* ga.py:145: indices of the top-T returns, ordered by (-return, arrival index) */
 int dne_ga_select(dne_handle *h, const float *returns, int m, int t, int32_t *out_idx);
 
-/* ---- A13 nses.py:12-32: novelty of one behaviour characterisation against an archive ------------------- */
+/* ---- A13 nses.py:12-32: novelty of one behaviour characterisation against an archive -------------------
+ * The archive (MasterClient.add_to_novelty_archive / get_archive, dist.py:93-98) is append-only, so it can live on the
+ * device: dne_archive_append uploads one entry, and the two novelty calls score against the resident archive when their
+ * `archive` argument is NULL.  A non-NULL archive replaces the resident one (one-shot form). */
+int dne_archive_append(dne_handle *h, const uint8_t *bc /*[bc_len][dim]*/, int bc_len, int dim);
+int dne_archive_clear(dne_handle *h);
+int dne_archive_size(dne_handle *h);
 int dne_novelty(dne_handle *h, const uint8_t *archive /*concatenated rows*/, const int32_t *archive_len,
                 int narchive, const uint8_t *bc, int bc_len, int dim, int k, double *out);
 /* nses.py:381-382 for a whole evaluated batch: novelty of each of the n members' RAM trajectories recorded by
