@@ -140,19 +140,24 @@ __global__ __launch_bounds__(64) void k_env_logic(EnvArgs E, const int *__restri
 }
 
 // max over the last two raw frames + WarpFrame + FrameStack for every member stepped by the logic kernel
-__global__ __launch_bounds__(1024) void k_env_render(EnvArgs E, const int *__restrict__ list, int gsize, int fill, int nbands) {
-    __shared__ __attribute__((aligned(16))) EnvLds s;
-    const int b = blockIdx.x / nbands, band = blockIdx.x % nbands, tid = threadIdx.x;
-    const int g = list ? list[b / gsize] : b / gsize;
-    const int m = g * gsize + b % gsize;
-    if (!E.stepped[m]) return;
-    synth_load_tables(s, E.T);
+__device__ __forceinline__ void render_body(EnvLds &s, const EnvArgs &E, int m, bool fill, int band, int nbands) {
+    const int tid = threadIdx.x;
     if (tid < 64) {
         s.ram_prev[tid] = E.ram_prev[(size_t)m * 128 + tid];
         s.ram_cur[tid] = E.ram_cur[(size_t)m * 128 + tid];
     }
     __syncthreads();
-    synth_observe(s, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), fill != 0, band, nbands);
+    synth_observe(s, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), fill, band, nbands);
+}
+
+__global__ __launch_bounds__(1024) void k_env_render(EnvArgs E, const int *__restrict__ list, int gsize, int fill, int nbands) {
+    __shared__ __attribute__((aligned(16))) EnvLds s;
+    const int b = blockIdx.x / nbands, band = blockIdx.x % nbands;
+    const int g = list ? list[b / gsize] : b / gsize;
+    const int m = g * gsize + b % gsize;
+    if (!E.stepped[m]) return;
+    synth_load_tables(s, E.T);
+    render_body(s, E, m, fill != 0, band, nbands);
 }
 
 // Tail of a generation (a few dozen members left, every kernel boundary is a visible bubble): one workgroup per
@@ -161,19 +166,28 @@ __global__ __launch_bounds__(1024) void k_env_render(EnvArgs E, const int *__res
 // chosen action on one lane, and renders the new observation -- k_out + k_env_logic + k_env_render in one launch.
 struct RamLds { uint8_t ram_prev[128], ram_cur[128]; };
 
-template <bool HAS_BN, bool RENDER>
-__global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const int *__restrict__ list, int gsize, int tslimit,
-                                                     const float *__restrict__ y3t, float *__restrict__ y3,
-                                                     int32_t *__restrict__ actions) {
-    __shared__ __attribute__((aligned(16))) std::conditional_t<RENDER, EnvLds, RamLds> s;
-    constexpr int WS = 260;                              // row stride of the transposed output weights (16-byte aligned, spreads banks)
-    __shared__ __attribute__((aligned(16))) float a3[256];
-    __shared__ float lg[32];
-    __shared__ __attribute__((aligned(16))) float wo[32 * WS];   // [action][k]
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int g = list ? list[b / gsize] : b / gsize;
-    const int m = g * gsize + b % gsize;
-    if (E.done[m]) { if (tid == 0) E.stepped[m] = 0; return; }
+constexpr int HEAD_WS = 260;   // row stride of the transposed output weights (16-byte aligned, spreads banks)
+template <bool RENDER>
+struct HeadLds {
+    __attribute__((aligned(16))) std::conditional_t<RENDER, EnvLds, RamLds> s;
+    __attribute__((aligned(16))) float a3[256];
+    float lg[32];
+    __attribute__((aligned(16))) float wo[32 * HEAD_WS];   // [action][k]
+};
+
+// The policy head + emulator step of one member, by one workgroup (>= 256 threads).  Everything that does not depend on the fc
+// partial sums (the output-layer weights, the RAM rows, the resize tables) is issued before wait() -- a hook a producer /
+// consumer variant would block in; the kernels in use pass NoWait.
+template <bool HAS_BN, bool RENDER, typename WaitFn>
+__device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, const EnvArgs &E, int m, int tslimit,
+                                          const float *__restrict__ y3t, float *__restrict__ y3, int32_t *__restrict__ actions,
+                                          WaitFn wait) {
+    constexpr int WS = HEAD_WS;
+    auto &s = H.s;
+    float (&a3)[256] = H.a3;
+    float (&lg)[32] = H.lg;
+    float (&wo)[32 * HEAD_WS] = H.wo;
+    const int tid = threadIdx.x;
     const Layout &L = A.L;
     const int nact = L.nact;
     const float sc = A.m_scale[m];
@@ -183,21 +197,6 @@ __global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const 
         s.ram_prev[tid] = E.ram_prev[(size_t)m * 128 + tid];
         s.ram_cur[tid] = E.ram_cur[(size_t)m * 128 + tid];
     }
-    if (tid < 256) {
-        const float *p = y3t + (size_t)m * 4 * 256 + tid;
-        const float s01 = p[0] + p[256];
-        const float s23 = p[512] + p[768];
-        float t = s01 + s23;
-        float pvb = sc * A.noise[off + L.fcb + tid];
-        const float fb = base[L.fcb + tid] + pvb;
-        t = t + fb;
-        y3[(size_t)m * 256 + tid] = t;
-        if (HAS_BN) {
-            t = t * A.bn[(size_t)m * 608 + 96 + tid];
-            t = t + A.bn[(size_t)m * 608 + 352 + tid];
-        }
-        a3[tid] = t > 0.0f ? t : 0.0f;
-    }
     {
         const float *wb = base + L.ow, *we = A.noise + off + L.ow;
         for (int i = tid; i < 256 * nact; i += blockDim.x) {   // the flat layout is [k][action]; every logit's column becomes an LDS row
@@ -206,6 +205,25 @@ __global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const 
         }
     }
     if constexpr (RENDER) synth_load_tables(s, E.T);
+    float fb = 0.0f;
+    if (tid < 256) {
+        float pvb = sc * A.noise[off + L.fcb + tid];
+        fb = base[L.fcb + tid] + pvb;
+    }
+    if (!wait()) return;
+    if (tid < 256) {
+        const float *p = y3t + (size_t)m * 4 * 256 + tid;
+        const float s01 = p[0] + p[256];
+        const float s23 = p[512] + p[768];
+        float t = s01 + s23;
+        t = t + fb;
+        y3[(size_t)m * 256 + tid] = t;
+        if (HAS_BN) {
+            t = t * A.bn[(size_t)m * 608 + 96 + tid];
+            t = t + A.bn[(size_t)m * 608 + 352 + tid];
+        }
+        a3[tid] = t > 0.0f ? t : 0.0f;
+    }
     __syncthreads();
     if (tid < nact) {
         float acc = 0.0f;
@@ -234,6 +252,18 @@ __global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const 
         __syncthreads();
         synth_observe(s, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), false);
     }
+}
+
+template <bool HAS_BN, bool RENDER>
+__global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const int *__restrict__ list, int gsize, int tslimit,
+                                                     const float *__restrict__ y3t, float *__restrict__ y3,
+                                                     int32_t *__restrict__ actions) {
+    __shared__ HeadLds<RENDER> H;
+    const int b = blockIdx.x;
+    const int g = list ? list[b / gsize] : b / gsize;
+    const int m = g * gsize + b % gsize;
+    if (E.done[m]) { if (threadIdx.x == 0) E.stepped[m] = 0; return; }
+    head_body<HAS_BN, RENDER>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{});
 }
 
 // order-preserving compaction of the active-group list

@@ -77,15 +77,16 @@ __device__ __forceinline__ Item decode_item(int b, const int *__restrict__ list,
 // (two independent accumulators cover the 40-cycle dependent-MFMA latency).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict__ list, int gsize, int F, int member0,
-                                               const uint8_t *__restrict__ stacks, const uint8_t *__restrict__ ref,
-                                               float *__restrict__ y1, int nsplit) {
-    // nsplit = 4 / 7 (few members left): four / seven workgroups share one member's 28 position tiles to cut the latency
-    const int part = blockIdx.x % nsplit;
-    const Item it = decode_item(blockIdx.x / nsplit, list, gsize, F, member0, stacks, ref, A.done);
-    if (it.skip) return;
-    __shared__ float lut[256];
-    __shared__ uint32_t img[88 * 88];
+struct Conv1Lds {
+    float lut[256];
+    uint32_t img[88 * 88];
+};
+
+// one member-frame (or 1/4, 1/7 of its position tiles when nsplit = 4 / 7: few members left, several workgroups share one
+// member's 28 tiles to cut the latency); called by all 256 threads of a workgroup
+__device__ __forceinline__ void conv1_body(Conv1Lds &S, const FwdArgs &A, const Item &it, float *__restrict__ y1, int part, int nsplit) {
+    float (&lut)[256] = S.lut;
+    uint32_t (&img)[88 * 88] = S.img;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, ci = lane >> 4;
     const float *base = A.bases + (size_t)A.m_slot[it.member] * A.base_stride + A.L.c1w;
     const float *eps = A.noise + A.m_off[it.member] + A.L.c1w;
@@ -156,6 +157,15 @@ __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict_
         if (j + 1 < 7) run(j, std::true_type{});
         else run(j, std::false_type{});
     }
+}
+
+__global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict__ list, int gsize, int F, int member0,
+                                               const uint8_t *__restrict__ stacks, const uint8_t *__restrict__ ref,
+                                               float *__restrict__ y1, int nsplit) {
+    __shared__ Conv1Lds S;
+    const Item it = decode_item(blockIdx.x / nsplit, list, gsize, F, member0, stacks, ref, A.done);
+    if (it.skip) return;
+    conv1_body(S, A, it, y1, blockIdx.x % nsplit, nsplit);
 }
 
 // Batch-norm moments of the reference pass, formed in the convolution epilogue (the oracle's bn_finish_tiles order): one
@@ -285,18 +295,21 @@ __global__ __launch_bounds__(256) void k_conv1_ref(FwdArgs A, int F, int member0
 // GEMM view [121 -> 128 positions] x [256 = (kh,kw,ci)] x [32 co] on the same fp32 MFMA: wave w owns
 // co tile (w & 1) and position tiles 4*(w>>1) .. +3 (4 independent accumulators); its B fragments (the
 // perturbed weights of 16 output channels) live in 64 VGPRs, A comes from the padded activation image in LDS.
+constexpr int C2_PS = 17;   // LDS pixel stride (16 channels + 1 pad)
+constexpr int C2_RW = 27;   // LDS row width in pixels (24 used): 2 * RW * PS = 22 mod 32 continues the 2-per-position bank
+                            // sequence across output rows, so the 16 positions of an MFMA tile never share a bank
+struct Conv2Lds {
+    float a_s[24 * C2_RW * C2_PS];
+    float wsum[4][2][16];
+};
+
+// nsplit = 2 / 4: two / four workgroups share one member's position tiles
 template <bool HAS_BN>
-__global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict__ list, int gsize, int F, int member0,
-                                               const float *__restrict__ y1, float *__restrict__ y2, int nsplit,
-                                               float *__restrict__ fr /*reference pass: [rows][2][32] per-frame moments, else null*/) {
-    const int part = blockIdx.x % nsplit;   // nsplit = 2 / 4: two / four workgroups share one member's position tiles
-    const Item it = decode_item(blockIdx.x / nsplit, list, gsize, F, member0, nullptr, nullptr, A.done);
-    if (it.skip) return;
-    constexpr int PS = 17;   // LDS pixel stride (16 channels + 1 pad)
-    constexpr int RW = 27;   // LDS row width in pixels (24 used): 2 * RW * PS = 22 mod 32 continues the 2-per-position bank
-                             // sequence across output rows, so the 16 positions of an MFMA tile never share a bank
-    __shared__ float a_s[24 * RW * PS];
-    __shared__ float wsum[4][2][16];
+__device__ __forceinline__ void conv2_body(Conv2Lds &S, const FwdArgs &A, const Item &it, const float *__restrict__ y1,
+                                           float *__restrict__ y2, int part, int nsplit, float *__restrict__ fr) {
+    constexpr int PS = C2_PS, RW = C2_RW;
+    float (&a_s)[24 * C2_RW * C2_PS] = S.a_s;
+    float (&wsum)[4][2][16] = S.wsum;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
     const int nt = wv & 1, mt0 = 4 * (wv >> 1);
     const float *base = A.bases + (size_t)A.m_slot[it.member] * A.base_stride + A.L.c2w;
@@ -390,6 +403,16 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
     if (nsplit == 4) run(std::integral_constant<int, 1>{});
     else if (nsplit == 2) run(std::integral_constant<int, 2>{});
     else run(std::integral_constant<int, 4>{});
+}
+
+template <bool HAS_BN>
+__global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict__ list, int gsize, int F, int member0,
+                                               const float *__restrict__ y1, float *__restrict__ y2, int nsplit,
+                                               float *__restrict__ fr /*reference pass: [rows][2][32] per-frame moments, else null*/) {
+    __shared__ Conv2Lds S;
+    const Item it = decode_item(blockIdx.x / nsplit, list, gsize, F, member0, nullptr, nullptr, A.done);
+    if (it.skip) return;
+    conv2_body<HAS_BN>(S, A, it, y1, y2, blockIdx.x % nsplit, nsplit, fr);
 }
 
 // ------------------------------------------------------------------------- fc (+ out + argmax)
@@ -910,21 +933,29 @@ __device__ __forceinline__ float quad_bcast(float v) {   // every lane of a quad
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), J * 0x55, 0xf, 0xf, true));
 }
 
-template <int NV, bool HAS_BN>
-__global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
-                                                 float *__restrict__ y3t /*[member][4 slices][256]*/) {
+template <int NV>
+struct QuadLds {
+    __attribute__((aligned(16))) float xs[NV][968];
+    float hand[NV][64];
+};
+
+struct NoWait {
+    __device__ __forceinline__ bool operator()() const { return true; }
+};
+
+template <int NV, bool HAS_BN, bool WEIGHTS_FIRST, typename WaitFn>
+__device__ __forceinline__ void fc_quad_body(QuadLds<NV> &S, const FwdArgs &A, int g, int cg, int sl, const float *__restrict__ y2,
+                                             float *__restrict__ y3t /*[member][4 slices][256]*/, WaitFn wait) {
     // One workgroup per (group, 16-column block, k-slice).  Its four waves split the slice's 242 four-row groups
     // 61/61/60/60: every wave has ALL of its rows in flight at once (4x the bytes in flight of a one-wave block --
     // this regime is pure load latency), perturbs them in registers, and then the waves run their parts of the
     // ordered chain one after the other, handing the chain value over through LDS.  Lane (rg, cl) loads row 4g + rg of
     // column cl; the chain takes row j's weight from lane j of the quad with a DPP operand, so all four lanes of a quad
     // carry the same value.
-    __shared__ __attribute__((aligned(16))) float xs[NV][968];
-    __shared__ float hand[NV][64];
+    float (&xs)[NV][968] = S.xs;
+    float (&hand)[NV][64] = S.hand;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, rg = lane & 3, cl = lane >> 2;
     const Layout &L = A.L;
-    const int item = blockIdx.x >> 6, cg = (blockIdx.x >> 2) & 15, sl = blockIdx.x & 3;
-    const int g = list ? list[item] : item;
     int member[NV];
     float scale[NV];
 #pragma unroll
@@ -943,19 +974,24 @@ __global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restric
     const int g0 = wv * 60 + (wv < 2 ? wv : 2), ng = wv < 2 ? 61 : 60;
     const float *eps = A.noise + off + L.fcw + (size_t)(kbeg + 4 * g0 + rg) * 256 + col;
     const float *th = base + L.fcw + (size_t)(kbeg + 4 * g0 + rg) * 256 + col;
-    // The activation loads are issued first and consumed after the weight loads are in flight: loads return in
-    // order, so the barrier below waits for (at most) the first weight rows, not for all of them.
+    // The activation loads are issued first and consumed after the weight loads are in flight: loads return in order, so the
+    // barrier below waits for (at most) the first weight rows, not for all of them.  WEIGHTS_FIRST (the single-launch lock-step
+    // experiment, DESIGN.md "measured and not adopted"): the weight rows go out before the activations exist, wait() blocks
+    // until their producer has signalled, then the activations load.
     float yv[NV][4], s2[NV][4], h2[NV][4];
+    auto load_y = [&]() {
 #pragma unroll
-    for (int v = 0; v < NV; v++)
+        for (int v = 0; v < NV; v++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int i = tid + 256 * j, ch = (kbeg + i) & 31;
-            const bool in = i < 968;
-            yv[v][j] = in ? y2[(size_t)member[v] * 3872 + kbeg + i] : 0.0f;
-            s2[v][j] = HAS_BN && in ? A.bn[(size_t)member[v] * 608 + 32 + ch] : 1.0f;
-            h2[v][j] = HAS_BN && in ? A.bn[(size_t)member[v] * 608 + 64 + ch] : 0.0f;
-        }
+            for (int j = 0; j < 4; j++) {
+                const int i = tid + 256 * j, ch = (kbeg + i) & 31;
+                const bool in = i < 968;
+                yv[v][j] = in ? y2[(size_t)member[v] * 3872 + kbeg + i] : 0.0f;
+                s2[v][j] = HAS_BN && in ? A.bn[(size_t)member[v] * 608 + 32 + ch] : 1.0f;
+                h2[v][j] = HAS_BN && in ? A.bn[(size_t)member[v] * 608 + 64 + ch] : 0.0f;
+            }
+    };
+    if (!WEIGHTS_FIRST) load_y();
     __builtin_amdgcn_sched_barrier(0);
     float e[GW], t[GW];
 #pragma unroll
@@ -965,6 +1001,10 @@ __global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restric
         t[i] = th[(size_t)(4 * ii) * 256];
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (WEIGHTS_FIRST) {
+        if (!wait()) return;
+        load_y();
+    }
 #pragma unroll
     for (int v = 0; v < NV; v++)
 #pragma unroll
@@ -1049,6 +1089,14 @@ __global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restric
         }
         if (p < 3) __syncthreads();
     }
+}
+
+template <int NV, bool HAS_BN>
+__global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
+                                                 float *__restrict__ y3t /*[member][4 slices][256]*/) {
+    __shared__ QuadLds<NV> S;
+    const int item = blockIdx.x >> 6, cg = (blockIdx.x >> 2) & 15, sl = blockIdx.x & 3;
+    fc_quad_body<NV, HAS_BN, false>(S, A, list ? list[item] : item, cg, sl, y2, y3t, NoWait{});
 }
 
 // Middle of the tail (a few dozen active groups): 4 workgroups per group (one per 64-column quarter), wave = k-slice,
