@@ -298,7 +298,10 @@ def main():
         total_steps, wall = float(st.item()), float(wt.item())
     else:
         total_steps = float(steps_local)
-    theta_sum = float(np.abs(engine.get_theta()).sum())
+    theta_final = engine.get_theta()
+    theta_sum = float(np.abs(theta_final).sum())
+    import hashlib
+    crumb("theta sha256 %s" % hashlib.sha256(theta_final.tobytes()).hexdigest())   # identical on every rank (redundant update)
     engine.check_redzones()   # raises if any kernel of the run wrote outside its device buffer
     crumb("red zones intact")
 

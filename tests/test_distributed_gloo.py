@@ -79,3 +79,75 @@ def test_two_ranks_gloo_bit_identical():
     assert eng.get_theta().tobytes() == th0
     rec = np.frombuffer(rec0[-1], es.RECORD)
     assert rec["len"].min() >= 1 and rec["len"].max() <= TSLIMIT and rec["ret"].dtype == np.float32
+
+
+# ------------------------------------------------------------------------------------------------ Deep GA, two ranks
+GA_CHILDREN, GA_PARENTS, GA_GENS = 7, 3, 3
+
+
+def _ga_engine():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_engine import OracleEngine
+    eng = OracleEngine(1)
+    eng.noise_upload(np.random.RandomState(123).randn(NOISE).astype(np.float32))
+    return eng
+
+
+def _gloo_allgather_bytes(buf, world):
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(buf.view(np.uint8).copy())
+    out = torch.empty(world * t.numel(), dtype=torch.uint8)
+    dist.all_gather_into_tensor(out, t)
+    return out.numpy().view(buf.dtype).reshape(world, -1)
+
+
+def _ga_rank_main(rank, world, port, q):
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "deep-neuroevolution_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from dne_hip import ga
+    eng = _ga_engine()
+    pop, score = [], np.array([], np.float32)
+    for g in range(GA_GENS):
+        pop, score, _ = ga.ga_generation(eng, NOISE, 0.005, pop, score, GA_CHILDREN, GA_PARENTS, 1, g, 12, rank, world,
+                                         transport=_gloo_allgather_bytes)
+    q.put((rank, repr(pop), score.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ga_two_ranks_gloo_same_elites():
+    """Deep GA with the children sharded over two ranks (odd count: 4 + 3): after the all-gather of 32-byte child records
+    every rank holds the same population, equal to a one-rank emulation of both shards (ga.py:136-149, 251-271)."""
+    import torch.multiprocessing as mp
+    from dne_hip import ga
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ga_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=500) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out[0][1:] == out[1][1:]
+    eng = _ga_engine()
+    pop, score = [], np.array([], np.float32)
+    for g in range(GA_GENS):      # serial emulation: evaluate both shards on one engine, merge in global child order
+        recs = np.zeros(GA_CHILDREN, ga.CHILD_RECORD)
+        for r in range(2):
+            mine, parent, fresh, env_seeds = ga.ga_generation_inputs(NOISE, eng.P, GA_CHILDREN, len(pop), g, r, 2)
+            chains = [(list(pop[p]) if p >= 0 else []) + [int(f)] for p, f in zip(parent, fresh)]
+            ret, sg, ln = eng.ga_eval(chains, 0.005, 12, env_seeds)
+            recs["parent"][mine], recs["seed"][mine], recs["ret"][mine], recs["len"][mine] = parent, fresh, ret, ln
+        cand = [list(c) for c in pop[:1]] + [(list(pop[r["parent"]]) if r["parent"] >= 0 else []) + [int(r["seed"])] for r in recs]
+        cand_ret = np.array(list(score[:1]) + list(recs["ret"]), np.float32)
+        pop, score = ga.truncate(eng, cand, cand_ret, GA_PARENTS)
+    assert repr(pop) == out[0][1] and score.tobytes() == out[0][2]
+    assert len(pop) == GA_PARENTS and all(len(c) >= 1 for c in pop) and max(len(c) for c in pop) >= 2

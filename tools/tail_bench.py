@@ -15,7 +15,7 @@ env = policies.HipAtariEnv(e, seed=0)
 ref = np.rint(np.stack(es.get_ref_batch(env, 128, np.random.RandomState(0))) * 255.0).astype(np.uint8)
 e.set_ref_batch(ref)
 out = {}
-for pairs in (1, 2, 4, 8, 16, 24):
+for pairs in ([int(x) for x in sys.argv[1].split(',')] if len(sys.argv) > 1 else (1, 2, 4, 8, 16, 24)):
     _, idx, seeds = es.generation_inputs(noise.noise.size, e.P, pairs, 3, 0, 1)
     e.es_eval(idx, 0.02, 50, seeds)
     t = time.time(); ret, sg, ln = e.es_eval(idx, 0.02, 400, seeds); wall = time.time() - t
