@@ -8,6 +8,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 N_PAIRS, NACT = 2500, 18
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
