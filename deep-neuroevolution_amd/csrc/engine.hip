@@ -347,6 +347,7 @@ struct dne_handle {
     dne_profile prof{};
     // GA parent cache: prefix chain -> base slot
     std::map<std::vector<int64_t>, int> ga_cache;
+    int ga_cache_mode = 0; float ga_cache_sigma = 0.0f;   // what the cached parents were built with (1 sigma / 2 per-seed powers)
     std::vector<int> free_slots;
     // every device allocation of the handle, each between two poisoned red zones (dne_check_redzones)
     struct Block { std::string name; uint8_t *raw; size_t bytes; };
@@ -362,7 +363,8 @@ struct dne_handle {
     int64_t *rec_idx = nullptr; float *rec_ret = nullptr, *rec_sign = nullptr; int32_t *rec_len = nullptr;
     uint8_t *rec_send = nullptr, *rec_recv = nullptr; size_t rec_cap = 0, rec_wire_cap = 0; int rec_n = 0;
     std::vector<int64_t> rec_idx_host;
-    int64_t *chain_offs = nullptr; size_t chain_cap = 0;
+    int64_t *chain_offs = nullptr; float *chain_pw = nullptr; size_t chain_cap = 0;   // GA: seed offsets (+ per-seed powers) of the chain being rebuilt
+    float *init_scale = nullptr;     // GA genomes in the gpu tree's form: root = noise[idx0] * init_scale (dne_ga_set_init_scale)
     // novelty archive resident on the device (dne_archive_append): rows of all entries back to back
     uint8_t *arch = nullptr; size_t arch_cap = 0, arch_rows = 0; int arch_dim = 0;
     int64_t *arch_row0 = nullptr; int32_t *arch_len = nullptr; size_t arch_ent_cap = 0;
@@ -1344,7 +1346,8 @@ static void launch_normc(dne_handle *h, float *th) {
 }
 
 // build theta(chain) into `slot`; `src_slot` >= 0 means chain[:src_len] is already materialised there
-static int build_chain(dne_handle *h, int slot, const int64_t *seeds, int nseeds, float sigma, int src_slot, int src_len) {
+static int build_chain(dne_handle *h, int slot, const int64_t *seeds, const float *powers /*per seed or null*/, int nseeds, float sigma,
+                       int src_slot, int src_len) {
     const int P = h->L.P, nb = (P + 255) / 256;
     float *dst = h->bases + (size_t)slot * h->base_stride;
     for (int s = 0; s < nseeds; s++)
@@ -1358,6 +1361,15 @@ static int build_chain(dne_handle *h, int slot, const int64_t *seeds, int nseeds
             HCHECK(h, hipMemcpyAsync(dst, src, (size_t)P * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
             return 0;
         }
+    } else if (powers) {   // the gpu tree's genome: root = noise[idx0] * scale_by (base.py:128-129)
+        if (!h->init_scale) return h->fail("genomes with per-seed powers need dne_ga_set_init_scale first");
+        const int32_t sl = slot; const int64_t o0 = seeds[0];
+        int32_t *d_slot = (int32_t *)h->scratch_f;
+        HCHECK(h, hipMemcpyAsync(d_slot, &sl, sizeof(sl), hipMemcpyHostToDevice, h->stream));
+        HCHECK(h, hipMemcpyAsync(h->scratch_i, &o0, sizeof(o0), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_copy_noise_scaled_batch, dim3(nb, 1), dim3(256), 0, h->stream, (const float *)h->noise, (const int64_t *)h->scratch_i,
+                           (const int32_t *)d_slot, h->base_stride, P, (const float *)h->init_scale, h->bases);
+        HCHECK(h, hipStreamSynchronize(h->stream));   // the two scratch words are reused by the next chain
     } else {
         hipLaunchKernelGGL(k_copy_noise, dim3(nb), dim3(256), 0, h->stream, (const float *)h->noise, seeds[0], P, dst);   // ga.py:256
         launch_normc(h, dst);                                                                                                // ga.py:258-260
@@ -1366,16 +1378,31 @@ static int build_chain(dne_handle *h, int slot, const int64_t *seeds, int nseeds
         const int n = nseeds - start;
         if ((size_t)n > h->chain_cap) {
             HCHECK(h, hipStreamSynchronize(h->stream));
-            HCHECK(h, h->release(h->chain_offs));
+            HCHECK(h, h->release(h->chain_offs)); HCHECK(h, h->release(h->chain_pw));
             h->chain_cap = std::max<size_t>(2 * (size_t)n, 1024);
-            HCHECK(h, h->alloc(&h->chain_offs, h->chain_cap, "chain_offs"));
+            HCHECK(h, h->alloc(&h->chain_offs, h->chain_cap, "chain_offs")); HCHECK(h, h->alloc(&h->chain_pw, h->chain_cap, "chain_pw"));
         }
         // pageable source: the copy is staged before hipMemcpyAsync returns, so the caller's array may go away; successive
         // chains are ordered on the stream
         HCHECK(h, hipMemcpyAsync(h->chain_offs, seeds + start, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(k_chain_sum, dim3(nb), dim3(256), 0, h->stream, (const float *)h->noise, (const int64_t *)h->chain_offs, n, P,
-                           sigma, src, dst);
+        if (powers) HCHECK(h, hipMemcpyAsync(h->chain_pw, powers + start, (size_t)n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_chain_sum, dim3(nb), dim3(256), 0, h->stream, (const float *)h->noise, (const int64_t *)h->chain_offs,
+                           powers ? (const float *)h->chain_pw : (const float *)nullptr, n, P, sigma, src, dst);
     }
+    return 0;
+}
+
+// gpu_implementation/neuroevolution/models/base.py:190-201: the per-parameter initial scale (weights std / sqrt(fan-in) in
+// dqn.py:24-27, biases 0); with it set, genomes given with per-seed powers start as noise[idx0] * scale_by
+extern "C" int dne_ga_set_init_scale(dne_handle *h, const float *scale_by, size_t n) {
+    DeviceGuard dg(h);
+    if (h->L.kind != DNE_KIND_GA) return h->fail("dne_ga_set_init_scale needs a GAAtariPolicy engine");
+    if (n != (size_t)h->L.P) return h->fail("dne_ga_set_init_scale: expected %d values, got %zu", h->L.P, n);
+    if (!h->init_scale) HCHECK(h, h->alloc(&h->init_scale, n, "init_scale"));
+    HCHECK(h, hipMemcpy(h->init_scale, scale_by, n * sizeof(float), hipMemcpyHostToDevice));
+    h->ga_cache.clear();
+    h->free_slots.clear();
+    for (int s2 = h->base_cap - 1; s2 >= 1; s2--) h->free_slots.push_back(s2);
     return 0;
 }
 
@@ -1385,21 +1412,51 @@ extern "C" int dne_ga_rebuild(dne_handle *h, int slot, const int64_t *seeds, int
     if (slot < 0 || nseeds < 1) return h->fail("bad arguments");
     if (grow_bases(h, slot + 1)) return -1;
     h->free_slots.erase(std::remove(h->free_slots.begin(), h->free_slots.end(), slot), h->free_slots.end());
-    if (build_chain(h, slot, seeds, nseeds, sigma, -1, 0)) return -1;
+    if (build_chain(h, slot, seeds, nullptr, nseeds, sigma, -1, 0)) return -1;
     HCHECK(h, hipGetLastError());
     HCHECK(h, hipStreamSynchronize(h->stream));
     if (out_host) HCHECK(h, hipMemcpy(out_host, h->bases + (size_t)slot * h->base_stride, (size_t)h->L.P * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 
-extern "C" int dne_ga_eval(dne_handle *h, const int32_t *co, const int64_t *seeds, int n, float sigma, int tslimit,
-                           const uint32_t *env_seed, float *returns, float *signreturns, int32_t *lengths, uint8_t *bc) {
+// the same for a genome ((idx0,), (idx1, power1), ...) of the gpu tree (base.py:118-139: compute_weights_from_seeds)
+extern "C" int dne_ga_rebuild_powers(dne_handle *h, int slot, const int64_t *seeds, const float *powers, int nseeds, float *out_host) {
     DeviceGuard dg(h);
+    if (h->L.kind != DNE_KIND_GA) return h->fail("dne_ga_rebuild_powers needs a GAAtariPolicy engine");
+    if (slot < 0 || nseeds < 1 || !powers) return h->fail("bad arguments");
+    if (grow_bases(h, slot + 1)) return -1;
+    h->free_slots.erase(std::remove(h->free_slots.begin(), h->free_slots.end(), slot), h->free_slots.end());
+    if (build_chain(h, slot, seeds, powers, nseeds, 0.0f, -1, 0)) return -1;
+    HCHECK(h, hipGetLastError());
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    if (out_host) HCHECK(h, hipMemcpy(out_host, h->bases + (size_t)slot * h->base_stride, (size_t)h->L.P * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Every child = parent chain + one fresh seed (ga.py:251-254).  Parents are materialised once into base slots (cached
+// across generations by chain) and the child's last mutation is applied on the fly by the forward kernels, exactly like an
+// ES perturbation with scale +sigma.  powers == null: es_distributed genomes (normc root, one sigma); powers != null: the
+// gpu tree's genomes ((idx0,), (idx1, power1), ...) with a scaled-noise root (base.py:118-149).
+static int ga_eval_impl(dne_handle *h, const int32_t *co, const int64_t *seeds, const float *powers, int n, float sigma, int tslimit,
+                        const uint32_t *env_seed, float *returns, float *signreturns, int32_t *lengths, uint8_t *bc) {
     if (h->L.kind != DNE_KIND_GA) return h->fail("dne_ga_eval needs a GAAtariPolicy engine");
     if (check_n(h, n)) return -1;
-    // Every child = parent chain + one fresh seed (ga.py:251-254).  Parents are materialised once into
-    // base slots (cached across generations by chain) and the child's last mutation is applied on the fly
-    // by the forward kernels, exactly like an ES perturbation with scale +sigma.
+    if (powers && !h->init_scale) return h->fail("genomes with per-seed powers need dne_ga_set_init_scale first");
+    const int stride = powers ? 2 : 1;   // cache key: the seeds, interleaved with the bit patterns of their powers
+    const int mode = powers ? 2 : 1;
+    if (h->ga_cache_mode != mode || (!powers && h->ga_cache_sigma != sigma)) {   // cached parents were built under other rules
+        for (auto &kv : h->ga_cache) h->free_slots.push_back(kv.second);
+        h->ga_cache.clear();
+        h->ga_cache_mode = mode; h->ga_cache_sigma = sigma;
+    }
+    auto key_of = [&](const int64_t *c, const float *pw, int len) {
+        std::vector<int64_t> k((size_t)len * stride);
+        for (int j = 0; j < len; j++) {
+            k[(size_t)j * stride] = c[j];
+            if (powers) { uint32_t bits = 0; if (j > 0) memcpy(&bits, &pw[j], 4); k[(size_t)j * stride + 1] = (int64_t)bits; }
+        }
+        return k;
+    };
     std::vector<std::vector<int64_t>> prefix(n);
     std::vector<int64_t> off(n);
     std::vector<float> sc(n);
@@ -1408,8 +1465,9 @@ extern "C" int dne_ga_eval(dne_handle *h, const int32_t *co, const int64_t *seed
         const int len = co[i + 1] - co[i];
         if (len < 1) return h->fail("member %d has an empty seed chain", i);
         const int64_t *c = seeds + co[i];
-        if (len == 1) { prefix[i].assign(c, c + 1); off[i] = c[0]; sc[i] = 0.0f; }
-        else { prefix[i].assign(c, c + len - 1); off[i] = c[len - 1]; sc[i] = sigma; }
+        const float *pw = powers ? powers + co[i] : nullptr;
+        if (len == 1) { prefix[i] = key_of(c, pw, 1); off[i] = c[0]; sc[i] = 0.0f; }
+        else { prefix[i] = key_of(c, pw, len - 1); off[i] = c[len - 1]; sc[i] = powers ? pw[len - 1] : sigma; }
         needed[prefix[i]] = -1;
     }
     size_t fresh = 0;
@@ -1427,15 +1485,16 @@ extern "C" int dne_ga_eval(dne_handle *h, const int32_t *co, const int64_t *seed
         // longest cached proper prefix as the starting point
         int src_slot = -1, src_len = 0;
         std::vector<int64_t> p(kv.first);
-        while (p.size() > 1) {
-            p.pop_back();
+        while ((int)p.size() > stride) {
+            p.resize(p.size() - stride);
             auto jt = h->ga_cache.find(p);
-            if (jt != h->ga_cache.end()) { src_slot = jt->second; src_len = (int)p.size(); break; }
+            if (jt != h->ga_cache.end()) { src_slot = jt->second; src_len = (int)p.size() / stride; break; }
         }
         kv.second = slot;
         fresh_list.push_back({&kv.first, slot, src_slot, src_len});
     }
-    {   // genomes with no cached ancestor start as normc(noise[s0]) (ga.py:256-260): one batched launch set for all
+    {   // genomes with no cached ancestor: one batched launch set for all roots.  es_distributed: normc(noise[s0])
+        // (ga.py:256-260); gpu tree: noise[s0] * scale_by (base.py:128-129)
         std::vector<int32_t> rslot; std::vector<int64_t> roff;
         for (auto &f : fresh_list)
             if (f.src_slot < 0) {
@@ -1450,22 +1509,36 @@ extern "C" int dne_ga_eval(dne_handle *h, const int32_t *co, const int64_t *seed
             HCHECK(h, hipMemcpyAsync(h->scratch_i, roff.data(), nr * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
             const Layout &L = h->L;
             const size_t st = h->base_stride;
-            hipLaunchKernelGGL(k_copy_noise_batch, dim3((L.P + 255) / 256, nr), dim3(256), 0, h->stream, (const float *)h->noise,
-                               (const int64_t *)h->scratch_i, (const int32_t *)d_slot, st, L.P, h->bases);
-            auto nc = [&](int off, int K, int C, float sd) { hipLaunchKernelGGL(k_normc_batch, dim3((C + 63) / 64, nr), dim3(64), 0, h->stream, h->bases, (const int32_t *)d_slot, st, off, K, C, sd); };
-            auto z = [&](int off, int n2) { hipLaunchKernelGGL(k_zero_batch, dim3((n2 + 63) / 64, nr), dim3(64), 0, h->stream, h->bases, (const int32_t *)d_slot, st, off, n2); };
-            nc(L.c1w, 256, 16, 1.0f); z(L.c1b, 16);
-            nc(L.c2w, 256, 32, 1.0f); z(L.c2b, 32);
-            nc(L.fcw, 3872, 256, 1.0f); z(L.fcb, 256);
-            nc(L.ow, 256, L.nact, 0.1f); z(L.ob, L.nact);
+            if (powers) {
+                hipLaunchKernelGGL(k_copy_noise_scaled_batch, dim3((L.P + 255) / 256, nr), dim3(256), 0, h->stream, (const float *)h->noise,
+                                   (const int64_t *)h->scratch_i, (const int32_t *)d_slot, st, L.P, (const float *)h->init_scale, h->bases);
+            } else {
+                hipLaunchKernelGGL(k_copy_noise_batch, dim3((L.P + 255) / 256, nr), dim3(256), 0, h->stream, (const float *)h->noise,
+                                   (const int64_t *)h->scratch_i, (const int32_t *)d_slot, st, L.P, h->bases);
+                auto nc = [&](int off, int K, int C, float sd) { hipLaunchKernelGGL(k_normc_batch, dim3((C + 63) / 64, nr), dim3(64), 0, h->stream, h->bases, (const int32_t *)d_slot, st, off, K, C, sd); };
+                auto z = [&](int off, int n2) { hipLaunchKernelGGL(k_zero_batch, dim3((n2 + 63) / 64, nr), dim3(64), 0, h->stream, h->bases, (const int32_t *)d_slot, st, off, n2); };
+                nc(L.c1w, 256, 16, 1.0f); z(L.c1b, 16);
+                nc(L.c2w, 256, 32, 1.0f); z(L.c2b, 32);
+                nc(L.fcw, 3872, 256, 1.0f); z(L.fcb, 256);
+                nc(L.ow, 256, L.nact, 0.1f); z(L.ob, L.nact);
+            }
             HCHECK(h, hipStreamSynchronize(h->stream));   // scratch is reused below
         }
     }
+    std::vector<int64_t> cs; std::vector<float> cp;
     for (auto &f : fresh_list) {
-        const auto &c = *f.chain;
-        if (f.src_slot < 0) {   // root already holds normc(noise[s0]); apply the remaining mutations in place
-            if (c.size() > 1 && build_chain(h, f.slot, c.data(), (int)c.size(), sigma, f.slot, 1)) return -1;
-        } else if (build_chain(h, f.slot, c.data(), (int)c.size(), sigma, f.src_slot, f.src_len)) return -1;
+        const auto &key = *f.chain;
+        const int len = (int)key.size() / stride;
+        cs.resize(len); cp.resize(len);
+        for (int j = 0; j < len; j++) {
+            cs[j] = key[(size_t)j * stride];
+            if (powers) { const uint32_t bits = (uint32_t)key[(size_t)j * stride + 1]; memcpy(&cp[j], &bits, 4); }
+        }
+        const float *pw = powers ? cp.data() : nullptr;
+        if (f.src_slot < 0) {   // root already initialised; apply the remaining mutations in place
+            if (len > 1 && build_chain(h, f.slot, cs.data(), pw, len, sigma, f.slot, 1)) return -1;
+        } else if (build_chain(h, f.slot, cs.data(), pw, len, sigma, f.src_slot, f.src_len)) return -1;
+        HCHECK(h, hipStreamSynchronize(h->stream));   // cs / cp are reused by the next chain
     }
     HCHECK(h, hipGetLastError());
     HCHECK(h, hipStreamSynchronize(h->stream));
@@ -1479,6 +1552,21 @@ extern "C" int dne_ga_eval(dne_handle *h, const int32_t *co, const int64_t *seed
     for (int i = 0; i < n; i++) slot[i] = needed[prefix[i]];
     if (dne_set_members(h, n, slot.data(), off.data(), sc.data())) return -1;
     return eval_core(h, n, 1, tslimit, env_seed, returns, signreturns, lengths, bc);
+}
+
+extern "C" int dne_ga_eval(dne_handle *h, const int32_t *co, const int64_t *seeds, int n, float sigma, int tslimit,
+                           const uint32_t *env_seed, float *returns, float *signreturns, int32_t *lengths, uint8_t *bc) {
+    DeviceGuard dg(h);
+    return ga_eval_impl(h, co, seeds, nullptr, n, sigma, tslimit, env_seed, returns, signreturns, lengths, bc);
+}
+
+// gpu_implementation/ga.py:161-166: offspring ((idx0,), (idx1, power1), ...) -- powers[] runs parallel to seeds[] (the root's
+// entry is ignored); needs dne_ga_set_init_scale
+extern "C" int dne_ga_eval_powers(dne_handle *h, const int32_t *co, const int64_t *seeds, const float *powers, int n, int tslimit,
+                                  const uint32_t *env_seed, float *returns, float *signreturns, int32_t *lengths, uint8_t *bc) {
+    DeviceGuard dg(h);
+    if (!powers) return h->fail("dne_ga_eval_powers: powers missing");
+    return ga_eval_impl(h, co, seeds, powers, n, 0.0f, tslimit, env_seed, returns, signreturns, lengths, bc);
 }
 
 // ------------------------------------------------------------------------------- reduce

@@ -186,8 +186,11 @@ __global__ __launch_bounds__(256) void k_axpy_noise(const float *__restrict__ no
 // ga.py:262-263 for a whole chain in one pass: dst[p] = (...((src[p] + sigma*noise[s_1 + p]) + sigma*noise[s_2 + p])...),
 // the same additions in the same order as one k_axpy_noise per seed, but theta stays in a register and the n noise
 // slices stream through once (4 (n + 2) P bytes instead of 12 n P).  Eight slices are in flight per thread.
-__global__ __launch_bounds__(256) void k_chain_sum(const float *__restrict__ noise, const int64_t *__restrict__ offs, int n, int P,
-                                                   float sigma, const float *__restrict__ src, float *__restrict__ dst) {
+// pw (may be null): one mutation power per seed (gpu_implementation/neuroevolution/models/base.py:141-149, where a genome is
+// ((idx0,), (idx1, power1), ...)); null: the same sigma for every seed (ga.py:262-263)
+__global__ __launch_bounds__(256) void k_chain_sum(const float *__restrict__ noise, const int64_t *__restrict__ offs,
+                                                   const float *__restrict__ pw, int n, int P, float sigma,
+                                                   const float *__restrict__ src, float *__restrict__ dst) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
     float v = src[p];
@@ -197,10 +200,18 @@ __global__ __launch_bounds__(256) void k_chain_sum(const float *__restrict__ noi
 #pragma unroll
         for (int j = 0; j < 8; j++) e[j] = noise[offs[s + j] + p];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { float t = sigma * e[j]; v = v + t; }
+        for (int j = 0; j < 8; j++) { float t = (pw ? pw[s + j] : sigma) * e[j]; v = v + t; }
     }
-    for (; s < n; s++) { float t = sigma * noise[offs[s] + p]; v = v + t; }
+    for (; s < n; s++) { float t = (pw ? pw[s] : sigma) * noise[offs[s] + p]; v = v + t; }
     dst[p] = v;
+}
+
+// gpu_implementation base.py:128-129: theta = noise.get(idx, num_params).copy() * self.scale_by (element-wise, float32)
+__global__ __launch_bounds__(256) void k_copy_noise_scaled_batch(const float *__restrict__ noise, const int64_t *__restrict__ offs,
+                                                                 const int32_t *__restrict__ slots, size_t stride, int P,
+                                                                 const float *__restrict__ scale_by, float *__restrict__ bases) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < P) bases[(size_t)slots[blockIdx.y] * stride + p] = noise[offs[blockIdx.y] + p] * scale_by[p];
 }
 
 // tf_util.py:122-130 _normalize on a [K][C] view: out *= std / sqrt(square(out).sum(axis=0)); the axis-0

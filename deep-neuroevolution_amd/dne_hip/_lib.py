@@ -277,6 +277,39 @@ class Engine:
                                       _ptr(bc, C.c_uint8)))
         return (ret, sg, ln, bc) if want_bc else (ret, sg, ln)
 
+    # ---- gpu-tree genomes: ((idx0,), (idx1, power1), ...)
+    def ga_set_init_scale(self, scale_by):
+        sb = _arr(scale_by, np.float32)
+        self._ck(self.lib.dne_ga_set_init_scale(self.h, _ptr(sb, C.c_float), C.c_size_t(sb.size)))
+
+    @staticmethod
+    def _split_powers(chain):
+        idx = np.array([c[0] if isinstance(c, (tuple, list)) else c for c in chain], np.int64)
+        pw = np.array([c[1] if isinstance(c, (tuple, list)) and len(c) > 1 else 0.0 for c in chain], np.float32)
+        return idx, pw
+
+    def ga_rebuild_powers(self, slot, seeds, copy_out=True):
+        idx, pw = self._split_powers(seeds)
+        out = np.empty(self.P, np.float32) if copy_out else None
+        self._ck(self.lib.dne_ga_rebuild_powers(self.h, int(slot), _ptr(idx, C.c_int64), _ptr(pw, C.c_float), int(idx.size), _ptr(out, C.c_float)))
+        return out
+
+    def ga_eval_powers(self, genomes, tslimit, env_seed, want_bc=False):
+        n = len(genomes)
+        co = np.zeros(n + 1, np.int32)
+        co[1:] = np.cumsum([len(g) for g in genomes])
+        parts = [self._split_powers(g) for g in genomes]
+        flat = _arr(np.concatenate([p[0] for p in parts]), np.int64)
+        pw = _arr(np.concatenate([p[1] for p in parts]), np.float32)
+        seeds = _arr(env_seed, np.uint32)
+        assert seeds.size == n
+        ret = np.empty(n, np.float32); sg = np.empty(n, np.float32); ln = np.empty(n, np.int32)
+        bc = self._bc_buf(n, want_bc)
+        self._ck(self.lib.dne_ga_eval_powers(self.h, _ptr(co, C.c_int32), _ptr(flat, C.c_int64), _ptr(pw, C.c_float), n, int(tslimit),
+                                             _ptr(seeds, C.c_uint32), _ptr(ret, C.c_float), _ptr(sg, C.c_float), _ptr(ln, C.c_int32),
+                                             _ptr(bc, C.c_uint8)))
+        return (ret, sg, ln, bc) if want_bc else (ret, sg, ln)
+
     def ga_rebuild(self, slot, seeds, sigma, copy_out=True):
         seeds = _arr(seeds, np.int64)
         out = np.empty(self.P, np.float32) if copy_out else None

@@ -138,6 +138,15 @@ int dne_ga_eval(dne_handle *h, const int32_t *chain_offsets /*n+1*/, const int64
 /* ga.py:151-158 / 256-264: rebuild one genome into base slot `slot` (and optionally copy it out) */
 int dne_ga_rebuild(dne_handle *h, int slot, const int64_t *seeds, int nseeds, float sigma, float *out_host);
 
+/* The gpu tree's genome form (gpu_implementation/neuroevolution/models/base.py:118-149, ga.py:161-166): seeds =
+ * ((idx0,), (idx1, power1), ...), theta = noise[idx0] * scale_by + sum_k power_k * noise[idx_k]; scale_by = the
+ * per-parameter initial scale (base.py:190-201).  powers[] runs parallel to seeds[]; the root's entry is ignored. */
+int dne_ga_set_init_scale(dne_handle *h, const float *scale_by, size_t n);
+int dne_ga_rebuild_powers(dne_handle *h, int slot, const int64_t *seeds, const float *powers, int nseeds, float *out_host);
+int dne_ga_eval_powers(dne_handle *h, const int32_t *chain_offsets /*n+1*/, const int64_t *seeds, const float *powers, int n,
+                       int tslimit, const uint32_t *env_seed, float *returns, float *signreturns, int32_t *lengths,
+                       uint8_t *bc);
+
 /* ---- A8-A10: on-device reduce ------------------------------------------------------------------------ */
 int dne_centered_ranks(dne_handle *h, const float *x, int n, float *out);           /* es.py:70-85, stable ties */
 /* es.py:291-296: g = (sum_i w[i] * noise[idx[i]:idx[i]+P]) / denom, kept on device; g_host may be NULL */

@@ -336,3 +336,16 @@ def es_init_theta(L, seed=0):
     xav(L.c1w, (8, 8, 4, 16)); xav(L.c2w, (4, 4, 16, 32)); xav(L.fcw, (3872, 256)); xav(L.ow, (256, L.nact))
     th[L.bn1g:L.bn1g + 16] = 1; th[L.bn2g:L.bn2g + 32] = 1; th[L.bn3g:L.bn3g + 256] = 1
     return th
+
+
+def ga_gpu_rebuild(noise, seeds, scale_by):
+    """gpu_implementation/neuroevolution/models/base.py:118-149 (compute_weights_from_seeds / compute_mutation), float32:
+    theta = noise.get(idx0, P).copy() * scale_by; for (idx, power) in seeds[1:]: theta = theta + power * noise.get(idx, P).
+    (`power * noise` with a Python float scalar stays float32 under numpy's value-based casting, like es.py:413.)"""
+    scale_by = np.asarray(scale_by, np.float32)
+    P = scale_by.size
+    idx0 = seeds[0][0] if isinstance(seeds[0], (tuple, list)) else seeds[0]
+    theta = noise[idx0:idx0 + P].copy() * scale_by
+    for idx, power in seeds[1:]:
+        theta = theta + np.float32(power) * noise[idx:idx + P]
+    return theta.astype(np.float32)

@@ -137,6 +137,18 @@ class OracleEngine:
         r, s, l = zip(*out)
         return np.array(r, np.float32), np.array(s, np.float32), np.array(l, np.int32)
 
+    def ga_set_init_scale(self, scale_by):
+        self.scale_by = np.asarray(scale_by, np.float32)
+
+    def ga_rebuild_powers(self, slot, seeds, copy_out=True):
+        return O.ga_gpu_rebuild(self.noise, seeds, self.scale_by)
+
+    def ga_eval_powers(self, genomes, tslimit, seeds, want_bc=False):
+        self.calls.append(("ga_eval_powers", len(genomes)))
+        out = [O.rollout(self.L, O.ga_gpu_rebuild(self.noise, g, self.scale_by), None, seeds[i], tslimit)[:3] for i, g in enumerate(genomes)]
+        r, s, l = zip(*out)
+        return np.array(r, np.float32), np.array(s, np.float32), np.array(l, np.int32)
+
     def ga_select(self, returns, t):
         return O.ga_select(returns, t)
 

@@ -108,3 +108,51 @@ def test_es_modified_vine_dumps(oracle, tmp_path):
                 assert r == row[128] and l == row[129] and np.array_equal(traj[-1], row[:128].astype(np.uint8))
             r, s, l, traj = oracle.rollout(L, theta0, me.ref, int(parent[-2]), 14, want_bc=True)
             assert r == parent[128] and l == parent[129] and np.array_equal(traj[-1], parent[:128].astype(np.uint8))
+
+
+def test_gpu_tree_ga_schedules_resume_and_elite(oracle, tmp_path):
+    """gpu_implementation/ga.py on the engine surface: schedules (helper.py:46-88), genomes with per-seed mutation power,
+    validated elite, snapshot.pkl resume -- two iterations in one go equal one iteration + a resumed one."""
+    import pickle
+    from oracle_engine import OracleEngine
+    from dne_hip import es, ga_gpu
+    assert ga_gpu.make_schedule(0.002).value(iteration=7) == 0.002
+    lin = ga_gpu.make_schedule({"type": "LinearSchedule", "schedule": 10, "initial_p": 0.01, "final_p": 0.001, "field": "iteration"})
+    assert lin.value(iteration=0) == 0.01 and abs(lin.value(iteration=5) - 0.0055) < 1e-12 and abs(lin.value(iteration=50) - 0.001) < 1e-15
+    ex = ga_gpu.make_schedule({"type": "ExponentialSchedule", "schedule": 4, "initial_p": 0.01, "final_p": 0.0001, "field": "iteration"})
+    assert abs(ex.value(iteration=2) - 0.001) < 1e-12 and abs(ex.value(iteration=9) - 0.0001) < 1e-15
+    with pytest.raises(AssertionError):
+        lin.value(timesteps_so_far=3)
+    exp = {"game": "frostbite", "model": "Model", "num_validation_episodes": 2, "num_test_episodes": 3, "population_size": 6,
+           "episode_cutoff_mode": 12, "timesteps": 10 ** 9, "validation_threshold": 2, "selection_threshold": 3,
+           "mutation_power": {"type": "LinearSchedule", "schedule": 4, "initial_p": 0.004, "final_p": 0.002, "field": "iteration"}}
+    noise = es.SharedNoiseTable(count=2_500_000)
+
+    def run(log_dir, iters):
+        eng = OracleEngine(1)
+        return ga_gpu.main(str(log_dir), engine=eng, noise=noise, seed=5, max_iters=iters, **exp), eng
+
+    (test2, val2, st2), eng2 = run(tmp_path / "a", 2)
+    assert st2.it == 2 and len(st2.population) == 6 and st2.elite is not None and val2["val"] == st2.curr_solution_val
+    fits = [o.fitness for o in st2.population]
+    assert fits == sorted(fits, reverse=True)
+    # generation 2's children: a parent genome + one (idx, power) with the scheduled power of iteration 1
+    child = next(o for o in st2.population if len(o.seeds) == 2)
+    assert isinstance(child.seeds[0], (int, np.integer)) and abs(child.seeds[1][1] - 0.0035) < 1e-12
+    assert os.path.exists(tmp_path / "a" / "snapshot.pkl")
+    st = pickle.load(open(tmp_path / "a" / "snapshot.pkl", "rb"))
+    assert st.it == 2 and [o.seeds for o in st.population] == [o.seeds for o in st2.population]
+    # the elite's weights through the engine surface = the reference formula
+    th = eng2.ga_rebuild_powers(0, st2.elite.seeds)
+    P = eng2.P
+    ref = noise.noise[st2.elite.seeds[0]:st2.elite.seeds[0] + P] * ga_gpu.model_scale_by(18)
+    for idx, power in st2.elite.seeds[1:]:
+        ref = ref + np.float32(power) * noise.noise[idx:idx + P]
+    assert np.array_equal(th, ref.astype(np.float32))
+    # resume: a second call in the same log_dir continues from iteration 2 with the saved population as parents
+    (_, _, st3), eng3 = run(tmp_path / "a", 1)
+    assert st3.it == 3 and st3.timesteps_so_far > st2.timesteps_so_far
+    assert all(tuple(o.seeds[:-1]) in [tuple(p.seeds) for p in st2.population[:3]] + [tuple(st2.elite.seeds)] for o in st3.population
+               if len(o.seeds) > 1 and o.seeds[-1][1] == pytest.approx(0.003))
+    sb = ga_gpu.model_scale_by(18)
+    assert sb.shape == (1008450,) and sb[0] == np.float32(1 / 16.0) and sb[4096] == 0.0 and abs(sb[-19] - 0.1 / 16.0) < 1e-9

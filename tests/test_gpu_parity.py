@@ -624,3 +624,34 @@ def test_es_final_ram_only(hip, oracle, small_noise, ref_batch):
             e.novelty_batch([np.zeros((3, 128), np.uint8)], ln, 1)                           # needs full trajectories
     finally:
         e.close()
+
+
+def test_gpu_tree_genomes_bit_exact(ga_engine, oracle, small_noise):
+    """Genomes of the reference's GPU tree -- ((idx0,), (idx1, power1), ...), root = noise[idx0] * scale_by, one mutation power
+    per seed (gpu_implementation/neuroevolution/models/base.py:118-149) -- rebuilt and evaluated on the device."""
+    from dne_hip import ga_gpu
+    e, O = ga_engine, oracle
+    L = O.layout(O.KIND_GA, NACT)
+    sb = ga_gpu.model_scale_by(NACT)
+    e.ga_set_init_scale(sb)
+    genomes = [(1234,), (200_000, (7, 0.002)), (2_900_000, (5, 0.004), (123_456, 0.001), (99, 0.0005)),
+               (200_000, (7, 0.002), (31_337, 0.003))]
+    for g in genomes:
+        assert np.array_equal(e.ga_rebuild_powers(1, g), O.ga_gpu_rebuild(small_noise, g, sb)), g
+    seeds = np.array([21, 22, 23, 24], np.uint32)
+    ret, sg, ln = e.ga_eval_powers(genomes, 70, seeds)
+    for i, g in enumerate(genomes):
+        r = O.rollout(L, O.ga_gpu_rebuild(small_noise, g, sb), None, seeds[i], 70)
+        assert (ret[i], sg[i], ln[i]) == r[:3], i
+    # children of the cached parents (the last mutation applied on the fly), then a plain-sigma generation on the same engine:
+    # the parent cache must not mix the two genome forms
+    kids = [genomes[1] + ((555, 0.0025),), genomes[3] + ((777_777, 0.0015),), genomes[1] + ((556, 0.0025),)]
+    ret, sg, ln = e.ga_eval_powers(kids, 70, seeds[:3])
+    for i, g in enumerate(kids):
+        r = O.rollout(L, O.ga_gpu_rebuild(small_noise, g, sb), None, seeds[i], 70)
+        assert (ret[i], sg[i], ln[i]) == r[:3], i
+    chains = [[200_000, 7], [200_000]]
+    ret, sg, ln = e.ga_eval(chains, 0.002, 50, seeds[:2])
+    for i, c in enumerate(chains):
+        r = O.rollout(L, O.ga_rebuild(L, small_noise, c, 0.002), None, seeds[i], 50)
+        assert (ret[i], sg[i], ln[i]) == r[:3], i
