@@ -1,6 +1,7 @@
 """CPU: pin the oracle against vectors produced by the REAL reference code
 (tests/golden/make_golden.py -> reference_vectors.npz) and against PIL/numpy/torch run here."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -184,3 +185,49 @@ def test_resize_against_pil(oracle):
     assert np.allclose(kh[0, :3], [0.45864663, 0.42857143, 0.11278196], atol=1e-8)
     assert np.allclose(kv[0, :4], [0.31818181, 0.40909091, 0.22727273, 0.04545455], atol=1e-8)
     assert np.allclose(kh.sum(1), 1) and np.allclose(kv.sum(1), 1)
+
+
+# ------------------------------------------------------------------ widened rows, pinned to the real reference (reference_wire.npz)
+@pytest.fixture(scope="module")
+def wire():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_wire.npz"))
+
+
+def test_reference_pickles_load_as_our_wire_types(wire):
+    """Payloads pickled BY the reference (dist.py:19-20) unpickle into dne_hip's wire types on a machine without the reference
+    (the GPU box): module path, field order and array contents survive; and our keys are the reference's."""
+    import pickle
+    from dne_hip import dist, es, es_modified, ga
+    task = pickle.loads(wire["wire_task"].tobytes())
+    assert type(task) is es.Task and task.timestep_limit == 7 and task.params.dtype == np.float32 and task.ref_batch[0].shape == (84, 84, 4)
+    gtask = pickle.loads(wire["wire_gatask"].tobytes())
+    assert type(gtask) is ga.GATask and gtask.population == [[1, 2], [3]] and gtask.timestep_limit == 9
+    tid, res = pickle.loads(wire["wire_result"].tobytes())
+    assert tid == 4 and type(res) is es.Result and res.worker_id == 3 and res.lengths_n2.dtype == np.int32
+    tid, mres = pickle.loads(wire["wire_modified_result"].tobytes())
+    assert tid == 6 and type(mres) is es_modified.Result and mres.bc_vectors[0][0].shape == (1, 128) and mres.bc_vectors[0][4] == 777
+    cfg = pickle.loads(wire["wire_config"].tobytes())
+    assert type(cfg) is es.Config and cfg.noise_stdev == 0.02 and cfg.episode_cutoff_mode == 5
+    # and the other way round: what we pickle names the reference's modules (so a reference master can load it)
+    mine = dist.serialize((4, es.Result(*res)))
+    assert b"es_distributed.es" in mine and b"dne_hip" not in mine
+    assert [str(k) for k in wire["wire_keys"]] == [dist.EXP_KEY, dist.TASK_ID_KEY, dist.TASK_DATA_KEY, dist.TASK_CHANNEL, dist.RESULTS_KEY, dist.ARCHIVE_KEY]
+
+
+def test_gpu_tree_schedules_and_genomes_match_the_reference(wire, oracle):
+    """helper.py:46-88 schedules and models/base.py:118-149 genomes against values produced by the reference's own classes."""
+    from dne_hip import ga_gpu
+    lin = ga_gpu.make_schedule({"type": "LinearSchedule", "schedule": 10, "initial_p": 0.01, "final_p": 0.001, "field": "iteration"})
+    assert [lin.value(iteration=int(i), timesteps_so_far=0) for i in wire["sched_iterations"]] == wire["sched_linear"].tolist()
+    assert ga_gpu.make_schedule(0.002).value(iteration=3) == wire["sched_constant"][0]
+    sb = ga_gpu.model_scale_by(18)
+    sel = wire["gpu_sel"]
+    assert np.array_equal(sb[sel], wire["gpu_scale_by_sel"])
+    noise = np.random.RandomState(123).randn(4_000_000).astype(np.float32)
+    idx, pw = wire["gpu_seeds_idx"], wire["gpu_seeds_power"]
+    genome = (int(idx[0]), (int(idx[1]), float(pw[1])), (int(idx[2]), float(pw[2])))
+    for n in range(3):
+        th = oracle.ga_gpu_rebuild(noise, genome[:n + 1], sb)
+        assert str(wire["gpu_theta%d_dtype" % n]) == "float32"
+        assert np.array_equal(th[sel], wire["gpu_theta%d_sel" % n]), n
+        assert th.astype(np.float64).sum() == float(wire["gpu_theta%d_sum" % n])
