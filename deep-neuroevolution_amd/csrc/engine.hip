@@ -347,6 +347,7 @@ struct dne_handle {
     dne_profile prof{};
     // GA parent cache: prefix chain -> base slot
     std::map<std::vector<int64_t>, int> ga_cache;
+    int ga_sort = 1;                 // DNE_GA_SORT: evaluate a generation's children grouped by parent
     int ga_cache_mode = 0; float ga_cache_sigma = 0.0f;   // what the cached parents were built with (1 sigma / 2 per-seed powers)
     std::vector<int> free_slots;
     // every device allocation of the handle, each between two poisoned red zones (dne_check_redzones)
@@ -606,6 +607,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
         env_int("DNE_STAGED_COPY", 0, 1, &sc);
         h->staged_copies = sc != 0;
     }
+    env_int("DNE_GA_SORT", 0, 1, &h->ga_sort);
     env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
     env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
     env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
@@ -1550,8 +1552,24 @@ static int ga_eval_impl(dne_handle *h, const int32_t *co, const int64_t *seeds, 
     for (auto &kv : needed) h->ga_cache[kv.first] = kv.second;
     std::vector<int32_t> slot(n);
     for (int i = 0; i < n; i++) slot[i] = needed[prefix[i]];
-    if (dne_set_members(h, n, slot.data(), off.data(), sc.data())) return -1;
-    return eval_core(h, n, 1, tslimit, env_seed, returns, signreturns, lengths, bc);
+    // Children of one parent sit next to each other in the member order (DNE_GA_SORT=0 keeps the caller's order): the workgroups
+    // that run side by side then stream the same parent rows, which the L2 serves once.  Members are independent, so the results
+    // are the same in any order; they are handed back in the caller's.
+    std::vector<int> order(n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    if (h->ga_sort) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return slot[a] < slot[b]; });
+    std::vector<int32_t> pslot(n); std::vector<int64_t> poff(n); std::vector<float> psc(n); std::vector<uint32_t> pseed(n);
+    for (int j = 0; j < n; j++) { const int i = order[j]; pslot[j] = slot[i]; poff[j] = off[i]; psc[j] = sc[i]; pseed[j] = env_seed[i]; }
+    if (dne_set_members(h, n, pslot.data(), poff.data(), psc.data())) return -1;
+    std::vector<float> pret(n), psg(n); std::vector<int32_t> plen(n); std::vector<uint8_t> pbc(bc ? (size_t)n * 128 : 0);
+    if (eval_core(h, n, 1, tslimit, pseed.data(), pret.data(), psg.data(), plen.data(), bc ? pbc.data() : nullptr)) return -1;
+    for (int j = 0; j < n; j++) {
+        const int i = order[j];
+        returns[i] = pret[j]; lengths[i] = plen[j];
+        if (signreturns) signreturns[i] = psg[j];
+        if (bc) memcpy(bc + (size_t)i * 128, pbc.data() + (size_t)j * 128, 128);
+    }
+    return 0;
 }
 
 extern "C" int dne_ga_eval(dne_handle *h, const int32_t *co, const int64_t *seeds, int n, float sigma, int tslimit,
