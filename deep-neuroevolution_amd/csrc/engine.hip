@@ -307,6 +307,7 @@ struct dne_handle {
     int dbg_skip = 0;   // DNE_DEBUG_SKIP bitmask (timing experiments only): 1 conv1, 2 conv2, 4 render
     int render_threads = 256;
     int conv1_fpw = 8;               // reference pass: frames per conv1 workgroup (DNE_CONV1_FPW: 1, 2, 4, 8)
+    int conv_fused = 1, conv_fused_min = 129;   // DNE_CONV_FUSED / DNE_CONV_FUSED_MIN: conv1 + conv2 in one kernel from this many members
     int conv_split_max = 32;         // members up to which the convolutions use their finest split (DNE_CONV_SPLIT_MAX)
     int fc_pairs = 2;                // ES full-width fc: antithetic pairs per work item (DNE_FC_PAIRS, 1 = k_fc<2>)
     int fc2_min_total = 800;         // k_fc2 from this many active groups upwards (DNE_FC2_MIN)
@@ -608,6 +609,10 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
         h->staged_copies = sc != 0;
     }
     env_int("DNE_GA_SORT", 0, 1, &h->ga_sort);
+    env_int("DNE_CONV_FUSED", 0, 1, &h->conv_fused);
+    env_int("DNE_CONV_FUSED_MIN", 1, 1 << 20, &h->conv_fused_min);
+    CH(hipFuncSetAttribute((const void *)k_conv12<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
+    CH(hipFuncSetAttribute((const void *)k_conv12<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
     env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
     env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
     env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
@@ -1078,6 +1083,12 @@ static void launch_forward(dne_handle *h, const int *list, int count, int gsize,
     const int items = count * gsize;
     // few members left: several workgroups per member (conv1: 28 position tiles over 4 or 7 workgroups; conv2: 8 over 2 or 4)
     const int s1 = items <= h->conv_split_max ? 7 : items <= 64 ? 4 : 1, s2 = items <= h->conv_split_max ? 4 : items <= 128 ? 2 : 1;
+    if (h->conv_fused && items >= h->conv_fused_min && !h->dbg_skip) {   // one workgroup per member through both convolutions, y1 stays in LDS
+        float *y1 = use_done ? nullptr : h->y1;                           // dne_act / debug_activations want y1; evaluations do not
+        if (es) hipLaunchKernelGGL((k_conv12<true>), dim3(items), dim3(256), sizeof(Conv12Lds), st, A, list, gsize, (const uint8_t *)h->stacks, y1, h->y2);
+        else hipLaunchKernelGGL((k_conv12<false>), dim3(items), dim3(256), sizeof(Conv12Lds), st, A, list, gsize, (const uint8_t *)h->stacks, y1, h->y2);
+        return;
+    }
     if (!(h->dbg_skip & 1))
     hipLaunchKernelGGL(k_conv1, dim3(items * s1), dim3(256), 0, st, A, list, gsize, 1, 0,
                        (const uint8_t *)h->stacks, (const uint8_t *)nullptr, h->y1, s1);
@@ -1863,6 +1874,23 @@ extern "C" int dne_allgather_results(dne_handle *h, int n_local, int n_global, v
     h->rec_n = n_global;
     if (records_out) memcpy(records_out, host.data(), (size_t)n_global * sizeof(PairRecord));
     return check_records_host(h, n_global);
+}
+
+// Test hook for the one piece of the N > 1 exchange that a one-GPU box cannot reach through RCCL: the device-side un-sharding
+// of a [world][per] all-gather result into global pair order.  gathered: what ncclAllGather would have produced.
+extern "C" int dne_debug_unshard(dne_handle *h, const void *gathered, int n_global, int world, void *ordered_out) {
+    DeviceGuard dg(h);
+    if (n_global < 1 || world < 1) return h->fail("dne_debug_unshard: bad sizes");
+    const int per = (n_global + world - 1) / world;
+    if (rec_reserve(h, n_global, per * world)) return -1;
+    PairRecord *g = (PairRecord *)h->rec_recv, *ordered = g + (size_t)per * world;
+    HCHECK(h, hipMemcpyAsync(g, gathered, (size_t)per * world * sizeof(PairRecord), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_records_unpack, dim3((n_global + 255) / 256), dim3(256), 0, h->stream, (const PairRecord *)g, n_global, world, per,
+                       h->rec_idx, h->rec_ret, h->rec_sign, h->rec_len, ordered);
+    HCHECK(h, hipGetLastError());
+    HCHECK(h, hipMemcpyAsync(ordered_out, ordered, (size_t)n_global * sizeof(PairRecord), hipMemcpyDeviceToHost, h->stream));
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    return 0;
 }
 
 // es.py:281-298 on the gathered, device-resident records: process returns, aggregate, optimizer step

@@ -415,6 +415,163 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
     conv2_body<HAS_BN>(S, A, it, y1, y2, blockIdx.x % nsplit, nsplit, fr);
 }
 
+// ------------------------------------------------------------------------------- conv1 -> conv2 in one kernel (lock-steps)
+// At full width a window's lock-step is a serial chain conv1 -> conv2 -> fc -> emulator, each link stretched by the other
+// windows' HBM streams; y1 (28 KB per member) made a round trip through the memory system between the first two.  Here one
+// workgroup takes a member through both convolutions: conv1's epilogue applies bn1 + relu and writes straight into conv2's
+// padded LDS image.  Same tiles, same MFMA order, same
+// bits as k_conv1 + k_conv2; y1 is written out only when asked (dne_debug_activations, dne_act).
+struct Conv12Lds {
+    float lut[256];
+    uint32_t img[88 * 88];
+    float a_s[24 * C2_RW * C2_PS];
+};
+
+template <bool HAS_BN>
+__global__ __launch_bounds__(256, 2) void k_conv12(FwdArgs A, const int *__restrict__ list, int gsize,
+                                                const uint8_t *__restrict__ stacks, float *__restrict__ y1 /*may be null*/,
+                                                float *__restrict__ y2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char conv12_raw[];
+    Conv12Lds &S = *reinterpret_cast<Conv12Lds *>(conv12_raw);
+    const Item it = decode_item(blockIdx.x, list, gsize, 1, 0, stacks, nullptr, A.done);
+    if (it.skip) return;
+    constexpr int PS = C2_PS, RW = C2_RW;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, ci = lane >> 4;
+    const float *base = A.bases + (size_t)A.m_slot[it.member] * A.base_stride;
+    const float *eps = A.noise + A.m_off[it.member];
+    const float sc = A.m_scale[it.member];
+    const float *bn = A.bn + (size_t)it.member * 608;
+    // ---- everything both convolutions need from memory, issued up front
+    uint32_t px[28];
+#pragma unroll
+    for (int j = 0; j < 28; j++) {
+        const int e = tid + 256 * j;
+        px[j] = e < 7056 ? ((const uint32_t *)it.ob)[e] : 0u;
+    }
+    float b[64];
+    {
+        const float *b1 = base + A.L.c1w, *e1 = eps + A.L.c1w;
+#pragma unroll
+        for (int kk = 0; kk < 64; kk++) {
+            float v = sc * e1[64 * kk + lane];
+            b[kk] = b1[64 * kk + lane] + v;
+        }
+    }
+    float pb1 = sc * eps[A.L.c1w + 4096 + lp];
+    const float bias1 = base[A.L.c1w + 4096 + lp] + pb1;
+    const float s1 = HAS_BN ? bn[lp] : 1.0f, h1 = HAS_BN ? bn[16 + lp] : 0.0f;      // conv1's output channel of this lane = lp
+    const int nt = wv & 1, mt0 = 4 * (wv >> 1), lk = ci;
+
+    float pb2 = sc * eps[A.L.c2w + 8192 + nt * 16 + lp];
+    const float bias2 = base[A.L.c2w + 8192 + nt * 16 + lp] + pb2;
+    S.lut[tid] = (float)tid / 255.0f;
+    for (int i = tid; i < 688; i += 256) {                                            // conv1's 2-pixel zero border
+        int r, c;
+        if (i < 352) { r = i / 88; r = r < 2 ? r : 84 + r; c = i % 88; }
+        else { const int j = i - 352; r = 2 + j / 4; c = j % 4; c = c < 2 ? c : 84 + c; }
+        S.img[r * 88 + c] = 0u;
+    }
+    for (int pix = tid; pix < 24 * 24; pix += 256) {                                  // conv2's SAME-padding ring
+        const int y = pix / 24, x = pix % 24;
+        if (y < 1 || y > 21 || x < 1 || x > 21)
+#pragma unroll
+            for (int c = 0; c < 16; c++) S.a_s[(y * RW + x) * PS + c] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 28; j++) {
+        const int e = tid + 256 * j;
+        if (e < 7056) S.img[(e / 84 + 2) * 88 + e % 84 + 2] = px[j];
+    }
+    __syncthreads();
+    // ---- conv1: 28 position tiles, 7 per wave (three pairs + one single), exactly k_conv1's schedule
+    float *out1 = y1 ? y1 + (size_t)it.row * 7056 : nullptr;
+    auto run1 = [&](int j, auto has_b) {
+        constexpr bool HASB = decltype(has_b)::value;
+        const int tA = wv + 4 * j, tB = wv + 4 * (j + 1);
+        const int pA = min(tA * 16 + lp, 440), pB = HASB ? min(tB * 16 + lp, 440) : 0;
+        const int oA = (pA / 21) * 4 * 88 + (pA % 21) * 4, oB = (pB / 21) * 4 * 88 + (pB % 21) * 4;
+        f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 8; kh++) {
+#pragma unroll
+            for (int kw = 0; kw < 8; kw++) {
+                const float xA = S.lut[(S.img[oA + kh * 88 + kw] >> (8 * ci)) & 255u];
+                accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xA, b[kh * 8 + kw], accA, 0, 0, 0);
+                if (HASB) {
+                    const float xB = S.lut[(S.img[oB + kh * 88 + kw] >> (8 * ci)) & 255u];
+                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xB, b[kh * 8 + kw], accB, 0, 0, 0);
+                }
+            }
+        }
+        auto emit = [&](const f32x4 &acc, int t) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {   // D[row = 4*(l>>4) + r][col = l&15]
+                const int pos = t * 16 + ci * 4 + r;
+                if (pos < 441) {
+                    const float y = acc[r] + bias1;
+                    if (out1) out1[pos * 16 + lp] = y;
+                    float a = y;
+                    if (HAS_BN) {
+                        a = a * s1;
+                        a = a + h1;
+                    }
+                    S.a_s[((pos / 21 + 1) * RW + pos % 21 + 1) * PS + lp] = a > 0.0f ? a : 0.0f;
+                }
+            }
+        };
+        emit(accA, tA);
+        if (HASB) emit(accB, tB);
+    };
+    run1(0, std::true_type{});
+    run1(2, std::true_type{});
+    run1(4, std::true_type{});
+    run1(6, std::false_type{});
+    // ---- conv2: its perturbed weights (fetching them before conv1 costs 69 spilled registers and was slower), then four
+    //      position tiles per wave over the image conv1 just wrote
+    float b2[64];
+    {
+        const float *w2 = base + A.L.c2w, *ee = eps + A.L.c2w;
+#pragma unroll
+        for (int kk = 0; kk < 64; kk++) {
+            const int o = (4 * kk + lk) * 32 + nt * 16 + lp;
+            float v = sc * ee[o];
+            b2[kk] = w2[o] + v;
+        }
+    }
+    __syncthreads();
+    int off[4];
+    f32x4 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int p = min((mt0 + m) * 16 + lp, 120);
+        off[m] = ((p / 11) * 2 * RW + (p % 11) * 2) * PS + lk;
+        acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int kh = 0; kh < 4; kh++) {
+#pragma unroll
+        for (int kw = 0; kw < 4; kw++) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++) {   // k = (kh*4+kw)*16 + c4*4 + (l>>4)
+                const int kk = (kh * 4 + kw) * 4 + c4;
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const float x = S.a_s[off[m] + (kh * RW + kw) * PS + c4 * 4];
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, b2[kk], acc[m], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float *o = y2 + (size_t)it.row * 3872;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int pos = (mt0 + m) * 16 + lk * 4 + r;
+            if (pos < 121) o[pos * 32 + nt * 16 + lp] = acc[m][r] + bias2;
+        }
+}
+
 // ------------------------------------------------------------------------- fc (+ out + argmax)
 // The HBM-bound kernel: streams the 3872x256 noise slice once per workgroup.  4 waves = the 4 k-slices;
 // lane l owns output columns 4l..4l+3 (one 16-byte load per lane per row = 1 KiB per wave-instruction).

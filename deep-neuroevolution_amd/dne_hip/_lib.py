@@ -386,6 +386,12 @@ class Engine:
         self._ck(self.lib.dne_allgather_results(self.h, int(n_local), int(n_global), rec.ctypes.data_as(C.c_void_p)))
         return rec
 
+    def debug_unshard(self, gathered, n_global, world):
+        g = np.ascontiguousarray(gathered, RECORD)
+        out = np.zeros(int(n_global), RECORD)
+        self._ck(self.lib.dne_debug_unshard(self.h, g.ctypes.data_as(C.c_void_p), int(n_global), int(world), out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def records_pack(self, n_local):
         rec = np.zeros(int(n_local), RECORD)
         self._ck(self.lib.dne_records_pack(self.h, int(n_local), rec.ctypes.data_as(C.c_void_p)))

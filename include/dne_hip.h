@@ -179,6 +179,8 @@ int dne_comm_allgather(dne_handle *h, const void *send, size_t bytes, void *recv
 /* all-gather of the records of the n_local pairs this rank evaluated in its last dne_es_eval, taken from the device
  * accumulators; the gathered set stays on the device in global pair order.  records_out: [n_global] records or NULL */
 int dne_allgather_results(dne_handle *h, int n_local, int n_global, void *records_out);
+/* test hook: un-shard a [nranks][ceil(n_global / nranks)] all-gather result (host copy) into global pair order on the device */
+int dne_debug_unshard(dne_handle *h, const void *gathered, int n_global, int nranks, void *ordered_out);
 /* other transports (the redis Result path, gloo in the CPU tests): this rank's shard out / the gathered set in */
 int dne_records_pack(dne_handle *h, int n_local, void *records_out /*[n_local]*/);
 int dne_records_set(dne_handle *h, const void *records /*[n_global], global pair order*/, int n_global);

@@ -154,6 +154,8 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
     {"DNE_RENDER_BANDS": "7", "DNE_BAND_THREADS": "1024"},              # frame split over 7 workgroups
     {"DNE_NSUB": "3", "DNE_FC_TAIL_MAX": "2", "DNE_FC2_MIN": "4"},      # three windows, k_fc2 / k_fc / tail kernels as the list shrinks
     {"DNE_RENDER_BANDS": "2"},                                          # two render workgroups per member
+    {"DNE_CONV_FUSED_MIN": "1"},                                        # conv1 + conv2 in one kernel (k_conv12) at every count
+    {"DNE_CONV_FUSED": "0", "DNE_CONV_SPLIT_MAX": "0"},                 # never: separate k_conv1 / k_conv2 launches
 ])
 def test_every_step_kernel_variant_is_bit_exact(knobs, oracle, small_noise, monkeypatch):
     """the engine picks its lock-step kernels by active count; the tuning knobs force each variant onto a population small

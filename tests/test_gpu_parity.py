@@ -550,6 +550,25 @@ def test_exchange_records_roundtrip(es_engine, oracle, small_noise, ref_batch):
         e.records_set(bad)                     # a noise index outside the table never reaches the aggregate kernel
 
 
+@pytest.mark.parametrize("n_global,world", [(7, 2), (2500, 8), (2500, 3), (5, 8), (64, 4)])
+def test_unshard_matches_the_host_transport(es_engine, n_global, world):
+    """The device-side un-sharding of an all-gather result (what dne_allgather_results runs after ncclAllGather) against the
+    host transport's reordering (es.allgather_records): ragged shards, more ranks than pairs."""
+    from dne_hip import es
+    e = es_engine
+    rs = np.random.RandomState(n_global * 31 + world)
+    full = np.zeros(n_global, es.RECORD)
+    full["noise_idx"] = rs.randint(0, 2 ** 40, n_global)
+    full["ret"] = rs.randn(n_global, 2).astype(np.float32); full["aux"] = rs.randn(n_global, 2).astype(np.float32)
+    full["len"] = rs.randint(1, 5000, (n_global, 2))
+    per = (n_global + world - 1) // world
+    gathered = np.zeros((world, per), es.RECORD)
+    for r in range(world):
+        ids = es.shard_pairs(n_global, r, world)
+        gathered[r, :len(ids)] = full[ids]
+    assert e.debug_unshard(gathered, n_global, world).tobytes() == full.tobytes()
+
+
 def test_rccl_single_rank_comm(hip, oracle, small_noise, ref_batch):
     O = oracle
     L = O.layout(O.KIND_ES, NACT)
