@@ -324,6 +324,8 @@ struct dne_handle {
     float *opt_m = nullptr, *opt_v = nullptr, *g = nullptr; int opt_t = 0;
     double *partial = nullptr;
     uint8_t *ref = nullptr; bool ref_set = false;
+    float *ref_f32 = nullptr;        // the reference frames as padded planar floats (k_conv1_ref_shared)
+    int conv1_shared = 1;            // DNE_CONV1_SHARED: reference-pass conv1 with eight members sharing a frame in LDS
     int32_t *m_slot = nullptr; int64_t *m_off = nullptr; float *m_scale = nullptr;
     float *bn = nullptr, *bn_mom = nullptr;
     uint8_t *ram_prev = nullptr, *ram_cur = nullptr, *stacks = nullptr;
@@ -643,6 +645,10 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipMemset(h->opt_m, 0, h->L.P * sizeof(float))); CH(hipMemset(h->opt_v, 0, h->L.P * sizeof(float)));
     CH(h->alloc(&h->partial, 2 * ((size_t)h->L.P / 256 + 1), "partial"));
     if (h->F) CH(h->alloc(&h->ref, (size_t)h->F * OB_BYTES, "ref"));
+    if (h->F) CH(h->alloc(&h->ref_f32, (size_t)h->F * RF_FRAME, "ref_f32"));
+    env_int("DNE_CONV1_SHARED", 0, 1, &h->conv1_shared);
+    CH(hipFuncSetAttribute((const void *)k_conv1_ref_shared<16>, hipFuncAttributeMaxDynamicSharedMemorySize, RF_FRAME * (int)sizeof(float)));
+    CH(hipFuncSetAttribute((const void *)k_conv1_ref_shared<8>, hipFuncAttributeMaxDynamicSharedMemorySize, RF_FRAME * (int)sizeof(float)));
     CH(h->alloc(&h->m_slot, M, "m_slot")); CH(h->alloc(&h->m_off, M, "m_off")); CH(h->alloc(&h->m_scale, M, "m_scale"));
     CH(hipMemset(h->m_slot, 0, M * sizeof(int32_t))); CH(hipMemset(h->m_off, 0, M * sizeof(int64_t)));
     CH(hipMemset(h->m_scale, 0, M * sizeof(float)));
@@ -866,6 +872,9 @@ extern "C" int dne_set_ref_batch(dne_handle *h, const uint8_t *ref, int count) {
     if (h->L.kind != DNE_KIND_ES) return h->fail("reference batch is an ESAtariPolicy concept");
     if (count != h->F) return h->fail("dne_set_ref_batch: engine was created for %d reference frames, got %d", h->F, count);
     HCHECK(h, hipMemcpy(h->ref, ref, (size_t)count * OB_BYTES, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_ref_to_float, dim3((count * RF_FRAME + 255) / 256), dim3(256), 0, h->stream, (const uint8_t *)h->ref, count, h->ref_f32);
+    HCHECK(h, hipGetLastError());
+    HCHECK(h, hipStreamSynchronize(h->stream));
     h->ref_set = true;
     return 0;
 }
@@ -1015,7 +1024,11 @@ static int ref_pass(dne_handle *h, int n) {
         float *fr1 = h->fr1[w], *fr2 = h->fr2[w];
         const int fpw = h->conv1_fpw >= 8 ? 8 : h->conv1_fpw >= 4 ? 4 : h->conv1_fpw >= 2 ? 2 : 1;   // F is a multiple of 8
 #define C1R(FPW) hipLaunchKernelGGL(k_conv1_ref<FPW>, dim3(nc * F / FPW), dim3(256), 0, st, A, F, m0, (const uint8_t *)h->ref, y1, fr1)
-        if (fpw == 8) C1R(8); else if (fpw == 4) C1R(4); else if (fpw == 2) C1R(2); else C1R(1);
+#define C1S(FPW) hipLaunchKernelGGL(k_conv1_ref_shared<FPW>, dim3((nc + 7) / 8 * (F / FPW)), dim3(512), RF_FRAME * sizeof(float), st, A, F, m0, nc, (const float *)h->ref_f32, y1, fr1)
+        if (h->conv1_shared && fpw == 8 && F % 16 == 0) C1S(16);
+        else if (h->conv1_shared && fpw == 8) C1S(8);
+        else if (fpw == 8) C1R(8); else if (fpw == 4) C1R(4); else if (fpw == 2) C1R(2); else C1R(1);
+#undef C1S
 #undef C1R
         // the convolutions leave per-frame moments behind; scale / shift per member is a 128-term sum per channel
         hipLaunchKernelGGL((k_bn_finalize<16>), dim3((nc * 16 + 255) / 256), dim3(256), 0, st, A, m0, nc, F, (const float *)fr1, 441, 0,

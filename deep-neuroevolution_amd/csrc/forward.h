@@ -290,6 +290,119 @@ __global__ __launch_bounds__(256) void k_conv1_ref(FwdArgs A, int F, int member0
     }
 }
 
+// Reference-pass conv1, shared-image form (round 2).  The 128 reference frames are the same for every member, so eight members
+// (one wave each, its perturbed weights in 64 VGPRs for the whole workgroup) share ONE frame at a time in LDS -- stored as
+// floats, planar per channel, already divided by 255 (k_ref_to_float, once per dne_set_ref_batch; the same (float)u8 / 255.0f as
+// the table of k_conv1).  A lane's operands for four consecutive taps are then one 16-byte LDS read and no table lookup, no byte
+// extraction: 0.25 LDS instructions per MFMA instead of 2.  Same taps in the same order, same tile sums, same bits as
+// k_conv1_ref.  The next frame is fetched into registers under the MFMAs of the current one.
+constexpr int RF_W = 88, RF_PLANE = 88 * 88, RF_FRAME = 4 * RF_PLANE;   // padded float frame: [4 channels][88][88]
+
+__global__ __launch_bounds__(256) void k_ref_to_float(const uint8_t *__restrict__ ref, int F, float *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= F * RF_FRAME) return;
+    const int f = i / RF_FRAME, c = (i / RF_PLANE) % 4, r = (i / RF_W) % 88, x = i % RF_W;
+    float v = 0.0f;
+    if (r >= 2 && r < 86 && x >= 2 && x < 86) v = (float)ref[(size_t)f * OB_BYTES + ((r - 2) * 84 + (x - 2)) * 4 + c] / 255.0f;
+    out[i] = v;
+}
+
+template <int FPW>
+__global__ __launch_bounds__(512) void k_conv1_ref_shared(FwdArgs A, int F, int member0, int n_local, const float *__restrict__ reff,
+                                                          float *__restrict__ y1 /*[n_local * F][441][16]*/,
+                                                          float *__restrict__ fr /*[n_local * F][2][16]*/) {
+    extern __shared__ __attribute__((aligned(16))) float imgf[];   // [4][88][88]
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, ci = lane >> 4;
+    const int gpm = F / FPW;
+    const int mloc = (blockIdx.x / gpm) * 8 + wv, f0 = (blockIdx.x % gpm) * FPW;
+    const bool live = mloc < n_local;
+    const int member = member0 + (live ? mloc : 0);
+    const float *base = A.bases + (size_t)A.m_slot[member] * A.base_stride + A.L.c1w;
+    const float *eps = A.noise + A.m_off[member] + A.L.c1w;
+    const float sc = A.m_scale[member];
+    constexpr int NV4 = RF_FRAME / 4 / 512 + 1;   // 16-byte words of a frame per thread (7744 = 15.1 x 512)
+    f32x4 pf[NV4];
+    auto fetch = [&](int f) {
+        const f32x4 *src = (const f32x4 *)(reff + (size_t)f * RF_FRAME);
+#pragma unroll
+        for (int j = 0; j < NV4; j++) {
+            const int e = tid + 512 * j;
+            pf[j] = e < RF_FRAME / 4 ? src[e] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < NV4; j++) {
+            const int e = tid + 512 * j;
+            if (e < RF_FRAME / 4) ((f32x4 *)imgf)[e] = pf[j];
+        }
+    };
+    fetch(f0);
+    float b[64];
+#pragma unroll
+    for (int kk = 0; kk < 64; kk++) {
+        float v = sc * eps[64 * kk + lane];
+        b[kk] = base[64 * kk + lane] + v;
+    }
+    float pb = sc * eps[4096 + lp];
+    const float bias = base[4096 + lp] + pb;
+    stage();
+    __syncthreads();
+    const float *plane = imgf + ci * RF_PLANE;
+    for (int fi = 0; fi < FPW; fi++) {
+        if (fi + 1 < FPW) fetch(f0 + fi + 1);        // in flight under the MFMAs below
+        float *out = y1 + ((size_t)mloc * F + f0 + fi) * 7056;
+        float Ws[4] = {0.f, 0.f, 0.f, 0.f}, Wq[4] = {0.f, 0.f, 0.f, 0.f};   // tile t adds to group t % 4, in tile order (bn_finish_tiles)
+        if (live) {
+            auto round2 = [&](int tA, float &WsA, float &WqA, float &WsB, float &WqB) {   // tiles tA, tA + 1 on two accumulators
+                const int tB = tA + 1;
+                const int pA = min(tA * 16 + lp, 440), pB = min(tB * 16 + lp, 440);
+                const float *qA = plane + (pA / 21) * 4 * RF_W + (pA % 21) * 4, *qB = plane + (pB / 21) * 4 * RF_W + (pB % 21) * 4;
+                f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kh = 0; kh < 8; kh++) {
+                    const f32x4 a0 = *(const f32x4 *)(qA + kh * RF_W), a1 = *(const f32x4 *)(qA + kh * RF_W + 4);
+                    const f32x4 c0 = *(const f32x4 *)(qB + kh * RF_W), c1 = *(const f32x4 *)(qB + kh * RF_W + 4);
+#pragma unroll
+                    for (int kw = 0; kw < 4; kw++) {
+                        accA = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[kw], b[kh * 8 + kw], accA, 0, 0, 0);
+                        accB = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[kw], b[kh * 8 + kw], accB, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int kw = 0; kw < 4; kw++) {
+                        accA = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kw], b[kh * 8 + 4 + kw], accA, 0, 0, 0);
+                        accB = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[kw], b[kh * 8 + 4 + kw], accB, 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int posA = tA * 16 + ci * 4 + r, posB = tB * 16 + ci * 4 + r;
+                    if (posA < 441) out[posA * 16 + lp] = accA[r] + bias;
+                    if (posB < 441) out[posB * 16 + lp] = accB[r] + bias;
+                }
+                tile_moments(accA, tA * 16 + ci * 4, 441, WsA, WqA);
+                tile_moments(accB, tB * 16 + ci * 4, 441, WsB, WqB);
+            };
+#pragma unroll 1
+            for (int r4 = 0; r4 < 7; r4++) {         // tiles 4 r4 .. 4 r4 + 3: one tile for each of the four groups, in tile order
+                round2(4 * r4, Ws[0], Wq[0], Ws[1], Wq[1]);
+                round2(4 * r4 + 2, Ws[2], Wq[2], Ws[3], Wq[3]);
+            }
+            if (ci == 0) {   // frame moments: (W0 + W1) + (W2 + W3) per channel
+                const float slo = Ws[0] + Ws[1], shi = Ws[2] + Ws[3], qlo = Wq[0] + Wq[1], qhi = Wq[2] + Wq[3];
+                float *dst = fr + ((size_t)mloc * F + f0 + fi) * 2 * 16;
+                dst[lp] = slo + shi;
+                dst[16 + lp] = qlo + qhi;
+            }
+        }
+        if (fi + 1 < FPW) {
+            __syncthreads();                         // every wave is done reading this frame
+            stage();
+            __syncthreads();
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ conv2
 // 4x4 stride 2 SAME(1,2); input = relu(bn1(y1)) formed while staging; y2[row][121][32] raw.
 // GEMM view [121 -> 128 positions] x [256 = (kh,kw,ci)] x [32 co] on the same fp32 MFMA: wave w owns

@@ -150,6 +150,7 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
     {"DNE_RENDER_BANDS": "1"},                                          # quad fc + tail step rendering in place
     {"DNE_CONV1_FPW": "1"},                                             # reference-pass conv1 with one frame per workgroup (default 8)
     {"DNE_CONV1_FPW": "4"},
+    {"DNE_CONV1_SHARED": "0"},                                          # reference-pass conv1 per member (k_conv1_ref<8>) instead of the shared float image
     {"DNE_CONV_SPLIT_MAX": "0"},                                        # convolutions with 4 / 2 workgroups per member instead of 7 / 4
     {"DNE_RENDER_BANDS": "7", "DNE_BAND_THREADS": "1024"},              # frame split over 7 workgroups
     {"DNE_NSUB": "3", "DNE_FC_TAIL_MAX": "2", "DNE_FC2_MIN": "4"},      # three windows, k_fc2 / k_fc / tail kernels as the list shrinks
