@@ -268,3 +268,30 @@ def test_emulator_step_from_crafted_states(eng, oracle):
             seen["level_up"] += int(ram[21] > cur[i, 21]); seen["game_over"] += int(over); seen["reward"] += int(tot > 0)
             seen["direction_flip"] += int(np.any(ram[34:38] != cur[i, 34:38]))
     assert all(v > 0 for v in seen.values()), seen
+
+
+@pytest.mark.parametrize("nref,members", [(8, 3), (24, 9), (40, 5), (32, 17), (64, 2)])
+def test_reference_batch_sizes(nref, members, oracle, small_noise):
+    """Virtual batch norm over reference batches other than the reference's 128 frames (es.py:160-162 takes any batch_size): multiples
+    of 8 that are / are not multiples of 16 (the shared-image conv1 takes 16 or 8 frames per workgroup), the matrix-core fc path
+    (16, 32, 64, 128 frames) and the generic one, member counts that do not fill the last eight-member workgroup."""
+    from dne_hip import _lib
+    e = _lib.Engine(_lib.KIND_ES, NACT, max_members=32, ref_count=nref)
+    try:
+        e.noise_upload(small_noise)
+        L = oracle.layout(0, NACT)
+        th = oracle.es_init_theta(L, 0)
+        e.set_theta(th)
+        ref = oracle.get_ref_batch(seed=3, batch_size=nref, nact=NACT)
+        e.set_ref_batch(ref)
+        rs = np.random.RandomState(nref)
+        off = rs.randint(0, small_noise.size - L.P, members).astype(np.int64)
+        scale = rs.choice([0.02, -0.02, 0.0, 0.1], members).astype(np.float32)
+        e.set_members(np.zeros(members, np.int32), off, scale)
+        e.ref_pass(members)
+        bn, mom = e.get_bn(members), e.get_bn_moments(members)
+        for i in (0, members - 1, members // 2):
+            obn, omom = oracle.es_ref_pass_moments(L, th + np.float32(scale[i]) * small_noise[off[i]:off[i] + L.P], ref)
+            assert np.array_equal(bn[i], obn) and np.array_equal(mom[i], omom), (nref, i)
+    finally:
+        e.close()
