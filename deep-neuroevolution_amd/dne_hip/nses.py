@@ -170,3 +170,47 @@ def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2,
             worker_id=worker_id, noise_inds_n=noise_inds, returns_n2=returns, signreturns_n2=novelty,
             lengths_n2=lengths, eval_return=None, eval_length=None, ob_sum=None, ob_sumsq=None, ob_count=0))
         pacer.pushed(task_id)
+
+
+# ---------------------------------------------------------------------------------------------- co-located GPUs (config 4)
+def blend_and_update(engine, rec, algo_type, return_proc_mode, l2coeff, optimizer):
+    """nses.py:217-236 on the gathered records: process the novelty (riding in the aux slot, Q7) by return_proc_mode, for
+    NSR-ES average with the reward ranks, then aggregate and step.  Identical inputs on every rank -> identical theta."""
+    returns_n2, nov_n2 = np.ascontiguousarray(rec['ret']), np.ascontiguousarray(rec['aux'])
+    if return_proc_mode == 'centered_rank':
+        proc = engine.centered_ranks(returns_n2)
+    elif return_proc_mode == 'sign':
+        proc = nov_n2
+    elif return_proc_mode == 'centered_sign_rank':
+        proc = engine.centered_ranks(nov_n2)
+    else:
+        raise NotImplementedError(return_proc_mode)
+    if algo_type == "nsr":
+        proc = ((engine.centered_ranks(returns_n2) + proc) / 2.0).astype(np.float32)
+    engine.weighted_sum(rec['noise_idx'], proc[:, 0] - proc[:, 1], float(returns_n2.size), copy_out=False)
+    return engine.optimizer_step(optimizer['type'], l2coeff, *optimizer_args(optimizer))
+
+
+def nses_generation(engine, noise_len, config, algo_type, archive, k, n_pairs, generation, tslimit, optimizer, rank=0, world=1,
+                    transport=None):
+    """One NS-ES / NSR-ES generation of the current parent on this rank's shard: rollouts record their
+    RAM trajectories in HBM, dne_novelty_batch scores them against the (replicated, device-resident) archive, only the
+    32-byte records -- novelty in the aux slot -- travel (engine.comm_allgather = RCCL, or `transport` on the host), and
+    every rank runs the same blend + update.  Returns (records[N], update_ratio)."""
+    from .es import RECORD, generation_inputs, pack_records
+    mine, idx, seeds = generation_inputs(noise_len, engine.P, n_pairs, generation, rank, world)
+    ret, _, ln = engine.es_eval(idx, config.noise_stdev, tslimit, seeds)
+    nov = engine.novelty_batch(archive, ln, k).astype(np.float32).reshape(-1, 2)       # nses.py:381-384
+    rec = pack_records(idx, ret, ln, nov)
+    if world > 1:
+        per = (n_pairs + world - 1) // world
+        buf = np.zeros(per, RECORD)
+        buf[:len(rec)] = rec
+        gathered = (engine.comm_allgather(buf) if transport is None else transport(buf, world)).reshape(world, per)
+        full = np.zeros(n_pairs, RECORD)
+        for r in range(world):
+            ids = shard_pairs(n_pairs, r, world)
+            full[ids] = gathered[r, :len(ids)]
+        rec = full
+    ratio = blend_and_update(engine, rec, algo_type, config.return_proc_mode, config.l2coeff, optimizer)
+    return rec, ratio

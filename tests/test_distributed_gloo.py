@@ -151,3 +151,79 @@ def test_ga_two_ranks_gloo_same_elites():
         pop, score = ga.truncate(eng, cand, cand_ret, GA_PARENTS)
     assert repr(pop) == out[0][1] and score.tobytes() == out[0][2]
     assert len(pop) == GA_PARENTS and all(len(c) >= 1 for c in pop) and max(len(c) for c in pop) >= 2
+
+
+# ------------------------------------------------------------------------------------------------ NS-ES / NSR-ES, two ranks
+def _nses_engine():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    from oracle_engine import OracleEngine
+    from dne_hip import policies
+    eng = OracleEngine(0, ref_count=16, bc_max_steps=TSLIMIT)
+    eng.noise_upload(np.random.RandomState(123).randn(NOISE).astype(np.float32))
+    eng.set_theta(policies.xavier_flat(18, 0))
+    eng.set_ref_batch(O.get_ref_batch(seed=0, batch_size=16))
+    return eng
+
+
+def _archive():
+    rs = np.random.RandomState(77)
+    return [rs.randint(0, 256, (n, 128)).astype(np.uint8) for n in (9, 4, 10)]
+
+
+def _nses_config():
+    from dne_hip import es
+    return es.Config(l2coeff=0.005, noise_stdev=0.02, episodes_per_batch=2 * N_PAIRS, timesteps_per_batch=10, calc_obstat_prob=0.0,
+                     eval_prob=0.0, snapshot_freq=0, return_proc_mode="centered_sign_rank", episode_cutoff_mode=TSLIMIT)
+
+
+def _nses_rank_main(rank, world, port, q):
+    for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "deep-neuroevolution_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from dne_hip import nses
+    eng = _nses_engine()
+    out = []
+    for g, algo in enumerate(("ns", "nsr")):
+        rec, _ = nses.nses_generation(eng, NOISE, _nses_config(), algo, _archive(), 2, N_PAIRS, g, TSLIMIT, OPT, rank, world,
+                                      transport=_gloo_allgather_bytes)
+        out.append(rec.tobytes())
+    q.put((rank, eng.get_theta().tobytes(), out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_nses_two_ranks_gloo_bit_identical():
+    """Config 4's exchange: novelty travels in the records' aux slot (nses.py:384), the rank blend (nses.py:217-228) and the
+    update run redundantly -- same theta on both ranks, equal to a one-rank run of the same two generations (NS then NSR)."""
+    import torch.multiprocessing as mp
+    from dne_hip import es, nses
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nses_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=500) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out[0][1:] == out[1][1:]
+    eng = _nses_engine()
+    cfg = _nses_config()
+    for g, algo in enumerate(("ns", "nsr")):          # serial emulation of both shards
+        full = np.zeros(N_PAIRS, es.RECORD)
+        for r in range(2):
+            mine, idx, seeds = es.generation_inputs(NOISE, eng.P, N_PAIRS, g, r, 2)
+            ret, _, ln = eng.es_eval(idx, cfg.noise_stdev, TSLIMIT, seeds)
+            nov = eng.novelty_batch(_archive(), ln, 2).astype(np.float32).reshape(-1, 2)
+            full[mine] = es.pack_records(idx, ret, ln, nov)
+        assert full.tobytes() == out[0][2][g]
+        nses.blend_and_update(eng, full, algo, cfg.return_proc_mode, cfg.l2coeff, OPT)
+    assert eng.get_theta().tobytes() == out[0][1]
+    rec = np.frombuffer(out[0][2][1], es.RECORD)
+    assert (rec["aux"] > 0).all()                      # novelty, not sign-returns
