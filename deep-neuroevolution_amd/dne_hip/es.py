@@ -15,6 +15,7 @@ import numpy as np
 
 from . import _lib
 from .dist import MasterClient, WorkerClient
+from .policies import snapshot_extension
 
 logger = logging.getLogger(__name__)
 
@@ -289,7 +290,7 @@ def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_i
             ("TimeElapsed", time.time() - tstart)])
         if config.snapshot_freq != 0 and task_id % config.snapshot_freq == 0:    # es.py:345-353
             import os.path as osp
-            fn = osp.join(log_dir, 'snapshot_iter{:05d}_rew{}.npz'.format(task_id, int(np.mean(ev)) if ev else np.nan))
+            fn = osp.join(log_dir, ('snapshot_iter{:05d}_rew{}' + snapshot_extension()).format(task_id, int(np.mean(ev)) if ev else np.nan))
             policy.save(fn)
             tlogger.log('Saved snapshot {}'.format(fn))
     return policy

@@ -24,6 +24,7 @@ from . import _lib
 from . import es as _es
 from .compat import Config, ModifiedResult as Result, Task   # noqa: F401
 from .dist import WorkerClient
+from .policies import snapshot_extension
 from .es import SharedNoiseTable, TaskPacer, shard_pairs   # noqa: F401
 
 logger = logging.getLogger(__name__)
@@ -42,7 +43,7 @@ def master_extract_parent(eval_bc_vecs, eval_rets, iteration, policy, ref_batch,
         import h5py  # noqa: F401
         policy.save(os.path.join(path, "snapshot_parent_{:04d}.h5".format(iteration)))
     except ImportError:
-        policy.save(os.path.join(path, "snapshot_parent_{:04d}.npz".format(iteration)))
+        policy.save(os.path.join(path, ("snapshot_parent_{:04d}" + snapshot_extension()).format(iteration)))
     with open(os.path.join(path, "snapshot_parent_{:04d}_rb.p".format(iteration)), "wb") as f:
         pickle.dump(ref_batch, f)
     if not eval_rets:

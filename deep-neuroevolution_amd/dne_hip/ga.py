@@ -14,6 +14,7 @@ import numpy as np
 
 from . import _lib
 from .dist import MasterClient, WorkerClient
+from .policies import snapshot_extension
 from .es import Config, Result, SharedNoiseTable, TaskPacer, collect_batch, log_generation, namedtuple, parse_cutoff  # noqa: F401
 
 logger = logging.getLogger(__name__)
@@ -92,7 +93,7 @@ def run_master(master_redis_cfg, log_dir, exp, *, engine=None, noise=None, max_i
             ("TimeElapsed", time.time() - tstart)])
         if config.snapshot_freq != 0:
             import os.path as osp
-            policy.save(osp.join(log_dir, 'snapshot_iter{:05d}_rew{}.npz'.format(
+            policy.save(osp.join(log_dir, ('snapshot_iter{:05d}_rew{}' + snapshot_extension()).format(
                 curr_task_id, np.nan if not eval_rets else int(np.mean(eval_rets)))))
     return policy, population, population_score
 

@@ -189,23 +189,30 @@ class Policy:
         return {}
 
     def save(self, filename):
-        """policies.py:49-57.  '.h5': the reference's HDF5 layout -- a dataset per TF variable name, attrs 'name' and
-        'args_and_kwargs' -- written through h5py when it is installed (it is not in this image); any other name (the
-        drivers use '.npz'): the same arrays, names and attributes in a numpy container, which tools/npz_to_h5.py
-        turns into the .h5 on a machine that has h5py."""
+        """policies.py:49-57.  '.h5': the reference's HDF5 layout -- a float32 dataset per TF variable name, root attributes
+        'name' and 'args_and_kwargs' -- written through h5py when it is installed, else through libhdf5 directly
+        (h5lite.py; this image has the C library but not h5py).  Any other name: the same arrays, names and attributes in
+        a numpy container, which tools/npz_to_h5.py turns into the .h5 (snapshot_extension() picks what the drivers use)."""
         arrays = self.variable_arrays()
-        blob = pickle.dumps((((tuple(self.ob_space_shape), self.num_actions)), self.kwargs), protocol=-1)
+        blob = _dumps_spaces(tuple(self.ob_space_shape), self.num_actions, self.kwargs) if filename.endswith('.h5') else \
+            pickle.dumps((((tuple(self.ob_space_shape), self.num_actions)), self.kwargs), protocol=-1)
         if filename.endswith('.h5'):
             try:
                 import h5py
             except ImportError:
-                raise RuntimeError("writing '.h5' snapshots needs h5py (absent here): save to '.npz' and run "
-                                   "tools/npz_to_h5.py where h5py exists") from None
-            with h5py.File(filename, 'w', libver='latest') as f:
-                for k, v in arrays.items():
-                    f[k] = v
-                f.attrs['name'] = type(self).__name__
-                f.attrs['args_and_kwargs'] = np.void(blob)
+                h5py = None
+            if h5py is not None:
+                with h5py.File(filename, 'w', libver='latest') as f:
+                    for k, v in arrays.items():
+                        f[k] = v
+                    f.attrs['name'] = type(self).__name__
+                    f.attrs['args_and_kwargs'] = np.void(blob)
+                return
+            from . import h5lite
+            if not h5lite.available():
+                raise RuntimeError("writing '.h5' snapshots needs h5py or libhdf5 (neither found; DNE_HDF5_LIB names the "
+                                   "library): save to '.npz' and run tools/npz_to_h5.py where h5py exists")
+            h5lite.write_snapshot(filename, arrays, type(self).__name__, blob)
             return
         np.savez(filename, __name__=type(self).__name__, __args_and_kwargs__=np.void(blob),
                  __variables__=np.array(list(arrays.keys())), **{'var%03d' % i: v for i, v in enumerate(arrays.values())})
@@ -214,14 +221,24 @@ class Policy:
     def _read_snapshot(filename):
         """-> (class name, (ob_shape, nact), kwargs, {variable name: array})"""
         if filename.endswith('.h5'):
-            import h5py
-            with h5py.File(filename, 'r') as f:
-                args, kwargs = pickle.loads(f.attrs['args_and_kwargs'].tobytes())
-                arrays = {}
-                f.visititems(lambda n, o: arrays.__setitem__(n, o[...]) if isinstance(o, h5py.Dataset) else None)
-                name = f.attrs['name']
+            try:
+                import h5py
+            except ImportError:
+                h5py = None
+            if h5py is not None:
+                with h5py.File(filename, 'r') as f:
+                    blob = f.attrs['args_and_kwargs'].tobytes()
+                    arrays = {}
+                    f.visititems(lambda n, o: arrays.__setitem__(n, o[...]) if isinstance(o, h5py.Dataset) else None)
+                    name = f.attrs['name']
+            else:
+                from . import h5lite
+                name, blob, arrays = h5lite.read_snapshot(filename)
+            args, kwargs = _loads_spaces(blob)
             ob, ac = args[0], args[1]     # the reference pickles gym spaces; ours are (shape, n)
-            return name, (tuple(getattr(ob, 'shape', ob)), int(getattr(ac, 'n', ac))), kwargs, arrays
+            ob_shape = getattr(ob, 'shape', None) or (ob.low.shape if hasattr(ob, 'low') else ob)
+            nact = getattr(ac, 'n', None) or (ac.low.shape[0] if hasattr(ac, 'low') else ac)
+            return name, (tuple(ob_shape), int(nact)), kwargs, arrays
         with np.load(filename, allow_pickle=False) as f:
             (ob_shape, nact), kwargs = pickle.loads(f['__args_and_kwargs__'].tobytes())
             names = [str(n) for n in f['__variables__']]
@@ -322,3 +339,69 @@ class GAAtariPolicy(Policy):
         """ga.py:256-264 / 151-158: theta = normc(noise[s0]) + noise_stdev * sum noise[s_k], built on device."""
         self._flat = self.engine.ga_rebuild(0, np.asarray(seeds, np.int64), noise_stdev)
         return self._flat
+
+
+def _dumps_spaces(ob_shape, nact, kwargs):
+    """policies.py:56: `pickle.dumps((self.args, self.kwargs))` where args are the gym spaces the policy was built with.  A stock
+    checkout's Policy.Load does `cls(*args, **kwargs)` and reads ob_space.shape / ac_space.n (policies.py:306-309, 434-438), so
+    the pickle must name gym's classes.  Stand-ins registered under gym's module paths for the duration of the dump give the
+    pickle gym 0.9.4 (requirements.txt:3) produces -- Box state {low, high}, Discrete state {n} -- whether or not gym is here.
+    The two bound arrays are written as `numpy.zeros(shape)` / `numpy.ones(shape)` calls rather than as 2 x 226 KB of buffer:
+    smaller, and free of the numpy-version-specific module path (`numpy._core` vs `numpy.core`) of a pickled ndarray."""
+    import io
+    import sys
+    import types
+    saved, names = {}, ('gym', 'gym.spaces', 'gym.spaces.box', 'gym.spaces.discrete')
+    try:
+        for m in names:
+            saved[m] = sys.modules.get(m)
+            sys.modules[m] = types.ModuleType(m)
+        Box = type('Box', (), {'__module__': 'gym.spaces.box'})
+        Discrete = type('Discrete', (), {'__module__': 'gym.spaces.discrete'})
+        sys.modules['gym.spaces.box'].Box, sys.modules['gym.spaces.discrete'].Discrete = Box, Discrete
+        ob, ac = Box(), Discrete()
+        ob.low, ob.high = np.zeros(ob_shape), np.ones(ob_shape)      # float64, as box.py builds them from scalar bounds
+        ac.n = int(nact)
+
+        class _Pickler(pickle.Pickler):
+            def reducer_override(self, obj):
+                if obj is ob.low:
+                    return np.zeros, (tuple(ob_shape),)
+                if obj is ob.high:
+                    return np.ones, (tuple(ob_shape),)
+                return NotImplemented
+        out = io.BytesIO()
+        _Pickler(out, protocol=2).dump(((ob, ac), kwargs))
+        return out.getvalue()
+    finally:
+        for m in names:
+            if saved[m] is None:
+                sys.modules.pop(m, None)
+            else:
+                sys.modules[m] = saved[m]
+
+
+def _loads_spaces(blob):
+    """pickle.loads for a snapshot's 'args_and_kwargs' (policies.py:56: the policy's gym spaces + kwargs): where gym is not
+    installed its space classes are stood in for by attribute bags, which is all Load needs (shape / n)."""
+    import io
+
+    class _Unpickler(pickle.Unpickler):
+        def find_class(self, mod, name):
+            try:
+                return super().find_class(mod, name)
+            except (ImportError, AttributeError):
+                if mod.split('.')[0] != 'gym':
+                    raise
+                return type(name, (), {'__module__': mod})
+    return _Unpickler(io.BytesIO(blob)).load()
+
+
+def snapshot_extension():
+    """'.h5' (es.py:288-291's snapshot_iter*.h5) when this machine can write HDF5 -- h5py, or libhdf5 through h5lite -- else '.npz'"""
+    try:
+        import h5py  # noqa: F401
+        return '.h5'
+    except ImportError:
+        from . import h5lite
+        return '.h5' if h5lite.available() else '.npz'

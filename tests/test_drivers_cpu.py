@@ -93,7 +93,7 @@ def test_es_modified_vine_dumps(oracle, tmp_path):
     theta0 = policies.xavier_flat(18, 0)
     for gen in range(2):
         d = os.path.join(root, "snapshot_gen_%04d" % gen)
-        assert os.path.exists(os.path.join(d, "snapshot_parent_%04d.npz" % gen))
+        assert os.path.exists(os.path.join(d, "snapshot_parent_%04d" % gen + policies.snapshot_extension()))
         ref = np.asarray(pickle.load(open(os.path.join(d, "snapshot_parent_%04d_rb.p" % gen), "rb")))
         assert ref.shape == (16, 84, 84, 4)
         cloud = np.loadtxt(os.path.join(d, "snapshot_offspring_%04d.dat" % gen))

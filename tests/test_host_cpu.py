@@ -171,8 +171,19 @@ def test_policy_surface(oracle, small_noise, tmp_path):
     assert (arrays["ESAtariPolicy/BatchNorm_2/moving_variance:0"] >= 0).all()
     with np.load(fn) as f:
         assert sorted(str(n) for n in f["__variables__"]) == sorted(want) and str(f["__name__"]) == "ESAtariPolicy"
-    with pytest.raises(RuntimeError):
-        pol.save(str(tmp_path / "snap.h5"))        # no h5py in this image: the error names the converter
+    from dne_hip import h5lite
+    if policies.snapshot_extension() == ".h5":     # h5py or libhdf5 present: the reference's own container (policies.py:49-57)
+        h5 = str(tmp_path / "snap.h5")
+        pol.save(h5)
+        pol3 = policies.ESAtariPolicy.Load(h5, engine=OracleEngine(0, ref_count=16))
+        assert np.array_equal(pol3.get_trainable_flat(), pol.get_trainable_flat())
+        name, (ob_shape, nact), _, got = policies.Policy._read_snapshot(h5)
+        assert name == "ESAtariPolicy" and tuple(ob_shape) == (84, 84, 4) and nact == 18 and sorted(got) == sorted(want)
+        assert all(np.array_equal(got[k], arrays[k]) and got[k].dtype == np.float32 for k in want)
+    else:
+        assert not h5lite.available()
+        with pytest.raises(RuntimeError):
+            pol.save(str(tmp_path / "snap.h5"))    # neither h5py nor libhdf5: the error names the converter
     # initialize_from (policies.py:345-372): a 14-action snapshot seeds the leading columns of an 18-action policy
     small = policies.ESAtariPolicy(env.observation_space, policies._Space(n=14))
     small.initialize(1)
