@@ -312,6 +312,10 @@ struct dne_handle {
     int fc_pairs = 2;                // ES full-width fc: antithetic pairs per work item (DNE_FC_PAIRS, 1 = k_fc<2>)
     int fc2_min_total = 800;         // k_fc2 from this many active groups upwards (DNE_FC2_MIN)
     bool fc2_now = false;            // decided per burst by eval_core
+    int duo_lag = 0;                 // DNE_DUO_LAG: extra row batches by which the second unit of a duo trails the first
+    int fc_duo = 1, fc_duo_min = 800;   // DNE_FC_DUO / DNE_FC_DUO_MIN: table-ordered fc (k_unit_order + k_fc_duo + k_out) from this many active groups
+    bool duo_now = false;            // decided per burst by eval_core (the unit order of each window is rebuilt then)
+    int *unit_order = nullptr;       // [4 * groups]: per window, its (group, k-slice) units in noise-table order
     bool uniform_base = false;       // every member perturbs base slot 0 (set by dne_es_eval, cleared by dne_set_members)
     int render_bands = 4, band_threads = 512;   // tail: workgroups per frame (DNE_RENDER_BANDS, 1 = render inside k_tail_step) and their size
     int tail_fused_max = 200;        // up to this many active groups (all windows) k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
@@ -615,6 +619,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_CONV_FUSED_MIN", 1, 1 << 20, &h->conv_fused_min);
     CH(hipFuncSetAttribute((const void *)k_conv12<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
     CH(hipFuncSetAttribute((const void *)k_conv12<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
+    CH(hipFuncSetAttribute((const void *)k_unit_order, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
     env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
     env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
@@ -626,6 +631,9 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_CONV1_FPW", 1, 8, &h->conv1_fpw);
     env_int("DNE_CONV_SPLIT_MAX", 0, 1 << 20, &h->conv_split_max);
     env_int("DNE_FC2_MIN", 2, 1 << 30, &h->fc2_min_total);
+    env_int("DNE_FC_DUO", 0, 1, &h->fc_duo);
+    env_int("DNE_DUO_LAG", 0, 64, &h->duo_lag);
+    env_int("DNE_FC_DUO_MIN", 2, 1 << 30, &h->fc_duo_min);
     env_int("DNE_RENDER_BANDS", 1, 12, &h->render_bands);
     env_int("DNE_FC_CHAIN_MIN", 1, 1 << 30, &h->fc_chain_min);
     env_int("DNE_FC_RB", 2, 8, &h->fc_rb);
@@ -666,6 +674,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(h->alloc(&h->len, M, "len")); CH(h->alloc(&h->done, M, "done")); CH(h->alloc(&h->action, M, "action")); CH(h->alloc(&h->seeds, M, "seeds")); CH(h->alloc(&h->stepped, M, "stepped"));
     CH(hipMemset(h->done, 0, M * sizeof(int32_t))); CH(hipMemset(h->len, 0, M * sizeof(int32_t)));
     CH(h->alloc(&h->y1, M * 7056, "y1")); CH(h->alloc(&h->y2, M * 3872, "y2")); CH(h->alloc(&h->y3, M * 256, "y3")); CH(h->alloc(&h->y3t, M * 4 * 256, "y3t"));
+    CH(h->alloc(&h->unit_order, M * 4, "unit_order"));
     if (h->F) {
         const size_t rr = (size_t)h->ref_chunk * h->F;
         for (int w = 0; w < 2; w++) {
@@ -1111,7 +1120,9 @@ static void launch_forward(dne_handle *h, const int *list, int count, int gsize,
 }
 
 static void launch_fc(dne_handle *h, const int *list, int count, int gsize, float *logits, hipStream_t st = nullptr,
-                      bool out_fused = false /* tail only: the caller runs k_tail_step instead of k_out */) {
+                      bool out_fused = false /* tail only: the caller runs k_tail_step instead of k_out */,
+                      const int *order = nullptr /* the window's units in noise-table order (k_unit_order), duo regime only */,
+                      hipEvent_t after_stream_kernel = nullptr /* duo regime: recorded between k_fc_duo and k_out (profiling) */) {
     if (!st) st = h->stream;
     // inside an evaluation (no logits requested) groups whose members are all done are skipped: they stay in the list until
     // the next compaction, and streaming their weights would be wasted bandwidth
@@ -1127,6 +1138,13 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         if (gsize == 2) { if (es) FCT(2, true); else FCT(2, false); }
         else { if (es) FCT(1, true); else FCT(1, false); }
 #undef FCT
+        return;
+    }
+    if (gsize == 2 && es && h->duo_now && !logits && order) {   // table-ordered units: adjacent (pair, k-slice) units share their noise rows
+        const int n_units = 4 * count, items = ((n_units + 1) / 2 + 3) / 4, blocks = std::min(items, h->fc_grid);
+        hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag);
+        if (after_stream_kernel) hipEventRecord(after_stream_kernel, st);
+        hipLaunchKernelGGL((k_out<2, true>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
         return;
     }
     if (gsize == 2 && es && h->uniform_base && h->fc2_now && !logits) {   // two pairs per work item share the base rows
@@ -1233,10 +1251,20 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     size_t fc_ring_pos = 0;
     // the profiled ("full") launches are one kernel: k_fc2 when this evaluation starts wide enough to use it, else k_fc
     const bool fc2_eval = h->fc_pairs == 2 && gsize == 2 && h->L.kind == DNE_KIND_ES && h->uniform_base && groups >= h->fc2_min_total;
+    const bool duo_eval = h->fc_duo && gsize == 2 && h->L.kind == DNE_KIND_ES && groups >= h->fc_duo_min;
     while (total > 0 && t < tslimit) {
         const int burst = std::min(16, tslimit - t);
         const int nsub = pick_nsub(total);
         h->fc2_now = h->fc_pairs == 2 && total >= h->fc2_min_total;
+        h->duo_now = h->fc_duo && gsize == 2 && h->L.kind == DNE_KIND_ES && total >= h->fc_duo_min &&
+                     (size_t)4 * ((total + nsub - 1) / nsub) * sizeof(long long) <= 160 * 1024;   // k_unit_order ranks a window's keys in LDS
+        if (h->duo_now)   // the list only changes at a compaction: rank each window's units by table address once per burst
+            for (int s = 0; s < nsub; s++) {
+                const int lo = (int)((long long)total * s / nsub), cnt = (int)((long long)total * (s + 1) / nsub) - lo;
+                if (cnt <= h->fc_tail_max) continue;
+                hipLaunchKernelGGL(k_unit_order, dim3((4 * cnt + 255) / 256), dim3(256), (size_t)4 * cnt * sizeof(long long), h->sub_streams[s],
+                                   (const int64_t *)h->m_off, (const int *)(cur + lo), cnt, gsize, h->unit_order + 4 * lo);
+            }
         for (int st = 0; st < burst; st++) {
             for (int s = 0; s < nsub; s++) {
                 const int lo = (int)((long long)total * s / nsub), cnt = (int)((long long)total * (s + 1) / nsub) - lo;
@@ -1246,7 +1274,8 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 std::array<size_t, 4> e{};
                 // events only around full-width launches: in the latency-bound tail every event packet is a bubble
                 // (with k_fc2 enabled the profiled launches are exactly the k_fc2 ones: the roofline kernel of bench.py)
-                const bool pe = prof && (fc2_eval ? h->fc2_now : cnt > h->fc_tail_max);
+                const bool duo_win = h->duo_now && cnt > h->fc_tail_max;
+                const bool pe = prof && (duo_eval ? duo_win : fc2_eval ? h->fc2_now : cnt > h->fc_tail_max);
                 if (pe) { e[0] = ne++; HCHECK(h, hipEventRecord(h->event(e[0]), sst)); }
                 launch_forward(h, lst, cnt, gsize, true, sst);
                 // optional: serialise the fc kernels of the windows (anti-phase); off by default, free-running measured faster
@@ -1255,9 +1284,11 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 if (pe) { e[1] = ne++; HCHECK(h, hipEventRecord(h->event(e[1]), sst)); }   // after the wait: brackets fc only
                 // fused policy head + emulator (+ render): while all windows together still fit the chip one workgroup per member
                 const bool tail = cnt <= h->fc_tail_max && total <= h->tail_fused_max;
-                launch_fc(h, lst, cnt, gsize, nullptr, sst, tail);
+                if (pe) e[2] = ne++;
+                launch_fc(h, lst, cnt, gsize, nullptr, sst, tail, h->duo_now ? h->unit_order + 4 * lo : nullptr,
+                          pe && duo_win ? h->event(e[2]) : nullptr);   // duo: the bracket ends behind k_fc_duo, before k_out
                 if (chain) { last_fc = h->fc_ring[fc_ring_pos++ % h->fc_ring.size()]; HCHECK(h, hipEventRecord(last_fc, sst)); }
-                if (pe) { e[2] = ne++; HCHECK(h, hipEventRecord(h->event(e[2]), sst)); }
+                if (pe && !duo_win) HCHECK(h, hipEventRecord(h->event(e[2]), sst));
                 E.step_counter = pe ? h->launch_units + evs.size() : nullptr;
                 if (tail) {
                     const FwdArgs A = h->fwd(false);
@@ -1307,7 +1338,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     P.env_steps = 0;
     for (int i = 0; i < n; i++) P.env_steps += lengths[i];
     P.fc_full_ms = P.fc_full_launches = P.fc_full_units = 0;
-    P.fc_full_kind = fc2_eval ? 2 : 1;
+    P.fc_full_kind = duo_eval ? 3 : fc2_eval ? 2 : 1;
     P.fc_full_union_ms = 0;
     if (prof) {
         HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[0], h->ev_pool[1]));

@@ -1045,6 +1045,267 @@ __global__ __launch_bounds__(256) void k_fc2(FwdArgs A, const int *__restrict__ 
     }
 }
 
+// ------------------------------------------------------- table-ordered fc: units that overlap in the noise table share its rows
+// The noise slices of a population overlap: 2500 slices of 1 M floats drawn from a 250 M table cover every table row about
+// ten times, and within the fc matrix a (pair, k-slice) unit of 968 rows starts on average 97 rows after the previous one in
+// table order.  k_unit_order ranks the units of a window by their table address; k_fc_duo gives each wave the two units of an
+// adjacent pair in that order and runs them in table lock-step: unit B starts `gb` row batches after unit A, so that both read
+// (nearly) the same table rows in the same load batch -- the second reader finds the lines in L1 / L2 and HBM delivers them once.
+// Which units travel together is a schedule, not arithmetic: every unit still walks its own 968 rows in k order from a zero
+// accumulator and the partial sums go to y3t[member][slice][256], where k_out combines them ((s0+s1)+(s2+s3)) + bias like
+// every other fc variant -- same bits.  Units of finished groups are dropped; an unpartnered unit runs alone.
+constexpr int SLICE_FLOATS = 968 * 256;
+
+__global__ __launch_bounds__(256) void k_unit_order(const int64_t *__restrict__ m_off, const int *__restrict__ list, int cnt, int gsize,
+                                                    int *__restrict__ order /*[4 * cnt]: unit = 4 * group + slice*/) {
+    extern __shared__ long long uo_keys[];
+    const int n = 4 * cnt;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int g = list ? list[i >> 2] : i >> 2;
+        uo_keys[i] = m_off[(size_t)g * gsize] + (long long)(i & 3) * SLICE_FLOATS;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long k = uo_keys[i];
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+        const long long kj = uo_keys[j];
+        rank += (kj < k || (kj == k && j < i)) ? 1 : 0;
+    }
+    const int g = list ? list[i >> 2] : i >> 2;
+    order[rank] = g * 4 + (i & 3);
+}
+
+// One side (unit) of a duo: its streams, its activations, its accumulators.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int NV>
+struct DuoSide {
+    const float *enext, *tnext;   // wave-uniform: the unit's next row block in the noise table / in the base vector
+    const float *xs[NV];
+    float scale[NV], s2[NV], h2[NV];
+    f32x2 acc[NV][2];             // this lane's 4 columns as two register pairs (v_pk_fma_f32)
+    float xv[NV], xn[NV];         // relu(bn2(y2)) of the current / next 64-row chunk, one row per lane
+    int lb;                       // index of the row block computed next (wave-uniform)
+    int sl, mem[NV];              // k-slice and members of the unit
+    long long key;                // table address of the unit's first row
+};
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni64(long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffll));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+// 16 bytes per lane from (uniform base + per-lane byte offset + OFF); the result lands asynchronously: read it only through
+// wait_rows.  Written as asm so that the load is issued exactly here, into the registers of the row just consumed -- the
+// compiler's own schedule hoists the loads of a row block to its top, which costs a second register set and a copy per row.
+template <int OFF>
+__device__ __forceinline__ void gload4(f32x4 &dst, unsigned voff, const float *sbase) {
+    // "+v": the registers of the row just consumed are the destination (its readers come first; nothing is kept alive or copied)
+    asm volatile("global_load_dwordx4 %[d], %[vo], %[sb] offset:%[of]" : [d] "+v"(dst) : [vo] "v"(voff), [sb] "s"(sbase), [of] "n"(OFF));
+}
+// the same load, pinned behind the accumulator updates of the row it replaces: without the (untouched) accumulators as
+// operands the compiler sinks a whole block's arithmetic below all of its loads and keeps the old rows alive in copies
+template <int OFF>
+__device__ __forceinline__ void gload4_after(f32x4 &dst, unsigned voff, const float *sbase, f32x2 &a0, f32x2 &a1, f32x2 &a2, f32x2 &a3) {
+    asm volatile("global_load_dwordx4 %[d], %[vo], %[sb] offset:%[of]"
+                 : [d] "+v"(dst), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : [vo] "v"(voff), [sb] "s"(sbase), [of] "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void wait_rows(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d) {   // at most N loads still in flight afterwards
+    asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : [n] "n"(N));
+}
+
+template <int NV, bool HAS_BN>
+__global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict__ order, int n_units,
+                                                const float *__restrict__ y2, float *__restrict__ y3t, int lag) {
+    constexpr int W = 8;                          // rows in flight per stream
+    constexpr int NBLK = 968 / W, BPC = 64 / W;   // row blocks per unit, per 64-row activation chunk
+    const int tid = threadIdx.x, wv = uni(tid >> 6), lane = tid & 63;
+    const unsigned voff = lane * 16;
+    const Layout &L = A.L;
+    __builtin_amdgcn_s_setprio(3);
+    const int n_duos = (n_units + 1) >> 1, n_items = (n_duos + 3) >> 2;
+    typedef DuoSide<NV> Side;
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const int d = item * 4 + wv;
+        if (d >= n_duos) continue;
+        int uA = uni(order[2 * d]), uB = 2 * d + 1 < n_units ? uni(order[2 * d + 1]) : -1;
+        if (A.done) {
+            auto finished = [&](int uu) {
+                int all_done = 1;
+#pragma unroll
+                for (int v = 0; v < NV; v++) all_done &= uni(A.done[(uu >> 2) * NV + v]) != 0;
+                return all_done != 0;
+            };
+            if (finished(uA)) uA = -1;
+            if (uB >= 0 && finished(uB)) uB = -1;
+        }
+        if (uA < 0) { uA = uB; uB = -1; }
+        if (uA < 0) continue;
+        const bool b_on = uB >= 0;
+        if (!b_on) uB = uA;   // valid addresses for the side that is never computed or stored
+
+        Side SA, SB;
+        auto init = [&](Side &Z, int uu) {
+            const int g = uu >> 2;
+            Z.sl = uu & 3;
+            const long long off = uni64(A.m_off[(size_t)g * NV]);
+            const int slot = uni(A.m_slot[g * NV]);
+            Z.key = off + (long long)Z.sl * SLICE_FLOATS;
+            Z.enext = A.noise + off + L.fcw + (size_t)Z.sl * SLICE_FLOATS;
+            Z.tnext = A.bases + (size_t)slot * A.base_stride + L.fcw + (size_t)Z.sl * SLICE_FLOATS;
+            const int ch = (8 * Z.sl + lane) & 31;   // bn2 channel of this lane's activation rows (968 = 8 mod 32)
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                Z.mem[v] = g * NV + v;
+                Z.scale[v] = A.m_scale[Z.mem[v]];
+                Z.s2[v] = HAS_BN ? A.bn[(size_t)Z.mem[v] * 608 + 32 + ch] : 1.0f;
+                Z.h2[v] = HAS_BN ? A.bn[(size_t)Z.mem[v] * 608 + 64 + ch] : 0.0f;
+                Z.xs[v] = y2 + (size_t)Z.mem[v] * 3872 + 968 * Z.sl;
+                Z.acc[v][0] = Z.acc[v][1] = f32x2{0.0f, 0.0f};
+                Z.xv[v] = Z.xn[v] = 0.0f;
+            }
+            Z.lb = 0;
+        };
+        init(SA, uA);
+        init(SB, uB);
+        // B trails A by gb row blocks: its row (blk - gb) * W + i then sits within W rows of A's row blk * W + i in the table
+        int gb = NBLK;
+        if (b_on) {
+            const long long delta = SB.key - SA.key;
+            gb = delta < 0 ? 0 : (int)min((long long)NBLK, delta / (256 * W) + lag);
+        }
+
+        // activations: chunk c = rows 64c .. 64c+63 of the unit's slice, one row per lane.  The raw values of chunk c + 1 are
+        // requested (asm, like the weight rows) when chunk c starts and turned into relu(bn2(.)) eight row blocks later, long
+        // after every load issued before the row loads of those blocks has landed (loads complete in order).
+        auto request_x = [&](Side &Z, int c) {
+            if (c >= 16) return;
+            const unsigned xoff = (c < 15 ? lane : min(lane, 7)) * 4;
+#pragma unroll
+            for (int v = 0; v < NV; v++)   // xv as an operand: behind take_x's arithmetic, when the old raw values are dead (no copy of a register in flight)
+                asm volatile("global_load_dword %[d], %[vo], %[sb]" : [d] "=v"(Z.xn[v]), "+v"(Z.xv[v]) : [vo] "v"(xoff), [sb] "s"(Z.xs[v] + 64 * c));
+        };
+        auto take_x = [&](Side &Z, int c) {   // xv = chunk c from the raw values in xn
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                asm volatile("" : "+v"(Z.xn[v]));   // not before this point of the asm sequence (the value lands asynchronously)
+                float t = Z.xn[v];
+                if (HAS_BN) {
+                    t = t * Z.s2[v];
+                    t = t + Z.h2[v];
+                }
+                t = t > 0.0f ? t : 0.0f;
+                Z.xv[v] = (c < 15 || lane < 8) ? t : 0.0f;
+            }
+        };
+        // A rolling window of W rows per stream: row i of a block is consumed and its registers are refilled at once with row i
+        // of the next block, so W rows per stream stay in flight and no register is ever copied.  The block after a unit's
+        // last one is fetched too and never used: it lies inside the member's own parameter slice (fc bias, bn3 and the
+        // output layer follow the fc matrix).
+        f32x4 eA[W], tA[W], eB[W], tB[W];
+#pragma unroll
+        for (int i = 0; i < W; i++) eA[i] = tA[i] = eB[i] = tB[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto refill = [&](Side &Z, f32x4 &e, f32x4 &t, auto ii) {   // row I of the side's next block
+            constexpr int I = decltype(ii)::value;
+            static_assert(NV == 2, "accumulator operands");
+            gload4_after<(I % 4) * 1024>(e, voff, Z.enext + (I / 4) * 1024, Z.acc[0][0], Z.acc[0][1], Z.acc[1][0], Z.acc[1][1]);
+            gload4<(I % 4) * 1024>(t, voff, Z.tnext + (I / 4) * 1024);
+        };
+        auto next_block = [&](Side &Z) {
+            Z.enext += W * 256;
+            Z.tnext += W * 256;
+        };
+        auto row = [&](Side &Z, const f32x4 &e, const f32x4 &t, int li, const float (&scale)[NV]) {
+            const f32x2 elo = {e[0], e[1]}, ehi = {e[2], e[3]}, tlo = {t[0], t[1]}, thi = {t[2], t[3]};
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                const float x = lane_bcast(Z.xv[v], li);
+                const f32x2 xx = {x, x}, sc = {scale[v], scale[v]};
+                f32x2 pl = sc * elo, ph = sc * ehi;       // base + scale * noise, two roundings, then one fused multiply-add
+                f32x2 wl = tlo + pl, wh = thi + ph;
+                Z.acc[v][0] = __builtin_elementwise_fma(xx, wl, Z.acc[v][0]);
+                Z.acc[v][1] = __builtin_elementwise_fma(xx, wh, Z.acc[v][1]);
+            }
+        };
+        auto end_block = [&](Side &Z) {
+            next_block(Z);
+            if (Z.lb % BPC == BPC - 1 && Z.lb + 1 < NBLK) {
+                take_x(Z, Z.lb / BPC + 1);
+                request_x(Z, Z.lb / BPC + 2);
+            }
+            Z.lb++;
+        };
+        auto fill = [&](auto sa, auto sb) {   // the first block of the selected sides; everything in flight has landed afterwards
+            constexpr bool DA = decltype(sa)::value, DB = decltype(sb)::value;
+            auto one = [&](auto ii) {
+                constexpr int I = decltype(ii)::value;
+                if (DA) refill(SA, eA[I], tA[I], ii);
+                if (DB) refill(SB, eB[I], tB[I], ii);
+            };
+            one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
+            one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+            one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+            if (DA) next_block(SA);
+            if (DB) next_block(SB);
+#pragma unroll
+            for (int i = 0; i < W; i++) wait_rows<0>(eA[i], tA[i], eB[i], tB[i]);
+        };
+        auto run = [&](auto da, auto db, int n) {   // n row blocks of the selected sides
+            constexpr bool DA = decltype(da)::value, DB = decltype(db)::value;
+            // before row i is read, the loads issued after its own are the (W - 1) other rows of every active stream
+            constexpr int PENDING = (W - 1) * 2 * ((DA ? 1 : 0) + (DB ? 1 : 0));
+            float scA[NV], scB[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) { scA[v] = SA.scale[v]; scB[v] = SB.scale[v]; }
+            for (int k = 0; k < n; k++) {
+                const int liA = (SA.lb % BPC) * W, liB = (SB.lb % BPC) * W;
+                auto one = [&](auto ii) {
+                    constexpr int I = decltype(ii)::value;
+                    wait_rows<PENDING>(eA[I], tA[I], eB[I], tB[I]);
+                    if (DA) row(SA, eA[I], tA[I], liA + I, scA);
+                    if (DB) row(SB, eB[I], tB[I], liB + I, scB);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (DA) refill(SA, eA[I], tA[I], ii);
+                    if (DB) refill(SB, eB[I], tB[I], ii);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
+                one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+                one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+                if (DA) end_block(SA);
+                if (DB) end_block(SB);
+            }
+        };
+        request_x(SA, 0);
+        fill(std::true_type{}, std::false_type{});
+        take_x(SA, 0);
+        request_x(SA, 1);
+        run(std::true_type{}, std::false_type{}, gb);                 // A alone until B's rows come into reach
+        if (b_on) {
+            request_x(SB, 0);
+            fill(std::false_type{}, std::true_type{});
+            take_x(SB, 0);
+            request_x(SB, 1);
+            run(std::true_type{}, std::true_type{}, NBLK - gb);       // table lock-step
+            run(std::false_type{}, std::true_type{}, gb);             // B finishes alone
+        }
+#pragma unroll
+        for (int i = 0; i < W; i++) wait_rows<0>(eA[i], tA[i], eB[i], tB[i]);   // the over-fetched block: nothing in flight into dead registers
+        auto store = [&](Side &Z) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                f4a o = {Z.acc[v][0][0], Z.acc[v][0][1], Z.acc[v][1][0], Z.acc[v][1][1]};
+                *(f4a *)(y3t + ((size_t)Z.mem[v] * 4 + Z.sl) * 256 + lane * 4) = o;
+            }
+        };
+        store(SA);
+        if (b_on) store(SB);
+    }
+}
+
 // ------------------------------------------------------- fc of the reference pass on the matrix cores
 // Virtual batch norm pushes F reference frames through every member's perturbed network (policies.py:399):
 // per member a [F x 3872] x [3872 x 256] GEMM with member-unique weights.  16 workgroups per member = 4 k-slices
@@ -1467,6 +1728,12 @@ __global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ 
     const Layout &L = A.L;
     const int g = list ? list[blockIdx.x] : blockIdx.x;
     const int nact = L.nact;
+    if (A.done) {   // finished group still in the list: its partial sums were not refreshed and nobody reads its action
+        bool all_done = true;
+#pragma unroll
+        for (int v = 0; v < NV; v++) all_done = all_done && A.done[g * NV + v] != 0;
+        if (all_done) return;
+    }
 #pragma unroll
     for (int v = 0; v < NV; v++) {
         const int m = g * NV + v;

@@ -96,6 +96,10 @@ def generation_inputs(noise_len, num_params, n_pairs, generation, rank, world):
     # one vectorised draw = the same values, in the same order, as len(mine) successive SharedNoiseTable.sample_index calls
     # (legacy RandomState.randint with fixed bounds; pinned by tests/test_host_cpu.py)
     idx = rs.randint(0, noise_len - num_params + 1, size=len(mine)).astype(np.int64)
+    # ascending table order: which of a worker's draws is "pair k" is a label (the reference's master takes results in arrival
+    # order, es.py:246-260), and neighbours in the list then read neighbouring -- largely the same -- rows of the noise table,
+    # which the table-ordered fc kernel (k_fc_duo) and the Infinity Cache turn into fewer HBM bytes
+    idx.sort()
     all_seeds = np.random.RandomState(1000 + generation).randint(0, 2 ** 32, size=2 * n_pairs, dtype=np.uint64).astype(np.uint32)
     seeds = np.stack([all_seeds[2 * mine], all_seeds[2 * mine + 1]], axis=1).reshape(-1)
     return mine, idx, seeds
@@ -365,7 +369,7 @@ def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2,
                                                signreturns_n2=None, lengths_n2=None, eval_return=float(er[0]),
                                                eval_length=int(el[0]), ob_sum=None, ob_sumsq=None, ob_count=None))
         mine = shard_pairs(n_pairs, rank, world)
-        noise_inds = np.array([noise.sample_index(rs, policy.num_params) for _ in range(len(mine))], dtype=np.int64)
+        noise_inds = np.sort(np.array([noise.sample_index(rs, policy.num_params) for _ in range(len(mine))], dtype=np.int64))   # table order: see generation_inputs
         seeds = rs.randint(0, 2 ** 32, size=2 * len(mine), dtype=np.uint64).astype(np.uint32)
         returns, signreturns, lengths = engine.es_eval(noise_inds, config.noise_stdev, tslimit, seeds)
         worker.push_result(task_id, Result(

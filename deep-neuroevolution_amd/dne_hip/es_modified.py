@@ -114,7 +114,7 @@ def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2,
                 eval_return=float(er[0]), eval_length=int(el[0]), ob_sum=None, ob_sumsq=None, ob_count=None,
                 bc_vectors=[(bc[0][None], float(er[0]), int(el[0]), policy_seed_eval, config.noise_stdev)]))
         mine = shard_pairs(n_pairs, rank, world)
-        noise_inds = np.array([noise.sample_index(rs, policy.num_params) for _ in range(len(mine))], dtype=np.int64)
+        noise_inds = np.sort(np.array([noise.sample_index(rs, policy.num_params) for _ in range(len(mine))], dtype=np.int64))   # table order: see es.generation_inputs
         seeds = np.tile(np.array([policy_seed_pos, policy_seed_neg], np.uint32), len(mine))
         returns, signreturns, lengths, bc = engine.es_eval(noise_inds, config.noise_stdev, tslimit, seeds, want_bc=True)
         bc_vectors = []

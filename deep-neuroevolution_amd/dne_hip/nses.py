@@ -162,7 +162,7 @@ def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2,
         policy.set_trainable_flat(task_data.params)
         tslimit = cap if task_data.timestep_limit is None else min(task_data.timestep_limit, cap)
         mine = shard_pairs(n_pairs, rank, world)
-        noise_inds = np.array([noise.sample_index(rs, policy.num_params) for _ in range(len(mine))], dtype=np.int64)
+        noise_inds = np.sort(np.array([noise.sample_index(rs, policy.num_params) for _ in range(len(mine))], dtype=np.int64))   # table order: see generation_inputs
         seeds = rs.randint(0, 2 ** 32, size=2 * len(mine), dtype=np.uint64).astype(np.uint32)
         returns, _, lengths = engine.es_eval(noise_inds, config.noise_stdev, tslimit, seeds)
         novelty = engine.novelty_batch(archive, lengths, k).astype(np.float32).reshape(-1, 2)   # nses.py:381-384

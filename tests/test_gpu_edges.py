@@ -143,6 +143,10 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
 
 @pytest.mark.parametrize("knobs", [
     {"DNE_FC2_MIN": "2", "DNE_FC_TAIL_MAX": "1"},                       # k_fc2 (two pairs per work item; odd count: repeated pair)
+    {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1"},                    # table-ordered units: k_unit_order + k_fc_duo + k_out (odd unit counts, finished partners)
+    {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_FC_RB": "2"},  # ... with 2-row batches
+    {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_NSUB": "2"},   # ... two windows, each with its own unit order
+    {"DNE_FC_DUO": "0", "DNE_FC2_MIN": "2", "DNE_FC_TAIL_MAX": "1"},    # the duo path switched off: k_fc2
     {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1"},                      # k_fc<2> streaming kernel
     {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1", "DNE_FC_RB": "2"},    # ... with 2-row batches
     {"DNE_FC_QUAD_MAX": "0", "DNE_TAIL_FUSED_MAX": "0"},                # k_fc_cols + k_out + separate emulator / render launches

@@ -445,7 +445,7 @@ def test_nses_driver_on_device(hip, oracle, small_noise, tmp_path):
     env = policies.HipAtariEnv(me, seed=0)
     refb = np.rint(np.stack(es.get_ref_batch(env, NREF, np.random.RandomState(0))) * 255.0).astype(np.uint8)
     rs = np.random.RandomState(9); rs.randint(2 ** 31)
-    idx = np.array([noise.sample_index(rs, L.P) for _ in range(4)], np.int64)
+    idx = np.sort(np.array([noise.sample_index(rs, L.P) for _ in range(4)], np.int64))   # the worker labels its draws in table order
     seeds = rs.randint(0, 2 ** 32, size=8, dtype=np.uint64).astype(np.uint32)
     assert np.array_equal(res.noise_inds_n, idx)
     for i in range(4):

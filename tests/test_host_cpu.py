@@ -80,11 +80,11 @@ def test_noise_table_and_sharding(small_noise, golden):
     both = np.zeros(20, np.uint32); both[np.repeat(2 * m0, 2) + np.tile([0, 1], 5)] = s0; both[np.repeat(2 * m1, 2) + np.tile([0, 1], 5)] = s1
     assert np.array_equal(both, sa)                            # env seeds depend on the global pair id only
     assert es.RECORD.itemsize == 32
-    # the vectorised index draw of generation_inputs equals successive sample_index calls on the same stream (es.py:412)
+    # the index draw of generation_inputs = successive sample_index calls on the same stream (es.py:412), in ascending order
     rs2 = np.random.RandomState(3 * 1 + 0)
     t4 = es.SharedNoiseTable(count=100_000, seed=123)
     _, iv, _ = es.generation_inputs(t4.noise.size, 1000, 64, 3, 0, 1)
-    assert iv.tolist() == [t4.sample_index(rs2, 1000) for _ in range(64)]
+    assert iv.tolist() == sorted(t4.sample_index(rs2, 1000) for _ in range(64))   # the worker's draws, labelled in table order
 
 
 def _exp(pop, tslimit):
@@ -125,7 +125,7 @@ def test_run_master_run_worker_in_process(oracle, small_noise, tmp_path):
     opt = oracle.Adam(th, 0.01)
     for it in range(2):
         rs.rand()
-        idx = np.array([noise.sample_index(rs, L.P) for _ in range(4)], np.int64)
+        idx = np.sort(np.array([noise.sample_index(rs, L.P) for _ in range(4)], np.int64))   # the worker labels its draws in table order
         seeds = rs.randint(0, 2 ** 32, size=8, dtype=np.uint64).astype(np.uint32)
         rets, sg, ln = oracle.es_eval(L, th, noise.noise, idx, 0.02, 12, ref, seeds)
         opt.theta = th.copy()

@@ -12,6 +12,8 @@ ap.add_argument("--tslimit", type=int, default=24)
 ap.add_argument("--noise-count", type=int, default=250_000_000)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--ref-chunk", type=int, default=0)
+ap.add_argument("--sort-idx", action="store_true", help="members in ascending noise-index order (Infinity Cache locality experiment)")
+ap.add_argument("--idx-range", type=int, default=0, help="draw the noise indices from [0, N) only: the whole working set cache-resident")
 a = ap.parse_args()
 e = _lib.Engine(_lib.KIND_ES, 18, max_members=2 * a.pairs, ref_count=128, profile_events=True, ref_chunk=a.ref_chunk)
 noise = es.SharedNoiseTable(count=a.noise_count); noise.attach(e)
@@ -21,6 +23,10 @@ ref = np.rint(np.stack(es.get_ref_batch(env, 128, np.random.RandomState(0))) * 2
 e.set_ref_batch(ref)
 for rep in range(a.reps):
     _, idx, seeds = es.generation_inputs(noise.noise.size, e.P, a.pairs, rep, 0, 1)
+    if a.idx_range:
+        idx = np.random.RandomState(rep).randint(0, a.idx_range, size=len(idx)).astype(idx.dtype)
+    if a.sort_idx:
+        idx = np.sort(idx)
     t = time.time(); ret, sg, ln = e.es_eval(idx, 0.02, a.tslimit, seeds); wall = time.time() - t
     p = e.profile()
     n = p["fc_launches"]

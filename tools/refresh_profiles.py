@@ -42,7 +42,7 @@ lines = ["kernel,grid_size,dispatches,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg"]
 for k in sorted(set(f) | set(w)):
     lines.append("%s,%d,%d,%.1f,%.1f" % (k[0], k[1], f.get(k, (0, 0))[0], f.get(k, (0, 0))[1], w.get(k, (0, 0))[1]))
 open(P + '/%s_pmc_fetch_write_by_kernel.csv' % PFX, 'w').write("\n".join(lines) + "\n")
-kf = max((k for k in f if k[0].startswith('dne::k_fc2<')), key=lambda k: f[k][1])   # the full-width launches (one window: DNE_NSUB=1)
+kf = max((k for k in f if k[0].startswith('dne::k_fc_duo<') or k[0].startswith('dne::k_fc2<')), key=lambda k: f[k][1])   # the full-width launches (one window: DNE_NSUB=1)
 units = 5000   # 2500 pairs = 5000 member-steps per launch
 fetch = f[kf][1] * 1024 * 2; write = w[kf][1] * 1024
 out = {"k_fc_step": {"kernel": kf[0], "grid_size": kf[1], "units_per_launch": units, "FETCH_SIZE_KB_avg": f[kf][1], "WRITE_SIZE_KB_avg": w[kf][1],
@@ -50,7 +50,7 @@ out = {"k_fc_step": {"kernel": kf[0], "grid_size": kf[1], "units_per_launch": un
                      "hbm_bytes_per_launch": fetch + write, "hbm_bytes_per_unit": (fetch + write) / units,
                      "algorithmic_bytes_per_unit": 4064456, "noise_bytes_per_pair": 3964928},
        "command": "DNE_NSUB=1 rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python tools/kbench.py --reps 1 --tslimit 6  "
-                  "(separate passes, 2500 pairs in one window: a k_fc2 launch = 5000 member-steps)"}
+                  "(separate passes, 2500 pairs in one window: a full-width fc launch = 5000 member-steps)"}
 for name, key, note in (('k_materialize', 'dne::k_materialize', "4 B/lane loads: FETCH_SIZE matches the known byte count without correction (calibration point)"),
                         ('k_weighted_sum', 'dne::k_weighted_sum', "4 B/lane loads; the 1 GB table is re-read ~10x so part of the traffic is served by L2 / Infinity Cache")):
     kk = [k for k in f if k[0] == key]
