@@ -131,10 +131,15 @@ def rccl_rendezvous(_lib, engine, rank, world):
     keyed by the launcher's pid and MASTER_PORT; the others wait for it.  Then every rank joins the communicator."""
     path = os.environ.get("DNE_RCCL_ID_FILE") or "/tmp/dne_rccl_id.%s.%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
     if rank == 0:
-        uid = _lib.comm_unique_id()
+        try:
+            uid = _lib.comm_unique_id()
+        except _lib.DneError:
+            uid = None
         with open(path + ".tmp", "wb") as f:
-            f.write(uid)
+            f.write(uid if uid is not None else b"!")   # a one-byte file tells the waiting ranks that there will be no id
         os.replace(path + ".tmp", path)
+        if uid is None:
+            raise _lib.DneError("rank 0 could not open RCCL")
     else:
         deadline = time.time() + 600
         while True:
@@ -142,6 +147,8 @@ def rccl_rendezvous(_lib, engine, rank, world):
                 uid = open(path, "rb").read()
                 if len(uid) == 128:
                     break
+                if len(uid) == 1:
+                    raise _lib.DneError("rank 0 could not open RCCL")
             except OSError:
                 pass
             if time.time() > deadline:
@@ -242,10 +249,17 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback (%s)" % e)
     crumb("engine created on device %d (%d pairs)" % (local_rank, my_pairs))
     transport = None
+    use_gloo = world > 1 and args.transport == "gloo"
     if world > 1 and args.transport == "rccl":
-        rccl_rendezvous(_lib, engine, rank, world)
-        crumb("RCCL communicator ready")
-    elif world > 1:
+        try:
+            rccl_rendezvous(_lib, engine, rank, world)
+            crumb("RCCL communicator ready")
+        except _lib.DneError as e:
+            # ncclCommInitRank fails on every rank or on none (same library, same topology): all ranks take the host path
+            # together.  The records are 32 bytes per pair, so the carrier decides nothing about the result, only ~1 ms of latency.
+            crumb("RCCL communicator could not be created (%s): falling back to the gloo carrier for the 32-byte records" % e)
+            use_gloo = True
+    if use_gloo:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -312,6 +312,8 @@ struct dne_handle {
     int fc_pairs = 2;                // ES full-width fc: antithetic pairs per work item (DNE_FC_PAIRS, 1 = k_fc<2>)
     int fc2_min_total = 800;         // k_fc2 from this many active groups upwards (DNE_FC2_MIN)
     bool fc2_now = false;            // decided per burst by eval_core
+    int duo_solo_below = 1500;       // DNE_DUO_SOLO_BELOW: with fewer active groups (all windows) every wave takes one unit instead of two (sparse table: little to share, and twice the waves)
+    bool duo_solo_now = false;       // decided per burst by eval_core
     int duo_lag = 0;                 // DNE_DUO_LAG: extra row batches by which the second unit of a duo trails the first
     int fc_duo = 1, fc_duo_min = 800;   // DNE_FC_DUO / DNE_FC_DUO_MIN: table-ordered fc (k_unit_order + k_fc_duo + k_out) from this many active groups
     bool duo_now = false;            // decided per burst by eval_core (the unit order of each window is rebuilt then)
@@ -633,6 +635,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC2_MIN", 2, 1 << 30, &h->fc2_min_total);
     env_int("DNE_FC_DUO", 0, 1, &h->fc_duo);
     env_int("DNE_DUO_LAG", 0, 64, &h->duo_lag);
+    env_int("DNE_DUO_SOLO_BELOW", 0, 1 << 30, &h->duo_solo_below);
     env_int("DNE_FC_DUO_MIN", 2, 1 << 30, &h->fc_duo_min);
     env_int("DNE_RENDER_BANDS", 1, 12, &h->render_bands);
     env_int("DNE_FC_CHAIN_MIN", 1, 1 << 30, &h->fc_chain_min);
@@ -1141,8 +1144,10 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         return;
     }
     if (gsize == 2 && es && h->duo_now && !logits && order) {   // table-ordered units: adjacent (pair, k-slice) units share their noise rows
-        const int n_units = 4 * count, items = ((n_units + 1) / 2 + 3) / 4, blocks = std::min(items, h->fc_grid);
-        hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag);
+        const bool solo = h->duo_solo_now;
+        const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 3) / 4, blocks = std::min(items, h->fc_grid);
+        hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t,
+                           h->duo_lag | (solo ? 256 : 0));
         if (after_stream_kernel) hipEventRecord(after_stream_kernel, st);
         hipLaunchKernelGGL((k_out<2, true>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
         return;
@@ -1258,6 +1263,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
         h->fc2_now = h->fc_pairs == 2 && total >= h->fc2_min_total;
         h->duo_now = h->fc_duo && gsize == 2 && h->L.kind == DNE_KIND_ES && total >= h->fc_duo_min &&
                      (size_t)4 * ((total + nsub - 1) / nsub) * sizeof(long long) <= 160 * 1024;   // k_unit_order ranks a window's keys in LDS
+        h->duo_solo_now = total < h->duo_solo_below;
         if (h->duo_now)   // the list only changes at a compaction: rank each window's units by table address once per burst
             for (int s = 0; s < nsub; s++) {
                 const int lo = (int)((long long)total * s / nsub), cnt = (int)((long long)total * (s + 1) / nsub) - lo;

@@ -1126,12 +1126,14 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
     const unsigned voff = lane * 16;
     const Layout &L = A.L;
     __builtin_amdgcn_s_setprio(3);
-    const int n_duos = (n_units + 1) >> 1, n_items = (n_duos + 3) >> 2;
+    const bool solo = (lag & 256) != 0;   // sparse windows: one unit per wave (twice the waves, nothing to share anyway)
+    lag &= 255;
+    const int n_duos = solo ? n_units : (n_units + 1) >> 1, n_items = (n_duos + 3) >> 2;
     typedef DuoSide<NV> Side;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int d = item * 4 + wv;
         if (d >= n_duos) continue;
-        int uA = uni(order[2 * d]), uB = 2 * d + 1 < n_units ? uni(order[2 * d + 1]) : -1;
+        int uA = uni(order[solo ? d : 2 * d]), uB = !solo && 2 * d + 1 < n_units ? uni(order[2 * d + 1]) : -1;
         if (A.done) {
             auto finished = [&](int uu) {
                 int all_done = 1;
