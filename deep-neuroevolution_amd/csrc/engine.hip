@@ -45,6 +45,11 @@ struct EnvArgs {
     uint8_t *bc;
     int bc_mode;                     // 0 none, 1 RAM per step (ES, policies.py:410,418), 2 final RAM (GA, policies.py:510)
     int bc_max_steps;
+    // speculative tail (k_env_spec / k_env_render_spec / k_tail_select): the outcome of EVERY action from the current state,
+    // indexed by (position in the active list, action)
+    uint8_t *spec_prev, *spec_cur;   // [SPEC_CAP * 32][128] RAM rows before / after the step's last frame
+    int32_t *spec_rw;                // [SPEC_CAP * 32][2]: reward, game over
+    uint8_t *spec_stacks;            // [SPEC_CAP * 32][84][84][4]
 };
 
 // The emulator state is 40 live bytes per member (RAM bytes 40..127 stay zero).  The per-frame logic is branchy
@@ -93,17 +98,11 @@ __global__ __launch_bounds__(64) void k_env_reset_logic(EnvArgs E, const uint32_
     E.ret[m] = 0.0f; E.sign[m] = 0.0f; E.step_reward[m] = 0.0f; E.len[m] = 0; E.done[m] = 0; E.stepped[m] = 1;
 }
 
-// one wrapped step of member m (atari_wrappers.py:88-107 skip-4 + the episode bookkeeping of policies.py:399-425);
-// the caller is a single lane.  lds_prev / lds_cur (optional): LDS copies of the RAM rows for a renderer in the same kernel.
-__device__ __forceinline__ void env_member_step(const EnvArgs &E, int m, int action, int tslimit, uint8_t *lds_prev = nullptr,
-                                                uint8_t *lds_cur = nullptr) {
+// the episode bookkeeping of one wrapped step of member m (policies.py:399-425) from its outcome: packed RAM before / after the
+// step's last frame, reward, game over.  lds_prev / lds_cur (optional): LDS copies of the RAM rows for a renderer in the same kernel.
+__device__ __forceinline__ void env_commit(const EnvArgs &E, int m, const uint32_t (&wp)[RAM_LIVE / 4], const uint32_t (&wc)[RAM_LIVE / 4],
+                                           int r, int over, int tslimit, uint8_t *lds_prev = nullptr, uint8_t *lds_cur = nullptr) {
     uint8_t *gp = E.ram_prev + (size_t)m * 128, *gc = E.ram_cur + (size_t)m * 128;
-    Emu cur = ram_load(gc), prev = cur;               // skip4 overwrites prev before its first use
-    int over;
-    const int r = skip4(prev, cur, action, &over);
-    uint32_t wp[RAM_LIVE / 4], wc[RAM_LIVE / 4];
-    emu_pack(prev, wp);
-    emu_pack(cur, wc);
 #pragma unroll
     for (int j = 0; j < RAM_LIVE / 4; j++) { ((uint32_t *)gp)[j] = wp[j]; ((uint32_t *)gc)[j] = wc[j]; }
     if (lds_prev) {
@@ -130,6 +129,24 @@ __device__ __forceinline__ void env_member_step(const EnvArgs &E, int m, int act
     if (over || t + 1 >= tslimit) E.done[m] = 1;             // policies.py:401,424-425
 }
 
+// one wrapped step of member m (atari_wrappers.py:88-107 skip-4) + its bookkeeping; the caller is a single lane
+__device__ __forceinline__ void env_member_step(const EnvArgs &E, int m, int action, int tslimit, uint8_t *lds_prev = nullptr,
+                                                uint8_t *lds_cur = nullptr) {
+    Emu cur = ram_load(E.ram_cur + (size_t)m * 128), prev = cur;   // skip4 overwrites prev before its first use
+    int over;
+    const int r = skip4(prev, cur, action, &over);
+    uint32_t wp[RAM_LIVE / 4], wc[RAM_LIVE / 4];
+    emu_pack(prev, wp);
+    emu_pack(cur, wc);
+    env_commit(E, m, wp, wc, r, over, tslimit, lds_prev, lds_cur);
+}
+
+// Speculative tail.  With a handful of members left a lock-step is a latency chain, forward pass -> emulator -> renderer, on a
+// nearly idle chip.  The emulator and the renderer do not need the forward pass, only its 1-of-nact answer: while the forward
+// pass of step t runs, these two kernels work out the step for EVERY action from the state after step t - 1 (one lane per
+// (member, action); a candidate frame stack per action), and k_tail_select only has to adopt the candidate of the action the
+// policy picks.  Nothing is predicted and nothing is ever rolled back; the arithmetic per (member, action) is env_member_step's.
+constexpr int SPEC_ACTIONS = 32;   // stride of the candidate arrays (>= n_actions)
 __global__ __launch_bounds__(64) void k_env_logic(EnvArgs E, const int *__restrict__ list, int gsize, int n_items, int tslimit) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n_items) return;
@@ -181,7 +198,7 @@ struct HeadLds {
 template <bool HAS_BN, bool RENDER, typename WaitFn>
 __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, const EnvArgs &E, int m, int tslimit,
                                           const float *__restrict__ y3t, float *__restrict__ y3, int32_t *__restrict__ actions,
-                                          WaitFn wait) {
+                                          WaitFn wait, int spec_pos = -1 /* >= 0: adopt the speculated outcome at this list position */) {
     constexpr int WS = HEAD_WS;
     auto &s = H.s;
     float (&a3)[256] = H.a3;
@@ -246,11 +263,30 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
         for (int a = 1; a < nact; a++)
             if (lg[a] > lg[best]) best = a;   // tf.argmax: first maximum
         actions[m] = best;
-        env_member_step(E, m, best, tslimit, RENDER ? s.ram_prev : nullptr, RENDER ? s.ram_cur : nullptr);
+        if (spec_pos < 0) {
+            env_member_step(E, m, best, tslimit, RENDER ? s.ram_prev : nullptr, RENDER ? s.ram_cur : nullptr);
+        } else {   // k_env_spec / k_env_render_spec have worked this step out for every action: take the chosen one
+            const size_t c = (size_t)spec_pos * SPEC_ACTIONS + best;
+            uint32_t wp[RAM_LIVE / 4], wc[RAM_LIVE / 4];
+#pragma unroll
+            for (int j = 0; j < RAM_LIVE / 4; j++) {
+                wp[j] = ((const uint32_t *)(E.spec_prev + c * 128))[j];
+                wc[j] = ((const uint32_t *)(E.spec_cur + c * 128))[j];
+            }
+            env_commit(E, m, wp, wc, E.spec_rw[2 * c], E.spec_rw[2 * c + 1], tslimit);
+            lg[31] = __int_as_float(best);
+        }
     }
     if constexpr (RENDER) {
         __syncthreads();
         synth_observe(s, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), false);
+    }
+    if (spec_pos >= 0) {   // the candidate frame stack of the chosen action becomes the member's stack
+        __syncthreads();
+        const int best = __float_as_int(lg[31]);
+        const uint4 *src = (const uint4 *)(E.spec_stacks + ((size_t)spec_pos * SPEC_ACTIONS + best) * OB_BYTES);
+        uint4 *dst = (uint4 *)(E.stacks + (size_t)m * OB_BYTES);
+        for (int i = tid; i < OB_BYTES / 16; i += blockDim.x) dst[i] = src[i];
     }
 }
 
@@ -264,6 +300,75 @@ __global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const 
     const int m = g * gsize + b % gsize;
     if (E.done[m]) { if (threadIdx.x == 0) E.stepped[m] = 0; return; }
     head_body<HAS_BN, RENDER>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{});
+}
+
+// The two speculative kernels ride in launches of the forward pass (same stream, no event traffic -- a cross-stream event
+// hand-over per lock-step costs more than the lock-step): the emulator lanes share conv1's launch, the candidate renderers share
+// the quad fc's (they need the emulator's output, i.e. a kernel boundary, and the fc is the longest stage to hide under).
+__global__ __launch_bounds__(256) void k_conv1_spec(FwdArgs A, EnvArgs E, const int *__restrict__ list, int gsize,
+                                                    float *__restrict__ y1, int nsplit, int n_conv_blocks, int n_items, int nact) {
+    __shared__ Conv1Lds S;
+    if ((int)blockIdx.x < n_conv_blocks) {
+        const Item it = decode_item(blockIdx.x / nsplit, list, gsize, 1, 0, E.stacks, nullptr, A.done);
+        if (it.skip) return;
+        conv1_body(S, A, it, y1, blockIdx.x % nsplit, nsplit);
+        return;
+    }
+    const int i = ((int)blockIdx.x - n_conv_blocks) * 256 + threadIdx.x;
+    if (i >= n_items * nact) return;
+    const int b = i / nact, a = i % nact;
+    const int g = list ? list[b / gsize] : b / gsize;
+    const int m = g * gsize + b % gsize;
+    if (E.done[m]) return;
+    Emu cur = ram_load(E.ram_cur + (size_t)m * 128), prev = cur;
+    int over;
+    const int r = skip4(prev, cur, a, &over);
+    const size_t c = (size_t)b * SPEC_ACTIONS + a;
+    ram_store(prev, E.spec_prev + c * 128);
+    ram_store(cur, E.spec_cur + c * 128);
+    E.spec_rw[2 * c] = r;
+    E.spec_rw[2 * c + 1] = over;
+}
+
+template <int NV, bool HAS_BN>
+__global__ __launch_bounds__(256) void k_fc_quad_spec(FwdArgs A, EnvArgs E, const int *__restrict__ list, int gsize,
+                                                      const float *__restrict__ y2, float *__restrict__ y3t, int n_fc_blocks,
+                                                      int nact, int nbands) {
+    constexpr size_t LDS_BYTES = sizeof(EnvLds) > sizeof(QuadLds<NV>) ? sizeof(EnvLds) : sizeof(QuadLds<NV>);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    if ((int)blockIdx.x < n_fc_blocks) {
+        QuadLds<NV> &S = *reinterpret_cast<QuadLds<NV> *>(lds);
+        const int item = blockIdx.x >> 6, cg = (blockIdx.x >> 2) & 15, sl = blockIdx.x & 3;
+        fc_quad_body<NV, HAS_BN, false>(S, A, list ? list[item] : item, cg, sl, y2, y3t, NoWait{});
+        return;
+    }
+    EnvLds &s = *reinterpret_cast<EnvLds *>(lds);
+    const int rb = (int)blockIdx.x - n_fc_blocks;
+    const int band = rb % nbands, ba = rb / nbands, b = ba / nact, a = ba % nact;
+    const int g = list ? list[b / gsize] : b / gsize;
+    const int m = g * gsize + b % gsize;
+    if (E.done[m]) return;
+    synth_load_tables(s, E.T);
+    const size_t c = (size_t)b * SPEC_ACTIONS + a;
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        s.ram_prev[tid] = E.spec_prev[c * 128 + tid];
+        s.ram_cur[tid] = E.spec_cur[c * 128 + tid];
+    }
+    __syncthreads();
+    synth_observe(s, (uint32_t *)(E.spec_stacks + c * OB_BYTES), false, band, nbands, (const uint32_t *)(E.stacks + (size_t)m * OB_BYTES));
+}
+
+template <bool HAS_BN>
+__global__ __launch_bounds__(1024) void k_tail_select(FwdArgs A, EnvArgs E, const int *__restrict__ list, int gsize, int tslimit,
+                                                       const float *__restrict__ y3t, float *__restrict__ y3,
+                                                       int32_t *__restrict__ actions) {
+    __shared__ HeadLds<false> H;
+    const int b = blockIdx.x;
+    const int g = list ? list[b / gsize] : b / gsize;
+    const int m = g * gsize + b % gsize;
+    if (E.done[m]) { if (threadIdx.x == 0) E.stepped[m] = 0; return; }
+    head_body<HAS_BN, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b);
 }
 
 // order-preserving compaction of the active-group list
@@ -318,6 +423,10 @@ struct dne_handle {
     int fc_duo = 1, fc_duo_min = 800;   // DNE_FC_DUO / DNE_FC_DUO_MIN: table-ordered fc (k_unit_order + k_fc_duo + k_out) from this many active groups
     bool duo_now = false;            // decided per burst by eval_core (the unit order of each window is rebuilt then)
     int *unit_order = nullptr;       // [4 * groups]: per window, its (group, k-slice) units in noise-table order
+    int spec_max = 8;                // DNE_SPEC_MAX: a single window of up to this many members (4 antithetic pairs) steps speculatively -- every action's outcome is worked out under the forward pass; 0 = off
+    uint8_t *spec_prev = nullptr, *spec_cur = nullptr, *spec_stacks = nullptr;
+    int32_t *spec_rw = nullptr;
+    int spec_bands = 7;              // DNE_SPEC_BANDS: 256-thread workgroups per candidate frame
     bool uniform_base = false;       // every member perturbs base slot 0 (set by dne_es_eval, cleared by dne_set_members)
     int render_bands = 4, band_threads = 512;   // tail: workgroups per frame (DNE_RENDER_BANDS, 1 = render inside k_tail_step) and their size
     int tail_fused_max = 200;        // up to this many active groups (all windows) k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
@@ -440,6 +549,7 @@ struct dne_handle {
         E.ram_prev = ram_prev; E.ram_cur = ram_cur; E.stacks = stacks; E.T = tables;
         E.ret = ret; E.sign = sign; E.step_reward = step_reward; E.len = len; E.done = done; E.stepped = stepped; E.action = action; E.step_counter = nullptr;
         E.bc = bc; E.bc_mode = bc ? bc_mode : 0; E.bc_max_steps = cfg.bc_max_steps;
+        E.spec_prev = spec_prev; E.spec_cur = spec_cur; E.spec_rw = spec_rw; E.spec_stacks = spec_stacks;
         return E;
     }
     hipEvent_t event(size_t i) {
@@ -633,6 +743,8 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_CONV1_FPW", 1, 8, &h->conv1_fpw);
     env_int("DNE_CONV_SPLIT_MAX", 0, 1 << 20, &h->conv_split_max);
     env_int("DNE_FC2_MIN", 2, 1 << 30, &h->fc2_min_total);
+    env_int("DNE_SPEC_MAX", 0, 64, &h->spec_max);
+    env_int("DNE_SPEC_BANDS", 1, 12, &h->spec_bands);
     env_int("DNE_FC_DUO", 0, 1, &h->fc_duo);
     env_int("DNE_DUO_LAG", 0, 64, &h->duo_lag);
     env_int("DNE_DUO_SOLO_BELOW", 0, 1 << 30, &h->duo_solo_below);
@@ -678,6 +790,13 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipMemset(h->done, 0, M * sizeof(int32_t))); CH(hipMemset(h->len, 0, M * sizeof(int32_t)));
     CH(h->alloc(&h->y1, M * 7056, "y1")); CH(h->alloc(&h->y2, M * 3872, "y2")); CH(h->alloc(&h->y3, M * 256, "y3")); CH(h->alloc(&h->y3t, M * 4 * 256, "y3t"));
     CH(h->alloc(&h->unit_order, M * 4, "unit_order"));
+    if (cfg->n_actions > SPEC_ACTIONS - 2) h->spec_max = 0;
+    if (h->spec_max > 0) {   // candidate outcomes of the speculative tail: [list position][action]
+        const size_t rows = (size_t)h->spec_max * SPEC_ACTIONS;
+        CH(h->alloc(&h->spec_prev, rows * 128, "spec_prev")); CH(h->alloc(&h->spec_cur, rows * 128, "spec_cur"));
+        CH(h->alloc(&h->spec_rw, rows * 2, "spec_rw")); CH(h->alloc(&h->spec_stacks, rows * OB_BYTES, "spec_stacks"));
+        CH(hipMemset(h->spec_prev, 0, rows * 128)); CH(hipMemset(h->spec_cur, 0, rows * 128));   // RAM bytes past the live 40 stay zero
+    }
     if (h->F) {
         const size_t rr = (size_t)h->ref_chunk * h->F;
         for (int w = 0; w < 2; w++) {
@@ -1283,13 +1402,39 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 const bool duo_win = h->duo_now && cnt > h->fc_tail_max;
                 const bool pe = prof && (duo_eval ? duo_win : fc2_eval ? h->fc2_now : cnt > h->fc_tail_max);
                 if (pe) { e[0] = ne++; HCHECK(h, hipEventRecord(h->event(e[0]), sst)); }
+                // fused policy head + emulator (+ render): while all windows together still fit the chip one workgroup per member
+                const bool tail = cnt <= h->fc_tail_max && total <= h->tail_fused_max;
+                // speculative tail: the emulator + renderer outcome of every action, inside the launches of this step's forward pass
+                const bool spec = tail && nsub == 1 && h->spec_max > 0 && cnt * gsize <= h->spec_max && cnt <= h->fc_quad_max &&
+                                  cnt * gsize <= h->conv_split_max && !h->dbg_skip;
+                if (spec) {
+                    const int items = cnt * gsize, nact = h->cfg.n_actions, nb = h->spec_bands;
+                    const FwdArgs A = h->fwd(true);
+                    const bool es = h->L.kind == DNE_KIND_ES;
+                    hipLaunchKernelGGL(k_conv1_spec, dim3(items * 7 + (items * nact + 255) / 256), dim3(256), 0, sst, A, E, lst, gsize, h->y1, 7,
+                                       items * 7, items, nact);
+                    if (es) hipLaunchKernelGGL((k_conv2<true>), dim3(items * 4), dim3(256), 0, sst, A, lst, gsize, 1, 0, (const float *)h->y1, h->y2, 4, (float *)nullptr);
+                    else hipLaunchKernelGGL((k_conv2<false>), dim3(items * 4), dim3(256), 0, sst, A, lst, gsize, 1, 0, (const float *)h->y1, h->y2, 4, (float *)nullptr);
+#define FQS(NV, BN) hipLaunchKernelGGL((k_fc_quad_spec<NV, BN>), dim3(cnt * 64 + items * nact * nb), dim3(256), 0, sst, A, E, lst, gsize, (const float *)h->y2, h->y3t, cnt * 64, nact, nb)
+                    if (gsize == 2) { if (es) FQS(2, true); else FQS(2, false); }
+                    else { if (es) FQS(1, true); else FQS(1, false); }
+#undef FQS
+                    if (es) hipLaunchKernelGGL((k_tail_select<true>), dim3(items), dim3(256), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
+                    else hipLaunchKernelGGL((k_tail_select<false>), dim3(items), dim3(256), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
+                    if (h->debug_sync) {
+                        hipError_t de = hipStreamSynchronize(sst);
+                        if (de == hipSuccess) de = hipGetLastError();
+                        if (de != hipSuccess) return h->fail("lock-step %d (speculative tail, %d active groups): %s", t + st, cnt, hipGetErrorString(de));
+                    }
+                    group_steps += cnt;
+                    launch_sets++;
+                    continue;
+                }
                 launch_forward(h, lst, cnt, gsize, true, sst);
                 // optional: serialise the fc kernels of the windows (anti-phase); off by default, free-running measured faster
                 const bool chain = nsub > 1 && cnt >= h->fc_chain_min;
                 if (chain && last_fc) HCHECK(h, hipStreamWaitEvent(sst, last_fc, 0));
                 if (pe) { e[1] = ne++; HCHECK(h, hipEventRecord(h->event(e[1]), sst)); }   // after the wait: brackets fc only
-                // fused policy head + emulator (+ render): while all windows together still fit the chip one workgroup per member
-                const bool tail = cnt <= h->fc_tail_max && total <= h->tail_fused_max;
                 if (pe) e[2] = ne++;
                 launch_fc(h, lst, cnt, gsize, nullptr, sst, tail, h->duo_now ? h->unit_order + 4 * lo : nullptr,
                           pe && duo_win ? h->event(e[2]) : nullptr);   // duo: the bracket ends behind k_fc_duo, before k_out

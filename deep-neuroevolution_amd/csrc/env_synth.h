@@ -369,7 +369,11 @@ __device__ inline void synth_load_tables(EnvLds &s, const ResizeLds *__restrict_
 // Render + warp max(prev, cur) and either shift it into the stack (fill == false) or fill all four
 // channels with it (fill == true, FrameStack reset).  Called by the whole workgroup (>= 256 threads) after
 // synth_load_tables and after ram_prev / ram_cur are in LDS.
-__device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bool fill, int band = 0, int nbands = 1) {
+// stack_in (optional): where the member's current frame stack is read when the shifted stack goes to another buffer
+// (speculative tail: one candidate stack per action); default = in place.
+__device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bool fill, int band = 0, int nbands = 1,
+                                     const uint32_t *__restrict__ stack_in = nullptr) {
+    if (!stack_in) stack_in = stack;
     // A workgroup produces output rows [yy0, yy1) of the 84 (all of them when nbands == 1; in the tail of a generation a
     // member's frame is split over several workgroups = several CUs).  It needs screen rows [ylo, yhi) only.
     const int tid = threadIdx.x, nthr = blockDim.x;   // 256 threads normally, 1024 when few members remain
@@ -383,7 +387,7 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
 #pragma unroll
         for (int j = 0; j < VP; j++) {
             const int i = tid + j * nthr;
-            old[j] = i < nout ? stack[out0 + i] : 0u;
+            old[j] = i < nout ? stack_in[out0 + i] : 0u;
         }
     }
     if (tid < 192) s.slot_of_key[tid] = -1;
@@ -438,7 +442,7 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
 #pragma unroll
             for (int j = 0; j < VP; j++) {
                 const int i = base + tid + j * nthr;
-                old[j] = i < nout ? stack[out0 + i] : 0u;
+                old[j] = i < nout ? stack_in[out0 + i] : 0u;
             }
         }
 #pragma unroll
