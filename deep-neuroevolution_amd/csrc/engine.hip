@@ -50,6 +50,7 @@ struct EnvArgs {
     uint8_t *spec_prev, *spec_cur;   // [SPEC_CAP * 32][128] RAM rows before / after the step's last frame
     int32_t *spec_rw;                // [SPEC_CAP * 32][2]: reward, game over
     uint8_t *spec_stacks;            // [SPEC_CAP * 32][84][84][4]
+    float *spec_y1;                  // [SPEC_CAP * 32][441][16]: conv1 of every candidate stack (the next step starts at conv2)
 };
 
 // The emulator state is 40 live bytes per member (RAM bytes 40..127 stay zero).  The per-frame logic is branchy
@@ -330,6 +331,37 @@ __global__ __launch_bounds__(256) void k_conv1_spec(FwdArgs A, EnvArgs E, const 
     E.spec_rw[2 * c + 1] = over;
 }
 
+// conv2 of the forward pass + the emulator outcome of every action.  y1_cand: the member's conv1 output is the candidate its
+// last action selected (k_tail_select_conv1 of the previous lock-step), not a row of y1.
+template <bool HAS_BN>
+__global__ __launch_bounds__(256) void k_conv2_spec(FwdArgs A, EnvArgs E, const int *__restrict__ list, int gsize,
+                                                    const float *__restrict__ y1, float *__restrict__ y2, int nsplit, int n_conv_blocks,
+                                                    int n_items, int nact, const int32_t *__restrict__ last_action) {
+    __shared__ Conv2Lds S;
+    if ((int)blockIdx.x < n_conv_blocks) {
+        const int b = blockIdx.x / nsplit;
+        const Item it = decode_item(b, list, gsize, 1, 0, nullptr, nullptr, A.done);
+        if (it.skip) return;
+        const float *row = E.spec_y1 + ((size_t)b * SPEC_ACTIONS + last_action[it.member]) * 7056;
+        conv2_body<HAS_BN>(S, A, it, y1, y2, blockIdx.x % nsplit, nsplit, nullptr, row);
+        return;
+    }
+    const int i = ((int)blockIdx.x - n_conv_blocks) * 256 + threadIdx.x;
+    if (i >= n_items * nact) return;
+    const int b = i / nact, a = i % nact;
+    const int g = list ? list[b / gsize] : b / gsize;
+    const int m = g * gsize + b % gsize;
+    if (E.done[m]) return;
+    Emu cur = ram_load(E.ram_cur + (size_t)m * 128), prev = cur;
+    int over;
+    const int r = skip4(prev, cur, a, &over);
+    const size_t c = (size_t)b * SPEC_ACTIONS + a;
+    ram_store(prev, E.spec_prev + c * 128);
+    ram_store(cur, E.spec_cur + c * 128);
+    E.spec_rw[2 * c] = r;
+    E.spec_rw[2 * c + 1] = over;
+}
+
 template <int NV, bool HAS_BN>
 __global__ __launch_bounds__(256) void k_fc_quad_spec(FwdArgs A, EnvArgs E, const int *__restrict__ list, int gsize,
                                                       const float *__restrict__ y2, float *__restrict__ y3t, int n_fc_blocks,
@@ -369,6 +401,35 @@ __global__ __launch_bounds__(1024) void k_tail_select(FwdArgs A, EnvArgs E, cons
     const int m = g * gsize + b % gsize;
     if (E.done[m]) { if (threadIdx.x == 0) E.stepped[m] = 0; return; }
     head_body<HAS_BN, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b);
+}
+
+// k_tail_select + conv1 of every candidate frame stack (workgroups past the first n_items): whichever action the policy picks in
+// the same launch, the next lock-step finds its conv1 output ready and starts at conv2.
+template <bool HAS_BN>
+__global__ __launch_bounds__(256) void k_tail_select_conv1(FwdArgs A, EnvArgs E, const int *__restrict__ list, int gsize, int tslimit,
+                                                           const float *__restrict__ y3t, float *__restrict__ y3,
+                                                           int32_t *__restrict__ actions, int n_items, int nact, int nsplit) {
+    constexpr size_t LDS_BYTES = sizeof(HeadLds<false>) > sizeof(Conv1Lds) ? sizeof(HeadLds<false>) : sizeof(Conv1Lds);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    if ((int)blockIdx.x < n_items) {
+        HeadLds<false> &H = *reinterpret_cast<HeadLds<false> *>(lds);
+        const int b = blockIdx.x;
+        const int g = list ? list[b / gsize] : b / gsize;
+        const int m = g * gsize + b % gsize;
+        if (E.done[m]) { if (threadIdx.x == 0) E.stepped[m] = 0; return; }
+        head_body<HAS_BN, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b);
+        return;
+    }
+    Conv1Lds &S = *reinterpret_cast<Conv1Lds *>(lds);
+    const int cb = (int)blockIdx.x - n_items, part = cb % nsplit, ba = cb / nsplit, b = ba / nact, a = ba % nact;
+    const int g = list ? list[b / gsize] : b / gsize;
+    Item it;
+    it.member = g * gsize + b % gsize;
+    if (E.done[it.member]) return;
+    it.row = b * SPEC_ACTIONS + a;
+    it.ob = E.spec_stacks + (size_t)it.row * OB_BYTES;
+    it.skip = false;
+    conv1_body(S, A, it, E.spec_y1, part, nsplit);
 }
 
 // order-preserving compaction of the active-group list
@@ -426,7 +487,9 @@ struct dne_handle {
     int spec_max = 8;                // DNE_SPEC_MAX: a single window of up to this many members (4 antithetic pairs) steps speculatively -- every action's outcome is worked out under the forward pass; 0 = off
     uint8_t *spec_prev = nullptr, *spec_cur = nullptr, *spec_stacks = nullptr;
     int32_t *spec_rw = nullptr;
+    float *spec_y1 = nullptr;
     int spec_bands = 7;              // DNE_SPEC_BANDS: 256-thread workgroups per candidate frame
+    int spec_conv1 = 1;              // DNE_SPEC_CONV1: conv1 of every candidate stack in the launch that picks the action
     bool uniform_base = false;       // every member perturbs base slot 0 (set by dne_es_eval, cleared by dne_set_members)
     int render_bands = 4, band_threads = 512;   // tail: workgroups per frame (DNE_RENDER_BANDS, 1 = render inside k_tail_step) and their size
     int tail_fused_max = 200;        // up to this many active groups (all windows) k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
@@ -549,7 +612,7 @@ struct dne_handle {
         E.ram_prev = ram_prev; E.ram_cur = ram_cur; E.stacks = stacks; E.T = tables;
         E.ret = ret; E.sign = sign; E.step_reward = step_reward; E.len = len; E.done = done; E.stepped = stepped; E.action = action; E.step_counter = nullptr;
         E.bc = bc; E.bc_mode = bc ? bc_mode : 0; E.bc_max_steps = cfg.bc_max_steps;
-        E.spec_prev = spec_prev; E.spec_cur = spec_cur; E.spec_rw = spec_rw; E.spec_stacks = spec_stacks;
+        E.spec_prev = spec_prev; E.spec_cur = spec_cur; E.spec_rw = spec_rw; E.spec_stacks = spec_stacks; E.spec_y1 = spec_y1;
         return E;
     }
     hipEvent_t event(size_t i) {
@@ -745,6 +808,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC2_MIN", 2, 1 << 30, &h->fc2_min_total);
     env_int("DNE_SPEC_MAX", 0, 64, &h->spec_max);
     env_int("DNE_SPEC_BANDS", 1, 12, &h->spec_bands);
+    env_int("DNE_SPEC_CONV1", 0, 1, &h->spec_conv1);
     env_int("DNE_FC_DUO", 0, 1, &h->fc_duo);
     env_int("DNE_DUO_LAG", 0, 64, &h->duo_lag);
     env_int("DNE_DUO_SOLO_BELOW", 0, 1 << 30, &h->duo_solo_below);
@@ -795,6 +859,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
         const size_t rows = (size_t)h->spec_max * SPEC_ACTIONS;
         CH(h->alloc(&h->spec_prev, rows * 128, "spec_prev")); CH(h->alloc(&h->spec_cur, rows * 128, "spec_cur"));
         CH(h->alloc(&h->spec_rw, rows * 2, "spec_rw")); CH(h->alloc(&h->spec_stacks, rows * OB_BYTES, "spec_stacks"));
+        CH(h->alloc(&h->spec_y1, rows * 7056, "spec_y1"));
         CH(hipMemset(h->spec_prev, 0, rows * 128)); CH(hipMemset(h->spec_cur, 0, rows * 128));   // RAM bytes past the live 40 stay zero
     }
     if (h->F) {
@@ -1411,15 +1476,24 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                     const int items = cnt * gsize, nact = h->cfg.n_actions, nb = h->spec_bands;
                     const FwdArgs A = h->fwd(true);
                     const bool es = h->L.kind == DNE_KIND_ES;
-                    hipLaunchKernelGGL(k_conv1_spec, dim3(items * 7 + (items * nact + 255) / 256), dim3(256), 0, sst, A, E, lst, gsize, h->y1, 7,
-                                       items * 7, items, nact);
-                    if (es) hipLaunchKernelGGL((k_conv2<true>), dim3(items * 4), dim3(256), 0, sst, A, lst, gsize, 1, 0, (const float *)h->y1, h->y2, 4, (float *)nullptr);
-                    else hipLaunchKernelGGL((k_conv2<false>), dim3(items * 4), dim3(256), 0, sst, A, lst, gsize, 1, 0, (const float *)h->y1, h->y2, 4, (float *)nullptr);
+                    const int emu_blocks = (items * nact + 255) / 256;
+                    if (st == 0 || !h->spec_conv1) {   // no conv1 candidates from the previous lock-step (a new burst = a new list)
+                        hipLaunchKernelGGL(k_conv1_spec, dim3(items * 7 + emu_blocks), dim3(256), 0, sst, A, E, lst, gsize, h->y1, 7, items * 7, items, nact);
+                        if (es) hipLaunchKernelGGL((k_conv2<true>), dim3(items * 4), dim3(256), 0, sst, A, lst, gsize, 1, 0, (const float *)h->y1, h->y2, 4, (float *)nullptr);
+                        else hipLaunchKernelGGL((k_conv2<false>), dim3(items * 4), dim3(256), 0, sst, A, lst, gsize, 1, 0, (const float *)h->y1, h->y2, 4, (float *)nullptr);
+                    } else if (es) {
+                        hipLaunchKernelGGL((k_conv2_spec<true>), dim3(items * 4 + emu_blocks), dim3(256), 0, sst, A, E, lst, gsize, (const float *)h->y1, h->y2, 4, items * 4, items, nact, (const int32_t *)h->action);
+                    } else {
+                        hipLaunchKernelGGL((k_conv2_spec<false>), dim3(items * 4 + emu_blocks), dim3(256), 0, sst, A, E, lst, gsize, (const float *)h->y1, h->y2, 4, items * 4, items, nact, (const int32_t *)h->action);
+                    }
 #define FQS(NV, BN) hipLaunchKernelGGL((k_fc_quad_spec<NV, BN>), dim3(cnt * 64 + items * nact * nb), dim3(256), 0, sst, A, E, lst, gsize, (const float *)h->y2, h->y3t, cnt * 64, nact, nb)
                     if (gsize == 2) { if (es) FQS(2, true); else FQS(2, false); }
                     else { if (es) FQS(1, true); else FQS(1, false); }
 #undef FQS
-                    if (es) hipLaunchKernelGGL((k_tail_select<true>), dim3(items), dim3(256), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
+                    if (h->spec_conv1 && st + 1 < burst) {   // the choice + conv1 of every candidate (the last lock-step of a burst has no successor to use them)
+                        if (es) hipLaunchKernelGGL((k_tail_select_conv1<true>), dim3(items + items * nact * 7), dim3(256), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action, items, nact, 7);
+                        else hipLaunchKernelGGL((k_tail_select_conv1<false>), dim3(items + items * nact * 7), dim3(256), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action, items, nact, 7);
+                    } else if (es) hipLaunchKernelGGL((k_tail_select<true>), dim3(items), dim3(256), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
                     else hipLaunchKernelGGL((k_tail_select<false>), dim3(items), dim3(256), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
                     if (h->debug_sync) {
                         hipError_t de = hipStreamSynchronize(sst);

@@ -419,7 +419,8 @@ struct Conv2Lds {
 // nsplit = 2 / 4: two / four workgroups share one member's position tiles
 template <bool HAS_BN>
 __device__ __forceinline__ void conv2_body(Conv2Lds &S, const FwdArgs &A, const Item &it, const float *__restrict__ y1,
-                                           float *__restrict__ y2, int part, int nsplit, float *__restrict__ fr) {
+                                           float *__restrict__ y2, int part, int nsplit, float *__restrict__ fr,
+                                           const float *__restrict__ y1_row = nullptr /* the member's conv1 output when it is not row it.row of y1 */) {
     constexpr int PS = C2_PS, RW = C2_RW;
     float (&a_s)[24 * C2_RW * C2_PS] = S.a_s;
     float (&wsum)[4][2][16] = S.wsum;
@@ -429,7 +430,7 @@ __device__ __forceinline__ void conv2_body(Conv2Lds &S, const FwdArgs &A, const 
     const float *eps = A.noise + A.m_off[it.member] + A.L.c2w;
     const float sc = A.m_scale[it.member];
     const float *bn = A.bn + (size_t)it.member * 608;
-    const float *src = y1 + (size_t)it.row * 7056;
+    const float *src = y1_row ? y1_row : y1 + (size_t)it.row * 7056;
     float yv[28];   // all of this thread's activation loads in flight at once (its channel is tid & 15 throughout)
 #pragma unroll
     for (int j = 0; j < 28; j++) {

@@ -152,6 +152,7 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
     {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1", "DNE_FC_RB": "2"},    # ... with 2-row batches
     {"DNE_SPEC_MAX": "0"},                                              # no speculative tail: k_tail_step + banded render (the default below steps every action under the forward pass)
     {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0"},                      # ... with k_fc_cols
+    {"DNE_SPEC_CONV1": "0"},                                            # speculative tail without the candidate conv1 (every lock-step starts at conv1)
     {"DNE_SPEC_MAX": "4"},                                              # speculative only for the last two pairs (default: the last four)
     {"DNE_SPEC_MAX": "64", "DNE_SPEC_BANDS": "2"},                      # speculative from the first lock-step on, two render workgroups per candidate
     {"DNE_FC_QUAD_MAX": "0", "DNE_TAIL_FUSED_MAX": "0"},                # k_fc_cols + k_out + separate emulator / render launches
