@@ -101,8 +101,10 @@ __global__ __launch_bounds__(64) void k_env_reset_logic(EnvArgs E, const uint32_
 
 // the episode bookkeeping of one wrapped step of member m (policies.py:399-425) from its outcome: packed RAM before / after the
 // step's last frame, reward, game over.  lds_prev / lds_cur (optional): LDS copies of the RAM rows for a renderer in the same kernel.
+struct EnvBook { int t; float ret, sign; };   // a member's step count and return accumulators, read ahead of the commit
 __device__ __forceinline__ void env_commit(const EnvArgs &E, int m, const uint32_t (&wp)[RAM_LIVE / 4], const uint32_t (&wc)[RAM_LIVE / 4],
-                                           int r, int over, int tslimit, uint8_t *lds_prev = nullptr, uint8_t *lds_cur = nullptr) {
+                                           int r, int over, int tslimit, uint8_t *lds_prev = nullptr, uint8_t *lds_cur = nullptr,
+                                           const EnvBook *book = nullptr) {
     uint8_t *gp = E.ram_prev + (size_t)m * 128, *gc = E.ram_cur + (size_t)m * 128;
 #pragma unroll
     for (int j = 0; j < RAM_LIVE / 4; j++) { ((uint32_t *)gp)[j] = wp[j]; ((uint32_t *)gc)[j] = wc[j]; }
@@ -110,7 +112,7 @@ __device__ __forceinline__ void env_commit(const EnvArgs &E, int m, const uint32
 #pragma unroll
         for (int j = 0; j < RAM_LIVE / 4; j++) { ((uint32_t *)lds_prev)[j] = wp[j]; ((uint32_t *)lds_cur)[j] = wc[j]; }
     }
-    const int t = E.len[m];
+    const int t = book ? book->t : E.len[m];
     if (E.bc_mode == 1 && t < E.bc_max_steps) {     // policies.py:410,418 RAM after every step
         uint32_t *d = (uint32_t *)(E.bc + ((size_t)m * E.bc_max_steps + t) * 128);
 #pragma unroll
@@ -121,8 +123,8 @@ __device__ __forceinline__ void env_commit(const EnvArgs &E, int m, const uint32
 #pragma unroll
         for (int j = 0; j < RAM_LIVE / 4; j++) d[j] = wc[j];
     }
-    E.ret[m] += (float)r;                                    // es.py:425 rews.sum()
-    E.sign[m] += (float)((r > 0) - (r < 0));                 // es.py:423 np.sign(rews).sum()
+    E.ret[m] = (book ? book->ret : E.ret[m]) + (float)r;                               // es.py:425 rews.sum()
+    E.sign[m] = (book ? book->sign : E.sign[m]) + (float)((r > 0) - (r < 0));          // es.py:423 np.sign(rews).sum()
     E.step_reward[m] = (float)r;
     E.len[m] = t + 1;
     E.stepped[m] = 1;
@@ -211,7 +213,21 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
     const float sc = A.m_scale[m];
     const int64_t off = A.m_off[m];
     const float *base = A.bases + (size_t)A.m_slot[m] * A.base_stride;
-    if (tid < 64) {
+    // speculative tail: thread a reads candidate a's outcome (and the member's bookkeeping) now, long before the choice is known
+    uint32_t cwp[RAM_LIVE / 4] = {}, cwc[RAM_LIVE / 4] = {};
+    int c_r = 0, c_over = 0;
+    EnvBook book = {0, 0.0f, 0.0f};
+    if (spec_pos >= 0 && tid < nact) {
+        const size_t c = (size_t)spec_pos * SPEC_ACTIONS + tid;
+#pragma unroll
+        for (int j = 0; j < RAM_LIVE / 4; j++) {
+            cwp[j] = ((const uint32_t *)(E.spec_prev + c * 128))[j];
+            cwc[j] = ((const uint32_t *)(E.spec_cur + c * 128))[j];
+        }
+        c_r = E.spec_rw[2 * c]; c_over = E.spec_rw[2 * c + 1];
+        book.t = E.len[m]; book.ret = E.ret[m]; book.sign = E.sign[m];
+    }
+    if (spec_pos < 0 && tid < 64) {
         s.ram_prev[tid] = E.ram_prev[(size_t)m * 128 + tid];
         s.ram_cur[tid] = E.ram_cur[(size_t)m * 128 + tid];
     }
@@ -259,35 +275,29 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
         lg[tid] = acc + bias;
     }
     __syncthreads();
+    if (spec_pos >= 0) {   // the emulator + renderer outcome of every action is on the table: every thread finds the policy's
+        int best = 0;      // choice, the thread that read that candidate commits it, all copy its frame stack
+        for (int a = 1; a < nact; a++)
+            if (lg[a] > lg[best]) best = a;   // tf.argmax: first maximum
+        if (tid == best) {
+            actions[m] = best;
+            env_commit(E, m, cwp, cwc, c_r, c_over, tslimit, nullptr, nullptr, &book);
+        }
+        const uint4 *src = (const uint4 *)(E.spec_stacks + ((size_t)spec_pos * SPEC_ACTIONS + best) * OB_BYTES);
+        uint4 *dst = (uint4 *)(E.stacks + (size_t)m * OB_BYTES);
+        for (int i = tid; i < OB_BYTES / 16; i += blockDim.x) dst[i] = src[i];
+        return;
+    }
     if (tid == 0) {
         int best = 0;
         for (int a = 1; a < nact; a++)
             if (lg[a] > lg[best]) best = a;   // tf.argmax: first maximum
         actions[m] = best;
-        if (spec_pos < 0) {
-            env_member_step(E, m, best, tslimit, RENDER ? s.ram_prev : nullptr, RENDER ? s.ram_cur : nullptr);
-        } else {   // k_env_spec / k_env_render_spec have worked this step out for every action: take the chosen one
-            const size_t c = (size_t)spec_pos * SPEC_ACTIONS + best;
-            uint32_t wp[RAM_LIVE / 4], wc[RAM_LIVE / 4];
-#pragma unroll
-            for (int j = 0; j < RAM_LIVE / 4; j++) {
-                wp[j] = ((const uint32_t *)(E.spec_prev + c * 128))[j];
-                wc[j] = ((const uint32_t *)(E.spec_cur + c * 128))[j];
-            }
-            env_commit(E, m, wp, wc, E.spec_rw[2 * c], E.spec_rw[2 * c + 1], tslimit);
-            lg[31] = __int_as_float(best);
-        }
+        env_member_step(E, m, best, tslimit, RENDER ? s.ram_prev : nullptr, RENDER ? s.ram_cur : nullptr);
     }
     if constexpr (RENDER) {
         __syncthreads();
         synth_observe(s, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), false);
-    }
-    if (spec_pos >= 0) {   // the candidate frame stack of the chosen action becomes the member's stack
-        __syncthreads();
-        const int best = __float_as_int(lg[31]);
-        const uint4 *src = (const uint4 *)(E.spec_stacks + ((size_t)spec_pos * SPEC_ACTIONS + best) * OB_BYTES);
-        uint4 *dst = (uint4 *)(E.stacks + (size_t)m * OB_BYTES);
-        for (int i = tid; i < OB_BYTES / 16; i += blockDim.x) dst[i] = src[i];
     }
 }
 
