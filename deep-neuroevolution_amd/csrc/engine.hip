@@ -805,6 +805,10 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipFuncSetAttribute((const void *)k_conv12<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
     CH(hipFuncSetAttribute((const void *)k_conv12<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
     CH(hipFuncSetAttribute((const void *)k_unit_order, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CH(hipFuncSetAttribute((const void *)k_out<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 32 * 4));
+    CH(hipFuncSetAttribute((const void *)k_out<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 32 * 4));
+    CH(hipFuncSetAttribute((const void *)k_out<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 32 * 4));
+    CH(hipFuncSetAttribute((const void *)k_out<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 32 * 4));
     env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
     env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
     env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
@@ -1330,7 +1334,7 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
     do {                                                                                                                     \
         if (count <= h->fc_quad_max) hipLaunchKernelGGL((k_fc_quad<NV, BN>), dim3(count * 64), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
         else hipLaunchKernelGGL((k_fc_cols<NV, BN>), dim3(count * 4), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
-        if (!out_fused) hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->y3, h->action, logits); \
+        if (!out_fused) hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), (size_t)NV * 256 * h->cfg.n_actions * sizeof(float), st, A, list, (const float *)h->y3t, h->y3, h->action, logits); \
     } while (0)
         if (gsize == 2) { if (es) FCT(2, true); else FCT(2, false); }
         else { if (es) FCT(1, true); else FCT(1, false); }
@@ -1343,7 +1347,7 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t,
                            h->duo_lag | (solo ? 256 : 0));
         if (after_stream_kernel) hipEventRecord(after_stream_kernel, st);
-        hipLaunchKernelGGL((k_out<2, true>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
+        hipLaunchKernelGGL((k_out<2, true>), dim3(count), dim3(256), (size_t)2 * 256 * h->cfg.n_actions * sizeof(float), st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
         return;
     }
     if (gsize == 2 && es && h->uniform_base && h->fc2_now && !logits) {   // two pairs per work item share the base rows

@@ -1758,7 +1758,10 @@ __global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ 
     }
     // the (256 x nact) output weights of every member are staged by the whole wave in a few load batches (the
     // chain below is latency-bound: 256 dependent fmaf per logit)
-    __shared__ float wo[NV][256 * 32];
+    extern __shared__ float wo_dyn[];   // [NV][256 * nact]: sized by the launch (36 KB for 18 actions, so that the kernel fits next to the convolutions' LDS)
+    float *wo[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) wo[v] = wo_dyn + (size_t)v * 256 * nact;
 #pragma unroll
     for (int v = 0; v < NV; v++) {
         const int m = g * NV + v;
