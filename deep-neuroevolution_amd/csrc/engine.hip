@@ -490,6 +490,7 @@ struct dne_handle {
     bool fc2_now = false;            // decided per burst by eval_core
     int duo_solo_below = 1500;       // DNE_DUO_SOLO_BELOW: with fewer active groups (all windows) every wave takes one unit instead of two (sparse table: little to share, and twice the waves)
     bool duo_solo_now = false;       // decided per burst by eval_core
+    int fc_duo_ga = 0;               // DNE_FC_DUO_GA: the table-ordered fc for GA evaluations too (single members, one base vector per parent); measured slower, off
     int duo_lag = 0;                 // DNE_DUO_LAG: extra row batches by which the second unit of a duo trails the first
     int fc_duo = 1, fc_duo_min = 800;   // DNE_FC_DUO / DNE_FC_DUO_MIN: table-ordered fc (k_unit_order + k_fc_duo + k_out) from this many active groups
     bool duo_now = false;            // decided per burst by eval_core (the unit order of each window is rebuilt then)
@@ -826,6 +827,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_DUO", 0, 1, &h->fc_duo);
     env_int("DNE_DUO_LAG", 0, 64, &h->duo_lag);
     env_int("DNE_DUO_SOLO_BELOW", 0, 1 << 30, &h->duo_solo_below);
+    env_int("DNE_FC_DUO_GA", 0, 1, &h->fc_duo_ga);
     env_int("DNE_FC_DUO_MIN", 2, 1 << 30, &h->fc_duo_min);
     env_int("DNE_RENDER_BANDS", 1, 12, &h->render_bands);
     env_int("DNE_FC_CHAIN_MIN", 1, 1 << 30, &h->fc_chain_min);
@@ -1341,13 +1343,15 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
 #undef FCT
         return;
     }
-    if (gsize == 2 && es && h->duo_now && !logits && order) {   // table-ordered units: adjacent (pair, k-slice) units share their noise rows
+    if (h->duo_now && !logits && order && (gsize == 2 ? es : !es)) {   // table-ordered units: adjacent (group, k-slice) units share their noise rows
         const bool solo = h->duo_solo_now;
         const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 3) / 4, blocks = std::min(items, h->fc_grid);
-        hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t,
-                           h->duo_lag | (solo ? 256 : 0));
+        const size_t out_lds = (size_t)gsize * 256 * h->cfg.n_actions * sizeof(float);
+        if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0));
+        else hipLaunchKernelGGL((k_fc_duo<1, false>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0));
         if (after_stream_kernel) hipEventRecord(after_stream_kernel, st);
-        hipLaunchKernelGGL((k_out<2, true>), dim3(count), dim3(256), (size_t)2 * 256 * h->cfg.n_actions * sizeof(float), st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
+        if (es) hipLaunchKernelGGL((k_out<2, true>), dim3(count), dim3(256), out_lds, st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
+        else hipLaunchKernelGGL((k_out<1, false>), dim3(count), dim3(256), out_lds, st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
         return;
     }
     if (gsize == 2 && es && h->uniform_base && h->fc2_now && !logits) {   // two pairs per work item share the base rows
@@ -1454,12 +1458,12 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     size_t fc_ring_pos = 0;
     // the profiled ("full") launches are one kernel: k_fc2 when this evaluation starts wide enough to use it, else k_fc
     const bool fc2_eval = h->fc_pairs == 2 && gsize == 2 && h->L.kind == DNE_KIND_ES && h->uniform_base && groups >= h->fc2_min_total;
-    const bool duo_eval = h->fc_duo && gsize == 2 && h->L.kind == DNE_KIND_ES && groups >= h->fc_duo_min;
+    const bool duo_eval = h->fc_duo && (h->L.kind == DNE_KIND_ES ? gsize == 2 : (gsize == 1 && h->fc_duo_ga)) && groups >= h->fc_duo_min;
     while (total > 0 && t < tslimit) {
         const int burst = std::min(16, tslimit - t);
         const int nsub = pick_nsub(total);
         h->fc2_now = h->fc_pairs == 2 && total >= h->fc2_min_total;
-        h->duo_now = h->fc_duo && gsize == 2 && h->L.kind == DNE_KIND_ES && total >= h->fc_duo_min &&
+        h->duo_now = h->fc_duo && (h->L.kind == DNE_KIND_ES ? gsize == 2 : (gsize == 1 && h->fc_duo_ga)) && total >= h->fc_duo_min &&
                      (size_t)4 * ((total + nsub - 1) / nsub) * sizeof(long long) <= 160 * 1024;   // k_unit_order ranks a window's keys in LDS
         h->duo_solo_now = total < h->duo_solo_below;
         if (h->duo_now)   // the list only changes at a compaction: rank each window's units by table address once per burst

@@ -1113,6 +1113,11 @@ __device__ __forceinline__ void gload4_after(f32x4 &dst, unsigned voff, const fl
     asm volatile("global_load_dwordx4 %[d], %[vo], %[sb] offset:%[of]"
                  : [d] "+v"(dst), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : [vo] "v"(voff), [sb] "s"(sbase), [of] "n"(OFF));
 }
+template <int OFF>
+__device__ __forceinline__ void gload4_after(f32x4 &dst, unsigned voff, const float *sbase, f32x2 &a0, f32x2 &a1) {
+    asm volatile("global_load_dwordx4 %[d], %[vo], %[sb] offset:%[of]"
+                 : [d] "+v"(dst), "+v"(a0), "+v"(a1) : [vo] "v"(voff), [sb] "s"(sbase), [of] "n"(OFF));
+}
 template <int N>
 __device__ __forceinline__ void wait_rows(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d) {   // at most N loads still in flight afterwards
     asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : [n] "n"(N));
@@ -1213,8 +1218,9 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
         for (int i = 0; i < W; i++) eA[i] = tA[i] = eB[i] = tB[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         auto refill = [&](Side &Z, f32x4 &e, f32x4 &t, auto ii) {   // row I of the side's next block
             constexpr int I = decltype(ii)::value;
-            static_assert(NV == 2, "accumulator operands");
-            gload4_after<(I % 4) * 1024>(e, voff, Z.enext + (I / 4) * 1024, Z.acc[0][0], Z.acc[0][1], Z.acc[1][0], Z.acc[1][1]);
+            static_assert(NV == 1 || NV == 2, "accumulator operands");
+            if constexpr (NV == 2) gload4_after<(I % 4) * 1024>(e, voff, Z.enext + (I / 4) * 1024, Z.acc[0][0], Z.acc[0][1], Z.acc[1][0], Z.acc[1][1]);
+            else gload4_after<(I % 4) * 1024>(e, voff, Z.enext + (I / 4) * 1024, Z.acc[0][0], Z.acc[0][1]);
             gload4<(I % 4) * 1024>(t, voff, Z.tnext + (I / 4) * 1024);
         };
         auto next_block = [&](Side &Z) {

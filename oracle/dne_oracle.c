@@ -35,6 +35,18 @@ void orc_layout_make(int kind, int nact, orc_layout *L) {
         L->bn3g = o; o += 256;
         L->ow = o; o += 256 * nact;
         L->ob = o; o += nact;
+    } else if (kind == ORC_KIND_GA_LARGE) { /* models/dqn.py:39-47: variables in creation order (models/base.py:35-41, 157-167) */
+        L->c1w = o; o += 8 * 8 * 4 * 32;
+        L->c1b = o; o += 32;
+        L->c2w = o; o += 4 * 4 * 32 * 64;
+        L->c2b = o; o += 64;
+        L->c3w = o; o += 3 * 3 * 64 * 64;
+        L->c3b = o; o += 64;
+        L->fcw = o; o += 7744 * 512;
+        L->fcb = o; o += 512;
+        L->ow = o; o += 512 * nact;
+        L->ob = o; o += nact;
+        L->bn1b = L->bn1g = L->bn2b = L->bn2g = L->bn3b = L->bn3g = -1;
     } else { /* policies.py:449-459 via tf_util.py:133-162 */
         L->c1w = o; o += 4096;
         L->c1b = o; o += 16;
@@ -197,9 +209,80 @@ void orc_forward_debug(const orc_layout *L, const float *th, const float *bn, co
     out_raw(th + L->ow, th + L->ob, a3, L->nact, logits);
 }
 
+/* ---- LargeModel (GPU tree).  models/base.py:50-78: extract_image_patches (depth order kh, kw, ci; SAME padding: the
+ * pad before is floor(total / 2)) x weights reshaped [k*k*cin, cout], + bias; models/dqn.py:39-47 puts relu on every layer
+ * but the last.  One fmaf chain per output in (kh, kw, ci) order, taps outside the image skipped (they would add x = 0). */
+static void conv_same(const float *w, const float *b, const float *in, int hin, int cin, int k, int stride, int hout, int cout,
+                      float *out) {
+    int total = (hout - 1) * stride + k - hin;
+    int pad = total > 0 ? total / 2 : 0;
+    for (int oy = 0; oy < hout; oy++)
+        for (int ox = 0; ox < hout; ox++) {
+            float acc[64];
+            for (int c = 0; c < cout; c++) acc[c] = 0.0f;
+            for (int kh = 0; kh < k; kh++) {
+                int iy = oy * stride - pad + kh;
+                if (iy < 0 || iy >= hin) continue;
+                for (int kw = 0; kw < k; kw++) {
+                    int ix = ox * stride - pad + kw;
+                    if (ix < 0 || ix >= hin) continue;
+                    for (int ci = 0; ci < cin; ci++) {
+                        float x = in[(iy * hin + ix) * cin + ci];
+                        const float *wk = w + ((size_t)(kh * k + kw) * cin + ci) * cout;
+                        for (int co = 0; co < cout; co++) acc[co] = fmaf(x, wk[co], acc[co]);
+                    }
+                }
+            }
+            float *o = out + (size_t)(oy * hout + ox) * cout;
+            for (int co = 0; co < cout; co++) o[co] = acc[co] + b[co];
+        }
+}
+
+void orc_forward_large_debug(const orc_layout *L, const float *th, const uint8_t *ob, float *y1, float *y2, float *y3, float *y4,
+                             float *logits) {
+    static __thread float x0[84 * 84 * 4], a1[21 * 21 * 32], a2[11 * 11 * 64], a3[11 * 11 * 64], a4[512];
+    static __thread float part[4][512];
+    ob_lut_init();
+    for (int i = 0; i < 84 * 84 * 4; i++) x0[i] = OB_LUT[ob[i]];
+    conv_same(th + L->c1w, th + L->c1b, x0, 84, 4, 8, 4, 21, 32, y1);
+    for (int i = 0; i < 21 * 21 * 32; i++) a1[i] = y1[i] > 0.0f ? y1[i] : 0.0f;
+    conv_same(th + L->c2w, th + L->c2b, a1, 21, 32, 4, 2, 11, 64, y2);
+    for (int i = 0; i < 11 * 11 * 64; i++) a2[i] = y2[i] > 0.0f ? y2[i] : 0.0f;
+    conv_same(th + L->c3w, th + L->c3b, a2, 11, 64, 3, 1, 11, 64, y3);
+    for (int i = 0; i < 11 * 11 * 64; i++) a3[i] = y3[i] > 0.0f ? y3[i] : 0.0f;
+    const float *w = th + L->fcw;
+    for (int s = 0; s < 4; s++) { /* 4 k-slices of 1936 rows, ((s0+s1)+(s2+s3)) + bias */
+        float *acc = part[s];
+        for (int j = 0; j < 512; j++) acc[j] = 0.0f;
+        for (int kk = s * 1936; kk < (s + 1) * 1936; kk++) {
+            float x = a3[kk];
+            const float *wk = w + (size_t)kk * 512;
+            for (int j = 0; j < 512; j++) acc[j] = fmaf(x, wk[j], acc[j]);
+        }
+    }
+    for (int j = 0; j < 512; j++) {
+        float s01 = part[0][j] + part[1][j];
+        float s23 = part[2][j] + part[3][j];
+        float t = s01 + s23;
+        y4[j] = t + th[L->fcb + j];
+        a4[j] = y4[j] > 0.0f ? y4[j] : 0.0f;
+    }
+    for (int a = 0; a < L->nact; a++) {
+        float acc = 0.0f;
+        for (int kk = 0; kk < 512; kk++) acc = fmaf(a4[kk], th[L->ow + kk * L->nact + a], acc);
+        logits[a] = acc + th[L->ob + a];
+    }
+}
+
 int orc_act(const orc_layout *L, const float *th, const float *bn, const uint8_t *ob, float *logits) {
-    static __thread float y1[7056], y2[3872], y3[256];
+    static __thread float y1[21 * 21 * 32], y2[11 * 11 * 64], y3[11 * 11 * 64];
     float lg[32];
+    if (L->kind == ORC_KIND_GA_LARGE) {
+        static __thread float y4[512];
+        orc_forward_large_debug(L, th, ob, y1, y2, y3, y4, lg);
+        if (logits) memcpy(logits, lg, sizeof(float) * L->nact);
+        return argmax_first(lg, L->nact);
+    }
     orc_forward_debug(L, th, bn, ob, y1, y2, y3, lg);
     if (logits) memcpy(logits, lg, sizeof(float) * L->nact);
     return argmax_first(lg, L->nact);
@@ -742,7 +825,7 @@ void orc_rollout(const orc_layout *L, const float *theta, const uint8_t *ref, in
         t++;
         if (done) break;
     }
-    if (bc && L->kind == ORC_KIND_GA) memcpy(bc, e.ram_cur, ORC_RAM); /* policies.py:510 */
+    if (bc && L->kind != ORC_KIND_ES) memcpy(bc, e.ram_cur, ORC_RAM); /* policies.py:510 */
     *ret = r; *signret = s; *len = t;
 }
 

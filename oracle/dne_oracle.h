@@ -32,6 +32,7 @@ extern "C" {
 
 #define ORC_KIND_ES 0 /* ESAtariPolicy  policies.py:305-429 */
 #define ORC_KIND_GA 1 /* GAAtariPolicy  policies.py:433-513 */
+#define ORC_KIND_GA_LARGE 2 /* LargeModel of the GPU tree: gpu_implementation/neuroevolution/models/dqn.py:39-47 over models/base.py:50-95 */
 
 #define ORC_OB_BYTES (84 * 84 * 4)
 #define ORC_RAM 128
@@ -46,6 +47,7 @@ typedef struct {
     int c2w, c2b, bn2b, bn2g;
     int fcw, fcb, bn3b, bn3g;
     int ow, ob;
+    int c3w, c3b; /* LargeModel only (else 0) */
 } orc_layout;
 
 void orc_layout_make(int kind, int nact, orc_layout *L);
@@ -59,6 +61,10 @@ void orc_es_ref_pass(const orc_layout *L, const float *theta, const uint8_t *ref
 void orc_es_ref_pass_moments(const orc_layout *L, const float *theta, const uint8_t *ref, int nref, float *bn, float *mom /*608 or NULL*/);
 /* A3/A4  single-observation act: returns argmax action; logits (nact floats) optional */
 int orc_act(const orc_layout *L, const float *theta, const float *bn, const uint8_t *ob, float *logits);
+/* LargeModel: conv 32 8x8/4, conv 64 4x4/2, conv 64 3x3/1 (all SAME, + bias, relu), fc 512, out.  Same numerics contract; the fc
+ * is 4 k-slices of 1936 rows.  Intermediates are raw (pre-relu, bias added): y1[21*21*32], y2[11*11*64], y3[11*11*64], y4[512]. */
+void orc_forward_large_debug(const orc_layout *L, const float *theta, const uint8_t *ob, float *y1, float *y2, float *y3, float *y4,
+                             float *logits);
 /* intermediate activations for kernel-level parity tests (raw = pre-BN/pre-ReLU) */
 void orc_forward_debug(const orc_layout *L, const float *theta, const float *bn, const uint8_t *ob,
                        float *y1_raw /*7056*/, float *y2_raw /*3872*/, float *y3_raw /*256*/, float *logits);

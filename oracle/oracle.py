@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libdne_oracle.so")
 
-KIND_ES, KIND_GA = 0, 1
+KIND_ES, KIND_GA, KIND_GA_LARGE = 0, 1, 2
 OB_SHAPE = (84, 84, 4)
 OB_BYTES = 84 * 84 * 4
 RAM = 128
@@ -32,7 +32,7 @@ def build(force=False):
 class Layout(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "kind", "nact", "P", "c1w", "c1b", "bn1b", "bn1g", "c2w", "c2b", "bn2b", "bn2g",
-        "fcw", "fcb", "bn3b", "bn3g", "ow", "ob")]
+        "fcw", "fcb", "bn3b", "bn3g", "ow", "ob", "c3w", "c3b")]
 
 
 class WEnv(C.Structure):
@@ -118,6 +118,17 @@ def forward_debug(L, theta, bn, ob):
                             _p(ob, C.c_uint8), _p(y1, C.c_float), _p(y2, C.c_float), _p(y3, C.c_float),
                             _p(lg, C.c_float))
     return y1, y2, y3, lg
+
+
+def forward_large_debug(L, theta, ob):
+    """LargeModel of the GPU tree (models/dqn.py:39-47): raw y1 [21,21,32], y2 / y3 [11,11,64], y4 [512], logits"""
+    theta = _f32(theta)
+    ob = np.ascontiguousarray(ob, dtype=np.uint8)
+    y1 = np.empty(21 * 21 * 32, np.float32); y2 = np.empty(11 * 11 * 64, np.float32); y3 = np.empty(11 * 11 * 64, np.float32)
+    y4 = np.empty(512, np.float32); lg = np.empty(L.nact, np.float32)
+    lib().orc_forward_large_debug(C.byref(L), _p(theta, C.c_float), _p(ob, C.c_uint8), _p(y1, C.c_float), _p(y2, C.c_float),
+                                  _p(y3, C.c_float), _p(y4, C.c_float), _p(lg, C.c_float))
+    return y1, y2, y3, y4, lg
 
 
 # ---- SynthAtari raw env -----------------------------------------------------

@@ -305,3 +305,39 @@ def test_reference_batch_sizes(nref, members, oracle, small_noise):
             assert np.array_equal(bn[i], obn) and np.array_equal(mom[i], omom), (nref, i)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("knobs", [
+    {"DNE_FC_DUO_GA": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1"},                              # table-ordered fc for single members, one unit per wave
+    {"DNE_FC_DUO_GA": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0"},   # ... two units per wave
+    {"DNE_SPEC_MAX": "0"},                                                                            # GA tail without speculation
+    {"DNE_SPEC_MAX": "64"},                                                                           # ... speculative from the first lock-step
+])
+def test_ga_step_kernel_variants_are_bit_exact(knobs, oracle, small_noise, monkeypatch):
+    """the GA evaluation (single members, one base vector per parent, final-RAM behaviour characterisation) through the kernel
+    variants the ES test above cannot reach"""
+    from dne_hip import _lib
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    O = oracle
+    e = _lib.Engine(_lib.KIND_GA, NACT, max_members=16, record_bc=True)
+    try:
+        e.noise_upload(small_noise)
+        L = O.layout(O.KIND_GA, NACT)
+        sigma, tslimit = 0.005, 70
+        rs = np.random.RandomState(11)
+        hi = small_noise.size - L.P + 1
+        gen0 = [[int(rs.randint(hi))] for _ in range(7)]
+        seeds = rs.randint(0, 2 ** 31, 7).astype(np.uint32)
+        ret, sg, ln, bc = e.ga_eval(gen0, sigma, tslimit, seeds, want_bc=True)
+        for i, chain in enumerate(gen0):
+            r, s, l, obc = O.rollout(L, O.ga_rebuild(L, small_noise, chain, sigma), None, seeds[i], tslimit, want_bc=True)
+            assert (ret[i], sg[i], ln[i]) == (r, s, l) and np.array_equal(bc[i], obc), (knobs, i)
+        parents = [gen0[2], gen0[5]]
+        gen1 = [parents[i % 2] + [int(rs.randint(hi))] for i in range(7)]
+        seeds = rs.randint(0, 2 ** 31, 7).astype(np.uint32)
+        ret, sg, ln = e.ga_eval(gen1, sigma, tslimit, seeds)
+        for i, chain in enumerate(gen1):
+            assert (ret[i], sg[i], ln[i]) == O.rollout(L, O.ga_rebuild(L, small_noise, chain, sigma), None, seeds[i], tslimit)[:3], (knobs, i)
+    finally:
+        e.close()

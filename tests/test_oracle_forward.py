@@ -112,3 +112,40 @@ def test_antithetic_symmetry(oracle, small_noise):
     assert np.abs((p + n) / 2 - th).max() < 1e-5
     v = np.float32(0.02) * small_noise[idx:idx + L.P]
     assert np.array_equal(p, th + v) and np.array_equal(n, th - v)
+
+
+def test_large_model_forward_vs_torch(oracle):
+    """LargeModel of the GPU tree (gpu_implementation/neuroevolution/models/dqn.py:39-47 over models/base.py:50-95: SAME
+    patches x reshaped weights + bias, relu): conv 32 8x8/4, conv 64 4x4/2, conv 64 3x3/1, fc 512, out.  TensorFlow is absent
+    ("parity unpinned"), so the oracle's restatement is cross-checked against torch like the small networks above."""
+    import torch
+    import torch.nn.functional as F
+    O = oracle
+    L = O.layout(O.KIND_GA_LARGE, 18)
+    assert L.P == 8 * 8 * 4 * 32 + 32 + 4 * 4 * 32 * 64 + 64 + 3 * 3 * 64 * 64 + 64 + 7744 * 512 + 512 + 512 * 18 + 18 == 4052658
+    rs = np.random.RandomState(3)
+    th = (rs.randn(L.P) * 0.03).astype(np.float32)
+    t = torch.from_numpy(th)
+
+    def tt(off, shape):
+        return t[off:off + int(np.prod(shape))].reshape(shape)
+    w1 = tt(L.c1w, (8, 8, 4, 32)).permute(3, 2, 0, 1); b1 = tt(L.c1b, (32,))
+    w2 = tt(L.c2w, (4, 4, 32, 64)).permute(3, 2, 0, 1); b2 = tt(L.c2b, (64,))
+    w3 = tt(L.c3w, (3, 3, 64, 64)).permute(3, 2, 0, 1); b3 = tt(L.c3b, (64,))
+    wf = tt(L.fcw, (7744, 512)); bf = tt(L.fcb, (512,)); wo = tt(L.ow, (512, 18)); bo = tt(L.ob, (18,))
+    obs = rs.randint(0, 256, (3, 84, 84, 4)).astype(np.uint8)
+    x = torch.from_numpy(obs.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2)
+    y1 = F.conv2d(F.pad(x, (2, 2, 2, 2)), w1, b1, stride=4)                      # SAME: total 4 -> 2 / 2
+    y2 = F.conv2d(F.pad(torch.relu(y1), (1, 2, 1, 2)), w2, b2, stride=2)         # total 3 -> 1 before, 2 after
+    y3 = F.conv2d(F.pad(torch.relu(y2), (1, 1, 1, 1)), w3, b3, stride=1)         # total 2 -> 1 / 1
+    y4 = torch.relu(y3).permute(0, 2, 3, 1).reshape(3, 7744) @ wf + bf            # NHWC flatten (models/base.py:97-98)
+    lg = torch.relu(y4) @ wo + bo
+    for i in range(3):
+        o1, o2, o3, o4, ol = O.forward_large_debug(L, th, obs[i])
+        assert np.allclose(o1.reshape(21, 21, 32), y1[i].permute(1, 2, 0).numpy(), atol=1e-4, rtol=1e-4)
+        assert np.allclose(o2.reshape(11, 11, 64), y2[i].permute(1, 2, 0).numpy(), atol=2e-4, rtol=1e-4)
+        assert np.allclose(o3.reshape(11, 11, 64), y3[i].permute(1, 2, 0).numpy(), atol=5e-4, rtol=1e-4)
+        assert np.allclose(o4, y4[i].numpy(), atol=2e-3, rtol=1e-4)
+        assert np.allclose(ol, lg[i].numpy(), atol=2e-3, rtol=1e-4)
+        a, lg2 = O.act(L, th, None, obs[i])
+        assert a == int(np.argmax(ol)) and np.array_equal(lg2, ol)
