@@ -21,6 +21,7 @@
 #include "../../include/dne_hip.h"
 #include "env_synth.h"
 #include "forward.h"
+#include "forward_large.h"
 #include "reduce.h"
 
 using namespace dne;
@@ -524,6 +525,7 @@ struct dne_handle {
     int32_t *launch_units = nullptr; size_t launch_units_cap = 0;
     uint32_t *seeds = nullptr;
     float *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *y3t = nullptr;   // step mode: one row per member (y3t: 4 k-slice partials)
+    bool large = false;              // DNE_KIND_GA_LARGE: y1 [441][32], y2 / y3 [121][64] (conv3 output), y3t = the 512 fc outputs
     float *y1r[2] = {nullptr, nullptr}, *y2r[2] = {nullptr, nullptr}, *y3pr[2] = {nullptr, nullptr};   // reference pass scratch, two ways
     float *fr1[2] = {nullptr, nullptr}, *fr2[2] = {nullptr, nullptr};   // per-frame batch-norm moments of conv1 / conv2 ([rows][2][C])
     hipEvent_t ev_ref[2] = {nullptr, nullptr};
@@ -659,6 +661,11 @@ static void make_layout(int kind, int nact, Layout *L) {
         L->c2w = take(8192); L->c2b = take(32); L->bn2b = take(32); L->bn2g = take(32);
         L->fcw = take(3872 * 256); L->fcb = take(256); L->bn3b = take(256); L->bn3g = take(256);
         L->ow = take(256 * nact); L->ob = take(nact);
+    } else if (kind == DNE_KIND_GA_LARGE) {   // models/dqn.py:39-47: variables in creation order (models/base.py:35-41)
+        L->c1w = take(8 * 8 * 4 * 32); L->c1b = take(32); L->c2w = take(4 * 4 * 32 * 64); L->c2b = take(64);
+        L->c3w = take(3 * 3 * 64 * 64); L->c3b = take(64);
+        L->fcw = take(7744 * 512); L->fcb = take(512); L->ow = take(512 * nact); L->ob = take(nact);
+        L->bn1b = L->bn1g = L->bn2b = L->bn2g = L->bn3b = L->bn3g = -1;
     } else {                     // policies.py:449-459 via tf_util.py:133-162
         L->c1w = take(4096); L->c1b = take(16); L->c2w = take(8192); L->c2b = take(32);
         L->fcw = take(3872 * 256); L->fcb = take(256); L->ow = take(256 * nact); L->ob = take(nact);
@@ -775,7 +782,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
         return -1;
     }
     if (cfg->max_members <= 0 || cfg->n_actions <= 1 || cfg->n_actions > 32 ||
-        (cfg->policy_kind != DNE_KIND_ES && cfg->policy_kind != DNE_KIND_GA)) {
+        (cfg->policy_kind != DNE_KIND_ES && cfg->policy_kind != DNE_KIND_GA && cfg->policy_kind != DNE_KIND_GA_LARGE)) {
         g_create_error = "dne_create: bad config";
         return -1;
     }
@@ -806,6 +813,9 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipFuncSetAttribute((const void *)k_conv12<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
     CH(hipFuncSetAttribute((const void *)k_conv12<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
     CH(hipFuncSetAttribute((const void *)k_unit_order, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CH(hipFuncSetAttribute((const void *)k_lconv_mfma<32, 64, 4, 2, 21, 11, 1, 34>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<32, 4, 2, 11, 34>()));
+    CH(hipFuncSetAttribute((const void *)k_lconv_mfma<64, 64, 3, 1, 11, 11, 1, 68>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<64, 3, 1, 11, 68>()));
+    CH(hipFuncSetAttribute((const void *)k_lout, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 32 * 4));
     CH(hipFuncSetAttribute((const void *)k_out<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 32 * 4));
     CH(hipFuncSetAttribute((const void *)k_out<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 32 * 4));
     CH(hipFuncSetAttribute((const void *)k_out<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 32 * 4));
@@ -868,7 +878,9 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(h->alloc(&h->logits, M * cfg->n_actions, "logits"));
     CH(h->alloc(&h->len, M, "len")); CH(h->alloc(&h->done, M, "done")); CH(h->alloc(&h->action, M, "action")); CH(h->alloc(&h->seeds, M, "seeds")); CH(h->alloc(&h->stepped, M, "stepped"));
     CH(hipMemset(h->done, 0, M * sizeof(int32_t))); CH(hipMemset(h->len, 0, M * sizeof(int32_t)));
-    CH(h->alloc(&h->y1, M * 7056, "y1")); CH(h->alloc(&h->y2, M * 3872, "y2")); CH(h->alloc(&h->y3, M * 256, "y3")); CH(h->alloc(&h->y3t, M * 4 * 256, "y3t"));
+    h->large = cfg->policy_kind == DNE_KIND_GA_LARGE;
+    if (h->large) { CH(h->alloc(&h->y1, M * 14112, "y1")); CH(h->alloc(&h->y2, M * 7744, "y2")); CH(h->alloc(&h->y3, M * 7744, "y3")); CH(h->alloc(&h->y3t, M * 512, "y3t")); }
+    else { CH(h->alloc(&h->y1, M * 7056, "y1")); CH(h->alloc(&h->y2, M * 3872, "y2")); CH(h->alloc(&h->y3, M * 256, "y3")); CH(h->alloc(&h->y3t, M * 4 * 256, "y3t")); }
     CH(h->alloc(&h->unit_order, M * 4, "unit_order"));
     if (cfg->n_actions > SPEC_ACTIONS - 2) h->spec_max = 0;
     if (h->spec_max > 0) {   // candidate outcomes of the speculative tail: [list position][action]
@@ -1304,6 +1316,13 @@ extern "C" int dne_get_bn_moments(dne_handle *h, int n, float *out) {
 static void launch_forward(dne_handle *h, const int *list, int count, int gsize, bool use_done, hipStream_t st = nullptr) {
     if (!st) st = h->stream;
     const FwdArgs A = h->fwd(use_done);
+    if (h->large) {   // LargeModel: three matrix-core convolutions (forward_large.h); members are single (GA)
+        constexpr size_t l2 = lconv_mfma_lds_bytes<32, 4, 2, 11, 34>(), l3 = lconv_mfma_lds_bytes<64, 3, 1, 11, 68>();
+        hipLaunchKernelGGL(k_lconv1, dim3(count * 2), dim3(256), 0, st, A, list, (const uint8_t *)h->stacks, h->y1);
+        hipLaunchKernelGGL((k_lconv_mfma<32, 64, 4, 2, 21, 11, 1, 34>), dim3(count * 4), dim3(256), l2, st, A, list, A.L.c2w, A.L.c2b, (const float *)h->y1, h->y2);
+        hipLaunchKernelGGL((k_lconv_mfma<64, 64, 3, 1, 11, 11, 1, 68>), dim3(count * 4), dim3(256), l3, st, A, list, A.L.c3w, A.L.c3b, (const float *)h->y2, h->y3);
+        return;
+    }
     const bool es = h->L.kind == DNE_KIND_ES;
     const int items = count * gsize;
     // few members left: several workgroups per member (conv1: 28 position tiles over 4 or 7 workgroups; conv2: 8 over 2 or 4)
@@ -1331,6 +1350,11 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
     // the next compaction, and streaming their weights would be wasted bandwidth
     const FwdArgs A = h->fwd(logits == nullptr);
     const bool es = h->L.kind == DNE_KIND_ES;
+    if (h->large) {   // LargeModel: streamed 7744 x 512 fc (two 256-column halves per member), then relu + output layer + argmax
+        hipLaunchKernelGGL(k_lfc, dim3(std::min(2 * count, 2 * h->fc_grid)), dim3(256), 0, st, A, list, 2 * count, (const float *)h->y3, h->y3t);
+        hipLaunchKernelGGL(k_lout, dim3(count), dim3(256), (size_t)512 * h->cfg.n_actions * sizeof(float), st, A, list, (const float *)h->y3t, h->action, logits);
+        return;
+    }
     if (count <= h->fc_tail_max) {   // latency-bound regime: 4 workgroups per group + a separate output-layer kernel
 #define FCT(NV, BN)                                                                                                          \
     do {                                                                                                                     \
@@ -1384,10 +1408,24 @@ extern "C" int dne_act(dne_handle *h, int n, int32_t *actions, float *logits) {
 extern "C" int dne_debug_activations(dne_handle *h, int member, float *y1, float *y2, float *y3) {
     DeviceGuard dg(h);
     if (member < 0 || member >= h->M) return h->fail("bad member");
+    if (h->large) return h->fail("dne_debug_activations: LargeModel engines use dne_debug_activations_large");
     HCHECK(h, hipStreamSynchronize(h->stream));
     if (y1) HCHECK(h, hipMemcpy(y1, h->y1 + (size_t)member * 7056, 7056 * sizeof(float), hipMemcpyDeviceToHost));
     if (y2) HCHECK(h, hipMemcpy(y2, h->y2 + (size_t)member * 3872, 3872 * sizeof(float), hipMemcpyDeviceToHost));
     if (y3) HCHECK(h, hipMemcpy(y3, h->y3 + (size_t)member * 256, 256 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// LargeModel: raw (bias added, pre-relu) outputs of conv1 [441][32], conv2 / conv3 [121][64] and the fc [512] after dne_act
+extern "C" int dne_debug_activations_large(dne_handle *h, int member, float *y1, float *y2, float *y3, float *y4) {
+    DeviceGuard dg(h);
+    if (member < 0 || member >= h->M) return h->fail("bad member");
+    if (!h->large) return h->fail("dne_debug_activations_large needs a DNE_KIND_GA_LARGE engine");
+    HCHECK(h, hipStreamSynchronize(h->stream));
+    if (y1) HCHECK(h, hipMemcpy(y1, h->y1 + (size_t)member * 14112, 14112 * sizeof(float), hipMemcpyDeviceToHost));
+    if (y2) HCHECK(h, hipMemcpy(y2, h->y2 + (size_t)member * 7744, 7744 * sizeof(float), hipMemcpyDeviceToHost));
+    if (y3) HCHECK(h, hipMemcpy(y3, h->y3 + (size_t)member * 7744, 7744 * sizeof(float), hipMemcpyDeviceToHost));
+    if (y4) HCHECK(h, hipMemcpy(y4, h->y3t + (size_t)member * 512, 512 * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1458,12 +1496,12 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     size_t fc_ring_pos = 0;
     // the profiled ("full") launches are one kernel: k_fc2 when this evaluation starts wide enough to use it, else k_fc
     const bool fc2_eval = h->fc_pairs == 2 && gsize == 2 && h->L.kind == DNE_KIND_ES && h->uniform_base && groups >= h->fc2_min_total;
-    const bool duo_eval = h->fc_duo && (h->L.kind == DNE_KIND_ES ? gsize == 2 : (gsize == 1 && h->fc_duo_ga)) && groups >= h->fc_duo_min;
+    const bool duo_eval = !h->large && h->fc_duo && (h->L.kind == DNE_KIND_ES ? gsize == 2 : (gsize == 1 && h->fc_duo_ga)) && groups >= h->fc_duo_min;
     while (total > 0 && t < tslimit) {
         const int burst = std::min(16, tslimit - t);
         const int nsub = pick_nsub(total);
         h->fc2_now = h->fc_pairs == 2 && total >= h->fc2_min_total;
-        h->duo_now = h->fc_duo && (h->L.kind == DNE_KIND_ES ? gsize == 2 : (gsize == 1 && h->fc_duo_ga)) && total >= h->fc_duo_min &&
+        h->duo_now = !h->large && h->fc_duo && (h->L.kind == DNE_KIND_ES ? gsize == 2 : (gsize == 1 && h->fc_duo_ga)) && total >= h->fc_duo_min &&
                      (size_t)4 * ((total + nsub - 1) / nsub) * sizeof(long long) <= 160 * 1024;   // k_unit_order ranks a window's keys in LDS
         h->duo_solo_now = total < h->duo_solo_below;
         if (h->duo_now)   // the list only changes at a compaction: rank each window's units by table address once per burst
@@ -1486,7 +1524,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 const bool pe = prof && (duo_eval ? duo_win : fc2_eval ? h->fc2_now : cnt > h->fc_tail_max);
                 if (pe) { e[0] = ne++; HCHECK(h, hipEventRecord(h->event(e[0]), sst)); }
                 // fused policy head + emulator (+ render): while all windows together still fit the chip one workgroup per member
-                const bool tail = cnt <= h->fc_tail_max && total <= h->tail_fused_max;
+                const bool tail = !h->large && cnt <= h->fc_tail_max && total <= h->tail_fused_max;   // (the fused tail kernels are the small networks')
                 // speculative tail: the emulator + renderer outcome of every action, inside the launches of this step's forward pass
                 const bool spec = tail && nsub == 1 && h->spec_max > 0 && cnt * gsize <= h->spec_max && cnt <= h->fc_quad_max &&
                                   cnt * gsize <= h->conv_split_max && !h->dbg_skip;
@@ -1696,7 +1734,7 @@ static int build_chain(dne_handle *h, int slot, const int64_t *seeds, const floa
 // dqn.py:24-27, biases 0); with it set, genomes given with per-seed powers start as noise[idx0] * scale_by
 extern "C" int dne_ga_set_init_scale(dne_handle *h, const float *scale_by, size_t n) {
     DeviceGuard dg(h);
-    if (h->L.kind != DNE_KIND_GA) return h->fail("dne_ga_set_init_scale needs a GAAtariPolicy engine");
+    if (h->L.kind == DNE_KIND_ES) return h->fail("dne_ga_set_init_scale needs a GA engine");
     if (n != (size_t)h->L.P) return h->fail("dne_ga_set_init_scale: expected %d values, got %zu", h->L.P, n);
     if (!h->init_scale) HCHECK(h, h->alloc(&h->init_scale, n, "init_scale"));
     HCHECK(h, hipMemcpy(h->init_scale, scale_by, n * sizeof(float), hipMemcpyHostToDevice));
@@ -1708,7 +1746,7 @@ extern "C" int dne_ga_set_init_scale(dne_handle *h, const float *scale_by, size_
 
 extern "C" int dne_ga_rebuild(dne_handle *h, int slot, const int64_t *seeds, int nseeds, float sigma, float *out_host) {
     DeviceGuard dg(h);
-    if (h->L.kind != DNE_KIND_GA) return h->fail("dne_ga_rebuild needs a GAAtariPolicy engine");
+    if (h->L.kind != DNE_KIND_GA) return h->fail("dne_ga_rebuild needs a GAAtariPolicy engine (LargeModel genomes carry per-seed powers: dne_ga_rebuild_powers)");
     if (slot < 0 || nseeds < 1) return h->fail("bad arguments");
     if (grow_bases(h, slot + 1)) return -1;
     h->free_slots.erase(std::remove(h->free_slots.begin(), h->free_slots.end(), slot), h->free_slots.end());
@@ -1722,7 +1760,7 @@ extern "C" int dne_ga_rebuild(dne_handle *h, int slot, const int64_t *seeds, int
 // the same for a genome ((idx0,), (idx1, power1), ...) of the gpu tree (base.py:118-139: compute_weights_from_seeds)
 extern "C" int dne_ga_rebuild_powers(dne_handle *h, int slot, const int64_t *seeds, const float *powers, int nseeds, float *out_host) {
     DeviceGuard dg(h);
-    if (h->L.kind != DNE_KIND_GA) return h->fail("dne_ga_rebuild_powers needs a GAAtariPolicy engine");
+    if (h->L.kind == DNE_KIND_ES) return h->fail("dne_ga_rebuild_powers needs a GA engine");
     if (slot < 0 || nseeds < 1 || !powers) return h->fail("bad arguments");
     if (grow_bases(h, slot + 1)) return -1;
     h->free_slots.erase(std::remove(h->free_slots.begin(), h->free_slots.end(), slot), h->free_slots.end());
@@ -1739,7 +1777,8 @@ extern "C" int dne_ga_rebuild_powers(dne_handle *h, int slot, const int64_t *see
 // gpu tree's genomes ((idx0,), (idx1, power1), ...) with a scaled-noise root (base.py:118-149).
 static int ga_eval_impl(dne_handle *h, const int32_t *co, const int64_t *seeds, const float *powers, int n, float sigma, int tslimit,
                         const uint32_t *env_seed, float *returns, float *signreturns, int32_t *lengths, uint8_t *bc) {
-    if (h->L.kind != DNE_KIND_GA) return h->fail("dne_ga_eval needs a GAAtariPolicy engine");
+    if (h->L.kind == DNE_KIND_ES) return h->fail("dne_ga_eval needs a GA engine");
+    if (h->large && !powers) return h->fail("LargeModel genomes are the GPU tree's: per-seed powers over a scaled-noise root (dne_ga_set_init_scale + dne_ga_eval_powers)");
     if (check_n(h, n)) return -1;
     if (powers && !h->init_scale) return h->fail("genomes with per-seed powers need dne_ga_set_init_scale first");
     const int stride = powers ? 2 : 1;   // cache key: the seeds, interleaved with the bit patterns of their powers

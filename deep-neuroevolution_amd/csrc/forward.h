@@ -23,6 +23,7 @@ namespace dne {
 struct Layout {
     int kind, nact, P;
     int c1w, c1b, bn1b, bn1g, c2w, c2b, bn2b, bn2g, fcw, fcb, bn3b, bn3g, ow, ob;
+    int c3w, c3b;   // LargeModel only
 };
 
 struct FwdArgs {
@@ -84,21 +85,26 @@ struct Conv1Lds {
 
 // one member-frame (or 1/4, 1/7 of its position tiles when nsplit = 4 / 7: few members left, several workgroups share one
 // member's 28 tiles to cut the latency); called by all 256 threads of a workgroup
-__device__ __forceinline__ void conv1_body(Conv1Lds &S, const FwdArgs &A, const Item &it, float *__restrict__ y1, int part, int nsplit) {
+// CO = output channels of the layer (16; 32 for the LargeModel, whose two 16-channel halves are two calls with half = 0 / 1):
+// the weights are [kh][kw][ci][CO], the output rows [441][CO].
+template <int CO = 16>
+__device__ __forceinline__ void conv1_body(Conv1Lds &S, const FwdArgs &A, const Item &it, float *__restrict__ y1, int part, int nsplit,
+                                           int half = 0) {
     float (&lut)[256] = S.lut;
     uint32_t (&img)[88 * 88] = S.img;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, ci = lane >> 4;
     const float *base = A.bases + (size_t)A.m_slot[it.member] * A.base_stride + A.L.c1w;
     const float *eps = A.noise + A.m_off[it.member] + A.L.c1w;
     const float sc = A.m_scale[it.member];
+    const int wl = CO == 16 ? lane : ci * CO + half * 16 + lp;   // this lane's weight within a tap's [ci][CO] block
     float b[64];
 #pragma unroll
     for (int kk = 0; kk < 64; kk++) {
-        float v = sc * eps[64 * kk + lane];
-        b[kk] = base[64 * kk + lane] + v;
+        float v = sc * eps[4 * CO * kk + wl];
+        b[kk] = base[4 * CO * kk + wl] + v;
     }
-    float pb = sc * eps[4096 + lp];
-    const float bias = base[4096 + lp] + pb;
+    float pb = sc * eps[256 * CO + half * 16 + lp];
+    const float bias = base[256 * CO + half * 16 + lp] + pb;
     lut[tid] = (float)tid / 255.0f;
     {   // stage the frame stack: all 28 loads of a thread are issued before the first LDS write (a rolled loop
         // would pay one L2 round trip per element); the 2-pixel zero border is written separately
@@ -121,7 +127,7 @@ __device__ __forceinline__ void conv1_body(Conv1Lds &S, const FwdArgs &A, const 
         }
     }
     __syncthreads();
-    float *out = y1 + (size_t)it.row * 7056;
+    float *out = y1 + (size_t)it.row * (441 * CO) + half * 16;
     // 28 position tiles, 7 per wave: three pairs (two independent accumulators cover the dependent-MFMA latency) and
     // one single tile -- the single one runs on one accumulator instead of dragging an empty partner through the pipe
     auto run = [&](int j, auto has_b) {
@@ -145,8 +151,8 @@ __device__ __forceinline__ void conv1_body(Conv1Lds &S, const FwdArgs &A, const 
 #pragma unroll
         for (int r = 0; r < 4; r++) {   // D[row = 4*(l>>4) + r][col = l&15]
             const int posA = tA * 16 + ci * 4 + r, posB = tB * 16 + ci * 4 + r;
-            if (posA < 441) out[posA * 16 + lp] = accA[r] + bias;
-            if (HASB && posB < 441) out[posB * 16 + lp] = accB[r] + bias;
+            if (posA < 441) out[posA * CO + lp] = accA[r] + bias;
+            if (HASB && posB < 441) out[posB * CO + lp] = accB[r] + bias;
         }
     };
     if (nsplit == 7) {   // the last handful of members: one tile per wave, seven workgroups per member

@@ -12,7 +12,7 @@ import numpy as np
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libdne_hip.so")
 
-KIND_ES, KIND_GA = 0, 1
+KIND_ES, KIND_GA, KIND_GA_LARGE = 0, 1, 2   # DNE_KIND_* (include/dne_hip.h); 2 = the GPU tree's LargeModel (models/dqn.py:39-47)
 PROC_MODES = {"centered_rank": 0, "sign": 1, "centered_sign_rank": 2}
 OPT_KINDS = {"adam": 0, "sgd": 1}
 OB_SHAPE = (84, 84, 4)
@@ -230,6 +230,12 @@ class Engine:
         actions = np.empty(n, np.int32); logits = np.empty((n, self.n_actions), np.float32)
         self._ck(self.lib.dne_act(self.h, int(n), _ptr(actions, C.c_int32), _ptr(logits, C.c_float)))
         return actions, logits
+
+    def debug_activations_large(self, member):
+        """LargeModel: raw conv1 [441*32], conv2 / conv3 [121*64] and fc [512] outputs of one member after act()"""
+        y1 = np.empty(14112, np.float32); y2 = np.empty(7744, np.float32); y3 = np.empty(7744, np.float32); y4 = np.empty(512, np.float32)
+        self._ck(self.lib.dne_debug_activations_large(self.h, int(member), _ptr(y1, C.c_float), _ptr(y2, C.c_float), _ptr(y3, C.c_float), _ptr(y4, C.c_float)))
+        return y1, y2, y3, y4
 
     def debug_activations(self, member):
         y1 = np.empty(7056, np.float32); y2 = np.empty(3872, np.float32); y3 = np.empty(256, np.float32)

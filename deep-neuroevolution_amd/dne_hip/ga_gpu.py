@@ -3,8 +3,9 @@
 genomes ((idx0,), (idx1, power1), ...) with a scaled-noise root (models/base.py:118-149), truncation selection with a
 validated elite (ga.py:166-204, 263-274).
 
-Scope: the small `Model` (models/dqn.py:24-37: conv 16 8x8/4, conv 32 4x4/2, fc 256, out) -- its forward is the engine's
-GAAtariPolicy network.  `LargeModel` (dqn.py:39-47: conv 32/64/64, fc 512) is a different network and is not built.
+Models: `Model` (models/dqn.py:24-37: conv 16 8x8/4, conv 32 4x4/2, fc 256, out) -- its forward is the engine's GAAtariPolicy
+network -- and `LargeModel` (dqn.py:39-47: conv 32/64/64, fc 512, the one configurations/ga_atari_config.json names), the engine's
+DNE_KIND_GA_LARGE (csrc/forward_large.h); exp['model'] picks one like ga.py:110.
 The reference evaluates through TensorFlow workers (ConcurrentWorkers.monitor_eval); here a generation is one
 dne_ga_eval_powers call and the validation / test episodes are batched calls of the same entry point.
 Unseeded streams of the reference (np.random.RandomState() in ga.py:127, the environments' own seeds) are seeded here.
@@ -113,10 +114,10 @@ class Offspring(object):
 
 
 # ---------------------------------------------------------------------------------------------- models/dqn.py:24-37, base.py:190-201
-def model_scale_by(nact):
-    """scale_by of `Model`: weights std / sqrt(prod(shape[:-1])) with std 1.0 (out layer 0.1), biases 0 -- in the engine's
-    GAAtariPolicy flat order (conv1 w, b, conv2 w, b, fc w, b, out w, b = the creation order of dqn.py:29-36)."""
-    spec, P = flat_layout(_lib.KIND_GA, nact)
+def model_scale_by(nact, kind=None):
+    """scale_by of `Model` / `LargeModel` (dqn.py:25-27, inherited by LargeModel): weights std / sqrt(prod(shape[:-1])) with std 1.0
+    (out layer 0.1), biases 0 -- in the engine's flat order = the creation order of dqn.py:29-36 / 39-47."""
+    spec, P = flat_layout(_lib.KIND_GA if kind is None else kind, nact)
     sb = np.zeros(P, np.float32)
     for name, (off, shape) in spec.items():
         n = int(np.prod(shape))
@@ -126,12 +127,15 @@ def model_scale_by(nact):
     return sb
 
 
+MODEL_KINDS = {'Model': _lib.KIND_GA, 'LargeModel': _lib.KIND_GA_LARGE}   # neuroevolution/models/dqn.py:24-47 (exp['model'], ga.py:110)
+
+
 class HipModel(object):
     """randomize / mutate / compute_weights_from_seeds of models/base.py:113-149, with theta living on the device"""
 
     def __init__(self, engine):
         self.engine, self.num_params = engine, engine.P
-        self.scale_by = model_scale_by(engine.n_actions)
+        self.scale_by = model_scale_by(engine.n_actions, engine.kind)
         engine.ga_set_init_scale(self.scale_by)
 
     def randomize(self, rs, noise):
@@ -161,7 +165,7 @@ def main(log_dir, engine=None, noise=None, seed=0, max_iters=None, **exp):
     from .es import SharedNoiseTable
     tlogger.start(log_dir)
     if engine is None:
-        engine = _lib.Engine(_lib.KIND_GA, 18, max_members=exp['population_size'])
+        engine = _lib.Engine(MODEL_KINDS[exp.get('model', 'Model')], 18, max_members=exp['population_size'])
     noise = noise if noise is not None else SharedNoiseTable()
     noise.attach(engine)
     model = HipModel(engine)

@@ -30,6 +30,12 @@ def flat_layout(kind, nact):
         add("conv2/weights", (4, 4, 16, 32)); add("conv2/biases", (32,)); add("BatchNorm_1/beta", (32,)); add("BatchNorm_1/gamma", (32,))
         add("fc/weights", (3872, 256)); add("fc/biases", (256,)); add("BatchNorm_2/beta", (256,)); add("BatchNorm_2/gamma", (256,))
         add("out/weights", (256, nact)); add("out/biases", (nact,))
+    elif kind == _lib.KIND_GA_LARGE:   # the GPU tree's LargeModel, gpu_implementation/neuroevolution/models/dqn.py:39-47 (creation order, base.py:35-41)
+        add("conv1/w", (8, 8, 4, 32)); add("conv1/b", (1, 1, 1, 32))
+        add("conv2/w", (4, 4, 32, 64)); add("conv2/b", (1, 1, 1, 64))
+        add("conv3/w", (3, 3, 64, 64)); add("conv3/b", (1, 1, 1, 64))
+        add("fc/w", (7744, 512)); add("fc/b", (1, 512))
+        add("out/w", (512, nact)); add("out/b", (1, nact))
     else:
         add("conv1/w", (8, 8, 4, 16)); add("conv1/b", (1, 1, 1, 16))
         add("conv2/w", (4, 4, 16, 32)); add("conv2/b", (1, 1, 1, 32))

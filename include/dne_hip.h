@@ -23,6 +23,8 @@ extern "C" {
 
 #define DNE_KIND_ES 0 /* ESAtariPolicy  es_distributed/policies.py:305-429 */
 #define DNE_KIND_GA 1 /* GAAtariPolicy  es_distributed/policies.py:433-513 */
+#define DNE_KIND_GA_LARGE 2 /* LargeModel of the GPU tree (conv 32/64/64, fc 512): gpu_implementation/neuroevolution/models/dqn.py:39-47.
+                               GA entry points only, genomes with per-seed powers (dne_ga_set_init_scale + dne_ga_eval_powers) */
 #define DNE_OB_BYTES (84 * 84 * 4)
 #define DNE_RAM_BYTES 128
 #define DNE_BN_FLOATS 608
@@ -119,6 +121,9 @@ int dne_get_bn(dne_handle *h, int n, float *out /*[n][608] scale,shift per layer
 int dne_get_bn_moments(dne_handle *h, int n, float *out);
 int dne_act(dne_handle *h, int n, int32_t *actions, float *logits /*[n][n_actions] or NULL*/);
 int dne_debug_activations(dne_handle *h, int member, float *y1 /*7056*/, float *y2 /*3872*/, float *y3 /*256*/);
+/* LargeModel engines (DNE_KIND_GA_LARGE): raw outputs of conv1 [441*32], conv2 / conv3 [121*64] and the fc [512] of one member after
+   dne_act -- kernel-level parity against the oracle's orc_forward_large_debug (models/dqn.py:39-47). */
+int dne_debug_activations_large(dne_handle *h, int member, float *y1, float *y2, float *y3, float *y4);
 
 /* ---- A1-A7: whole-batch evaluation ------------------------------------------------------------------ */
 /* es.py:411-426 for n pairs at once: returns_n2/signreturns_n2/lengths_n2 are [n][2] like Result (es.py:18-23).
