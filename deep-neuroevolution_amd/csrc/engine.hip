@@ -525,6 +525,9 @@ struct dne_handle {
     int32_t *launch_units = nullptr; size_t launch_units_cap = 0;
     uint32_t *seeds = nullptr;
     float *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *y3t = nullptr;   // step mode: one row per member (y3t: 4 k-slice partials)
+    int ga_materialize = 0;          // DNE_GA_MATERIALIZE: GA children written out once per generation (default: on for the LargeModel)
+    bool members_materialized = false;   // the current members are plain vectors (scale 0 everywhere): kernels that have one skip the noise stream
+    std::vector<int> child_slots;    // base slots set aside for materialised children
     bool large = false;              // DNE_KIND_GA_LARGE: y1 [441][32], y2 / y3 [121][64] (conv3 output), y3t = the 512 fc outputs
     float *y1r[2] = {nullptr, nullptr}, *y2r[2] = {nullptr, nullptr}, *y3pr[2] = {nullptr, nullptr};   // reference pass scratch, two ways
     float *fr1[2] = {nullptr, nullptr}, *fr2[2] = {nullptr, nullptr};   // per-frame batch-norm moments of conv1 / conv2 ([rows][2][C])
@@ -879,6 +882,9 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(h->alloc(&h->len, M, "len")); CH(h->alloc(&h->done, M, "done")); CH(h->alloc(&h->action, M, "action")); CH(h->alloc(&h->seeds, M, "seeds")); CH(h->alloc(&h->stepped, M, "stepped"));
     CH(hipMemset(h->done, 0, M * sizeof(int32_t))); CH(hipMemset(h->len, 0, M * sizeof(int32_t)));
     h->large = cfg->policy_kind == DNE_KIND_GA_LARGE;
+    h->ga_materialize = h->large ? 1 : 0;
+    env_int("DNE_GA_MATERIALIZE", 0, 1, &h->ga_materialize);
+    if (!h->large) h->ga_materialize = 0;   // only the LargeModel's fc has a noise-free variant
     if (h->large) { CH(h->alloc(&h->y1, M * 14112, "y1")); CH(h->alloc(&h->y2, M * 7744, "y2")); CH(h->alloc(&h->y3, M * 7744, "y3")); CH(h->alloc(&h->y3t, M * 512, "y3t")); }
     else { CH(h->alloc(&h->y1, M * 7056, "y1")); CH(h->alloc(&h->y2, M * 3872, "y2")); CH(h->alloc(&h->y3, M * 256, "y3")); CH(h->alloc(&h->y3t, M * 4 * 256, "y3t")); }
     CH(h->alloc(&h->unit_order, M * 4, "unit_order"));
@@ -1224,6 +1230,7 @@ extern "C" int dne_set_members(dne_handle *h, int n, const int32_t *slot, const 
     HCHECK(h, hipStreamSynchronize(h->stream));
     h->uniform_base = true;
     for (int i = 0; i < n; i++) h->uniform_base = h->uniform_base && slot[i] == slot[0];
+    h->members_materialized = false;
     return 0;
 }
 
@@ -1351,7 +1358,8 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
     const FwdArgs A = h->fwd(logits == nullptr);
     const bool es = h->L.kind == DNE_KIND_ES;
     if (h->large) {   // LargeModel: streamed 7744 x 512 fc (two 256-column halves per member), then relu + output layer + argmax
-        hipLaunchKernelGGL(k_lfc, dim3(std::min(2 * count, 2 * h->fc_grid)), dim3(256), 0, st, A, list, 2 * count, (const float *)h->y3, h->y3t);
+        if (h->members_materialized) hipLaunchKernelGGL((k_lfc<false>), dim3(std::min(2 * count, 2 * h->fc_grid)), dim3(256), 0, st, A, list, 2 * count, (const float *)h->y3, h->y3t);
+        else hipLaunchKernelGGL((k_lfc<true>), dim3(std::min(2 * count, 2 * h->fc_grid)), dim3(256), 0, st, A, list, 2 * count, (const float *)h->y3, h->y3t);
         hipLaunchKernelGGL(k_lout, dim3(count), dim3(256), (size_t)512 * h->cfg.n_actions * sizeof(float), st, A, list, (const float *)h->y3t, h->action, logits);
         return;
     }
@@ -1897,7 +1905,39 @@ static int ga_eval_impl(dne_handle *h, const int32_t *co, const int64_t *seeds, 
     if (h->ga_sort) std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return slot[a] < slot[b]; });
     std::vector<int32_t> pslot(n); std::vector<int64_t> poff(n); std::vector<float> psc(n); std::vector<uint32_t> pseed(n);
     for (int j = 0; j < n; j++) { const int i = order[j]; pslot[j] = slot[i]; poff[j] = off[i]; psc[j] = sc[i]; pseed[j] = env_seed[i]; }
+    h->members_materialized = false;
+    if (h->ga_materialize) {
+        // Every child's vector written out once (parent + power * noise, the forward kernels' own two roundings): a member-step then
+        // reads its rows as they are instead of streaming a parent row and a noise row -- for the LargeModel, whose 20 parents
+        // (318 MB) do not fit the Infinity Cache, half the HBM bytes of the fc.  Roots (no mutation) are their own vector already.
+        if (h->child_slots.size() < (size_t)n) {
+            const int need = n - (int)h->child_slots.size();
+            if ((int)h->free_slots.size() < need && grow_bases(h, h->base_cap + need - (int)h->free_slots.size())) return -1;
+            for (int k = 0; k < need; k++) { h->child_slots.push_back(h->free_slots.back()); h->free_slots.pop_back(); }
+        }
+        std::vector<int32_t> cs(n), mp; std::vector<int64_t> mo; std::vector<float> ms; std::vector<int32_t> mc;
+        for (int j = 0; j < n; j++) {
+            if (psc[j] == 0.0f) { cs[j] = pslot[j]; continue; }
+            cs[j] = h->child_slots[j];
+            mp.push_back(pslot[j]); mo.push_back(poff[j]); ms.push_back(psc[j]); mc.push_back(cs[j]);
+        }
+        const int nm = (int)mp.size();
+        if (nm > 0) {
+            if ((size_t)3 * nm > h->scratch_cap) return h->fail("too many children to materialise");
+            int32_t *d_ps = (int32_t *)h->scratch_f, *d_cs = d_ps + nm;
+            float *d_sc = h->scratch_f + 2 * nm;
+            HCHECK(h, hipMemcpyAsync(d_ps, mp.data(), nm * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+            HCHECK(h, hipMemcpyAsync(d_cs, mc.data(), nm * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+            HCHECK(h, hipMemcpyAsync(d_sc, ms.data(), nm * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            HCHECK(h, hipMemcpyAsync(h->scratch_i, mo.data(), nm * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_materialize_children, dim3((h->L.P + 255) / 256, nm), dim3(256), 0, h->stream, (const float *)h->noise, h->bases,
+                               h->base_stride, h->L.P, (const int32_t *)d_ps, (const int64_t *)h->scratch_i, (const float *)d_sc, (const int32_t *)d_cs);
+            HCHECK(h, hipStreamSynchronize(h->stream));
+        }
+        for (int j = 0; j < n; j++) { pslot[j] = cs[j]; psc[j] = 0.0f; }
+    }
     if (dne_set_members(h, n, pslot.data(), poff.data(), psc.data())) return -1;
+    h->members_materialized = h->ga_materialize != 0;   // (dne_set_members clears it: a caller's own members carry noise)
     std::vector<float> pret(n), psg(n); std::vector<int32_t> plen(n); std::vector<uint8_t> pbc(bc ? (size_t)n * 128 : 0);
     if (eval_core(h, n, 1, tslimit, pseed.data(), pret.data(), psg.data(), plen.data(), bc ? pbc.data() : nullptr)) return -1;
     for (int j = 0; j < n; j++) {

@@ -98,6 +98,9 @@ constexpr size_t lconv_mfma_lds_bytes() {
 
 // fc 7744 -> 512, streamed: workgroup = (member, 256-column half), wave = k-slice of 1936 rows, lane = 4 columns; two row batches
 // of 4 in flight per wave.  The activations are relu(conv3) read 64 rows at a time, one per lane, and broadcast with v_readlane.
+// NOISE = false: every member's vector is materialised (a GA child = its parent + one mutation, written out once per
+// generation by k_materialize_children): the rows are read as they are -- half the bytes of streaming parent and noise rows.
+template <bool NOISE>
 __global__ __launch_bounds__(256) void k_lfc(FwdArgs A, const int *__restrict__ list, int n_items, const float *__restrict__ y3,
                                              float *__restrict__ y4) {
     __shared__ float part[4][256];
@@ -125,12 +128,12 @@ __global__ __launch_bounds__(256) void k_lfc(FwdArgs A, const int *__restrict__ 
             return t;
         };
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        f4u e_cur[RB], e_nxt[RB];
+        f4u e_cur[RB] = {}, e_nxt[RB] = {};
         f4a t_cur[RB], t_nxt[RB];
         float xv = load_x(0), xn = load_x(1);
 #pragma unroll
         for (int i = 0; i < RB; i++) {
-            e_cur[i] = *(const f4u *)(eps + (size_t)i * PITCH);
+            if (NOISE) e_cur[i] = *(const f4u *)(eps + (size_t)i * PITCH);
             t_cur[i] = *(const f4a *)(th + (size_t)i * PITCH);
         }
         for (int bt = 0; bt < NB; bt++) {
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256) void k_lfc(FwdArgs A, const int *__restrict__ 
 #pragma unroll
                 for (int i = 0; i < RB; i++) {
                     const size_t ro = (size_t)((bt + 1) * RB + i) * PITCH;
-                    e_nxt[i] = *(const f4u *)(eps + ro);
+                    if (NOISE) e_nxt[i] = *(const f4u *)(eps + ro);
                     t_nxt[i] = *(const f4a *)(th + ro);
                 }
             }
@@ -148,13 +151,16 @@ __global__ __launch_bounds__(256) void k_lfc(FwdArgs A, const int *__restrict__ 
                 const float x = lane_bcast(xv, li + i);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    float pv = sc * e_cur[i][q];
-                    float w = t_cur[i][q] + pv;
+                    float w = t_cur[i][q];
+                    if (NOISE) {
+                        float pv = sc * e_cur[i][q];
+                        w = t_cur[i][q] + pv;
+                    }
                     acc[q] = __builtin_fmaf(x, w, acc[q]);
                 }
             }
 #pragma unroll
-            for (int i = 0; i < RB; i++) { e_cur[i] = e_nxt[i]; t_cur[i] = t_nxt[i]; }
+            for (int i = 0; i < RB; i++) { if (NOISE) e_cur[i] = e_nxt[i]; t_cur[i] = t_nxt[i]; }
             if (bt % BPC == BPC - 1) {
                 xv = xn;
                 xn = load_x(bt / BPC + 2);
@@ -168,8 +174,11 @@ __global__ __launch_bounds__(256) void k_lfc(FwdArgs A, const int *__restrict__ 
             const float s01 = part[0][j] + part[1][j];
             const float s23 = part[2][j] + part[3][j];
             float s = s01 + s23;
-            float pv = sc * A.noise[off + L.fcb + col];
-            const float bias = base[L.fcb + col] + pv;
+            float bias = base[L.fcb + col];
+            if (NOISE) {
+                float pv = sc * A.noise[off + L.fcb + col];
+                bias = base[L.fcb + col] + pv;
+            }
             y4[(size_t)m * 512 + col] = s + bias;
         }
         __syncthreads();   // part is reused by the next item

@@ -336,4 +336,16 @@ __global__ __launch_bounds__(256) void k_bc_sqdist_batch(const uint8_t *__restri
     if (threadIdx.x == 0) { out[((size_t)i * narch + a) * 2] = ra[0]; out[((size_t)i * narch + a) * 2 + 1] = rb[0]; }
 }
 
+
+// GA children written out once per generation: child = parent + scale * noise[off ..] (base.py:141-142 compute_mutation; the same
+// two roundings the forward kernels apply on the fly).  grid (ceil(P / 256), children).
+__global__ __launch_bounds__(256) void k_materialize_children(const float *__restrict__ noise, float *__restrict__ bases, size_t stride, int P,
+                                                              const int32_t *__restrict__ pslot, const int64_t *__restrict__ off,
+                                                              const float *__restrict__ scale, const int32_t *__restrict__ cslot) {
+    const int p = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (p >= P) return;
+    float pv = scale[j] * noise[off[j] + p];
+    bases[(size_t)cslot[j] * stride + p] = bases[(size_t)pslot[j] * stride + p] + pv;
+}
+
 }  // namespace dne

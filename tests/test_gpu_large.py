@@ -64,9 +64,15 @@ def test_forward_every_layer_bit_exact(large_engine, oracle, big_noise):
         assert np.array_equal(logits[i], ol) and acts[i] == int(np.argmax(ol)), i
 
 
-def test_genomes_evaluated_bit_exact(large_engine, oracle, big_noise):
+@pytest.mark.parametrize("materialize", ["1", "0"])
+def test_genomes_evaluated_bit_exact(materialize, oracle, big_noise, monkeypatch):
+    """materialize = 1 (default): children written out once per generation, the fc streams plain rows; 0: parent + noise rows on the fly"""
     from dne_hip import _lib, ga_gpu
-    e, O = large_engine, oracle
+    monkeypatch.setenv("DNE_GA_MATERIALIZE", materialize)
+    e = _lib.Engine(_lib.KIND_GA_LARGE, NACT, max_members=16, record_bc=True)
+    e.noise_upload(big_noise)
+    e.ga_set_init_scale(ga_gpu.model_scale_by(NACT, _lib.KIND_GA_LARGE))
+    O = oracle
     L = O.layout(O.KIND_GA_LARGE, NACT)
     sb = ga_gpu.model_scale_by(NACT, _lib.KIND_GA_LARGE)
     genomes = [(1234,), (200_000, (7, 0.002)), (2_900_000, (5, 0.004), (123_456, 0.001)), (200_000, (7, 0.002), (31_337, 0.003)),
@@ -77,8 +83,14 @@ def test_genomes_evaluated_bit_exact(large_engine, oracle, big_noise):
         r, s, l, obc = O.rollout(L, O.ga_gpu_rebuild(big_noise, g, sb), None, seeds[i], 45, want_bc=True)
         assert (ret[i], sg[i], ln[i]) == (r, s, l) and np.array_equal(bc[i], obc), i
     assert len(set(ln.tolist())) > 1 or ln.max() == 45
+    # next generation: children of cached parents, evaluated in another order
+    kids = [genomes[1] + ((555, 0.0025),), genomes[3] + ((777_777, 0.0015),), genomes[1] + ((556, 0.0025),), genomes[4] + ((4_400_000, 0.002),)]
+    ret, sg, ln = e.ga_eval_powers(kids, 45, seeds[:4])
+    for i, g in enumerate(kids):
+        assert (ret[i], sg[i], ln[i]) == O.rollout(L, O.ga_gpu_rebuild(big_noise, g, sb), None, seeds[i], 45)[:3], i
     with pytest.raises(_lib.DneError):
         e.ga_eval([[5, 6]], 0.002, 10, seeds[:1])            # es_distributed genomes (normc root) are GAAtariPolicy's
+    e.close()
 
 
 def test_deep_ga_driver_with_large_model(oracle, big_noise, tmp_path):
