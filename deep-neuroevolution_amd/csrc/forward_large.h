@@ -22,33 +22,29 @@ __global__ __launch_bounds__(256) void k_lconv1(FwdArgs A, const int *__restrict
     conv1_body<32>(S, A, it, y1, 0, 1, blockIdx.x & 1);
 }
 
-// conv2 / conv3 on v_mfma_f32_16x16x4_f32 (bitwise a k-ordered fp32 fmaf chain): one workgroup = one member x 16 output
-// channels.  GEMM view [HOUT^2 positions] x [K*K*CIN] x [16]: the four k-values of one MFMA are four consecutive input channels
+// conv2 / conv3 on v_mfma_f32_16x16x4_f32 (bitwise a k-ordered fp32 fmaf chain): one workgroup = one member, its 16-channel
+// output tiles one after the other over an image staged once.  GEMM view [HOUT^2 positions] x [K*K*CIN] x [16]: the four k-values of one MFMA are four consecutive input channels
 // of one tap, so lane (lp = l & 15, kq = l >> 4) feeds x[position lp][ci0 + kq] and w[tap][ci0 + kq][co lp].  The relu'd input
 // image sits in LDS with a zero border (SAME padding) and a pixel stride PS chosen so that the 64 operand reads of an MFMA hit
 // 64 different banks (S * PS = 4 mod 64: bank = 4 lp + kq); the member's perturbed 16-column weight tile sits next to it.
 // Each wave owns two position tiles (two independent accumulators cover the dependent-MFMA latency).
 template <int CIN, int COUT, int K, int S, int HIN, int HOUT, int PAD, int PS>
 __global__ __launch_bounds__(256) void k_lconv_mfma(FwdArgs A, const int *__restrict__ list, int w_off, int b_off,
-                                                    const float *__restrict__ in_all, float *__restrict__ out_all) {
+                                                    const float *__restrict__ in_all, float *__restrict__ out_all,
+                                                    int nsplit /* workgroups per member (1, 2 or 4): each takes NT / nsplit of the 16-channel tiles */) {
     constexpr int HP = (HOUT - 1) * S + K, NPOS = HOUT * HOUT, KK = K * K * CIN, NT = COUT / 16;
     constexpr int NTILE = (NPOS + 15) / 16;
     static_assert(NTILE <= 8 && CIN % 4 == 0, "two position tiles per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    float *wt = reinterpret_cast<float *>(lds_raw);   // [KK][16]
-    float *xf = wt + KK * 16;                          // [HP][HP][PS]
+    float *wt = reinterpret_cast<float *>(lds_raw);   // [KK][16]: one 16-channel weight tile at a time
+    float *xf = wt + KK * 16;                          // [HP][HP][PS]: the image, staged once for all NT tiles
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, kq = lane >> 4;
-    const int item = blockIdx.x / NT, tile = blockIdx.x % NT;
+    const int item = blockIdx.x / nsplit, part = blockIdx.x % nsplit;
     const int m = list ? list[item] : item;
     if (A.done && A.done[m]) return;
     const float sc = A.m_scale[m];
     const int64_t off = A.m_off[m];
     const float *base = A.bases + (size_t)A.m_slot[m] * A.base_stride;
-    for (int i = tid; i < KK * 16; i += 256) {
-        const size_t p = (size_t)w_off + (size_t)(i >> 4) * COUT + tile * 16 + (i & 15);
-        float pv = sc * A.noise[off + p];
-        wt[i] = base[p] + pv;
-    }
     const float *src = in_all + (size_t)m * (HIN * HIN * CIN);
     for (int i = tid; i < HP * HP * CIN; i += 256) {
         const int ci = i % CIN, px = (i / CIN) % HP, py = i / (CIN * HP), x = px - PAD, y = py - PAD;
@@ -59,34 +55,42 @@ __global__ __launch_bounds__(256) void k_lconv_mfma(FwdArgs A, const int *__rest
         }
         xf[(py * HP + px) * PS + ci] = v;
     }
-    __syncthreads();
-    float pvb = sc * A.noise[off + b_off + tile * 16 + lp];
-    const float bias = base[b_off + tile * 16 + lp] + pvb;
     const int tA = wv, tB = wv + 4;
     const bool hasB = tB < NTILE;
     const int pA = min(tA * 16 + lp, NPOS - 1), pB = min(tB * 16 + lp, NPOS - 1);
     const float *xA = xf + ((pA / HOUT) * S * HP + (pA % HOUT) * S) * PS + kq;
     const float *xB = xf + ((pB / HOUT) * S * HP + (pB % HOUT) * S) * PS + kq;
     const float *wl = wt + kq * 16 + lp;
-    f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int kh = 0; kh < K; kh++)
-#pragma unroll 1
-        for (int kw = 0; kw < K; kw++) {
-            const int xo = (kh * HP + kw) * PS, wo = (kh * K + kw) * CIN * 16;
-#pragma unroll
-            for (int c0 = 0; c0 < CIN; c0 += 4) {
-                const float b = wl[wo + c0 * 16];
-                accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xA[xo + c0], b, accA, 0, 0, 0);
-                if (hasB) accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xB[xo + c0], b, accB, 0, 0, 0);
-            }
+    for (int tile = part * (NT / nsplit); tile < (part + 1) * (NT / nsplit); tile++) {
+        __syncthreads();                               // the previous tile's readers are done (first pass: nothing to wait for)
+        for (int i = tid; i < KK * 16; i += 256) {
+            const size_t p = (size_t)w_off + (size_t)(i >> 4) * COUT + tile * 16 + (i & 15);
+            float pv = sc * A.noise[off + p];
+            wt[i] = base[p] + pv;
         }
-    float *out = out_all + (size_t)m * (NPOS * COUT) + tile * 16 + lp;
+        float pvb = sc * A.noise[off + b_off + tile * 16 + lp];
+        const float bias = base[b_off + tile * 16 + lp] + pvb;
+        __syncthreads();
+        f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int kh = 0; kh < K; kh++)
+#pragma unroll 1
+            for (int kw = 0; kw < K; kw++) {
+                const int xo = (kh * HP + kw) * PS, wo = (kh * K + kw) * CIN * 16;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {   // D[row = 4 * (l >> 4) + r][col = l & 15]
-        const int posA = tA * 16 + kq * 4 + r, posB = tB * 16 + kq * 4 + r;
-        if (posA < NPOS) out[(size_t)posA * COUT] = accA[r] + bias;
-        if (hasB && posB < NPOS) out[(size_t)posB * COUT] = accB[r] + bias;
+                for (int c0 = 0; c0 < CIN; c0 += 4) {
+                    const float b = wl[wo + c0 * 16];
+                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xA[xo + c0], b, accA, 0, 0, 0);
+                    if (hasB) accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xB[xo + c0], b, accB, 0, 0, 0);
+                }
+            }
+        float *out = out_all + (size_t)m * (NPOS * COUT) + tile * 16 + lp;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {   // D[row = 4 * (l >> 4) + r][col = l & 15]
+            const int posA = tA * 16 + kq * 4 + r, posB = tB * 16 + kq * 4 + r;
+            if (posA < NPOS) out[(size_t)posA * COUT] = accA[r] + bias;
+            if (hasB && posB < NPOS) out[(size_t)posB * COUT] = accB[r] + bias;
+        }
     }
 }
 
@@ -100,14 +104,14 @@ constexpr size_t lconv_mfma_lds_bytes() {
 // of 4 in flight per wave.  The activations are relu(conv3) read 64 rows at a time, one per lane, and broadcast with v_readlane.
 // NOISE = false: every member's vector is materialised (a GA child = its parent + one mutation, written out once per
 // generation by k_materialize_children): the rows are read as they are -- half the bytes of streaming parent and noise rows.
-template <bool NOISE>
+template <bool NOISE, int RB>
 __global__ __launch_bounds__(256) void k_lfc(FwdArgs A, const int *__restrict__ list, int n_items, const float *__restrict__ y3,
                                              float *__restrict__ y4) {
     __shared__ float part[4][256];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const Layout &L = A.L;
     __builtin_amdgcn_s_setprio(3);
-    constexpr int ROWS = 1936, PITCH = 512, RB = 4, NB = ROWS / RB, BPC = 64 / RB;
+    constexpr int ROWS = 1936, PITCH = 512, NB = ROWS / RB, BPC = 64 / RB;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int mi = item >> 1, half = item & 1;
         const int m = list ? list[mi] : mi;
@@ -182,6 +186,73 @@ __global__ __launch_bounds__(256) void k_lfc(FwdArgs A, const int *__restrict__ 
             y4[(size_t)m * 512 + col] = s + bias;
         }
         __syncthreads();   // part is reused by the next item
+    }
+}
+
+// The same fc for a handful of members (the tail of a generation): eight workgroups per member, one per 64-column block,
+// wave = k-slice, lane = ONE column with 2 x 16 rows in flight -- eight times the workgroups pulling on one member's 15.9 MB.
+template <bool NOISE>
+__global__ __launch_bounds__(256) void k_lfc_cols(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y3,
+                                                  float *__restrict__ y4) {
+    __shared__ float part[4][64];
+    __shared__ float xs[4][1936];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const Layout &L = A.L;
+    constexpr int ROWS = 1936, PITCH = 512, RB = 16, NB = ROWS / RB;
+    const int mi = blockIdx.x >> 3, cb = blockIdx.x & 7;
+    const int m = list ? list[mi] : mi;
+    if (A.done && A.done[m]) return;
+    const float sc = A.m_scale[m];
+    const int64_t off = A.m_off[m];
+    const float *base = A.bases + (size_t)A.m_slot[m] * A.base_stride;
+    const int kbeg = ROWS * wv, col = cb * 64 + lane;
+    const float *eps = A.noise + off + L.fcw + (size_t)kbeg * PITCH + col;
+    const float *th = base + L.fcw + (size_t)kbeg * PITCH + col;
+    float e_cur[RB] = {}, e_nxt[RB] = {}, t_cur[RB], t_nxt[RB];
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+        if (NOISE) e_cur[i] = eps[(size_t)i * PITCH];
+        t_cur[i] = th[(size_t)i * PITCH];
+    }
+    for (int i = lane; i < ROWS; i += 64) {   // the slice's activations (relu of conv3), each wave its own
+        const float t = y3[(size_t)m * 7744 + kbeg + i];
+        xs[wv][i] = t > 0.0f ? t : 0.0f;
+    }
+    float acc = 0.0f;
+    for (int bt = 0; bt < NB; bt++) {
+        if (bt + 1 < NB) {
+#pragma unroll
+            for (int i = 0; i < RB; i++) {
+                const size_t ro = (size_t)((bt + 1) * RB + i) * PITCH;
+                if (NOISE) e_nxt[i] = eps[ro];
+                t_nxt[i] = th[ro];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; i++) {
+            float w = t_cur[i];
+            if (NOISE) {
+                float pv = sc * e_cur[i];
+                w = t_cur[i] + pv;
+            }
+            acc = __builtin_fmaf(xs[wv][bt * RB + i], w, acc);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; i++) { if (NOISE) e_cur[i] = e_nxt[i]; t_cur[i] = t_nxt[i]; }
+    }
+    part[wv][lane] = acc;
+    __syncthreads();
+    if (tid < 64) {
+        const int c = cb * 64 + tid;
+        const float s01 = part[0][tid] + part[1][tid];
+        const float s23 = part[2][tid] + part[3][tid];
+        float s = s01 + s23;
+        float bias = base[L.fcb + c];
+        if (NOISE) {
+            float pv = sc * A.noise[off + L.fcb + c];
+            bias = base[L.fcb + c] + pv;
+        }
+        y4[(size_t)m * 512 + c] = s + bias;
     }
 }
 
