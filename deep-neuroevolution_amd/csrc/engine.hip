@@ -491,6 +491,9 @@ struct dne_handle {
     bool fc2_now = false;            // decided per burst by eval_core
     int duo_solo_below = 1500;       // DNE_DUO_SOLO_BELOW: with fewer active groups (all windows) every wave takes one unit instead of two (sparse table: little to share, and twice the waves)
     bool duo_solo_now = false;       // decided per burst by eval_core
+    int out_lds_kb = 64;             // DNE_OUT_LDS_KB: k_out's LDS reservation; the 37 KB it needs at 18 actions let four workgroups share a CU with the
+                                     // streaming fc and the convolutions and cost 0.9 % of the generation (same-box A/B, 403.3 vs 399.8 ms): two per CU
+    int duo_head_fused = 1;          // DNE_DUO_HEAD_FUSED: behind k_fc_duo the policy head and the emulator step share a launch (k_tail_step) instead of k_out + k_env_logic
     int fc_duo_ga = 0;               // DNE_FC_DUO_GA: the table-ordered fc for GA evaluations too (single members, one base vector per parent); measured slower, off
     int duo_lag = 0;                 // DNE_DUO_LAG: extra row batches by which the second unit of a duo trails the first
     int fc_duo = 1, fc_duo_min = 800;   // DNE_FC_DUO / DNE_FC_DUO_MIN: table-ordered fc (k_unit_order + k_fc_duo + k_out) from this many active groups
@@ -841,6 +844,8 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_DUO", 0, 1, &h->fc_duo);
     env_int("DNE_DUO_LAG", 0, 64, &h->duo_lag);
     env_int("DNE_DUO_SOLO_BELOW", 0, 1 << 30, &h->duo_solo_below);
+    env_int("DNE_DUO_HEAD_FUSED", 0, 1, &h->duo_head_fused);
+    env_int("DNE_OUT_LDS_KB", 0, 64, &h->out_lds_kb);
     env_int("DNE_FC_DUO_GA", 0, 1, &h->fc_duo_ga);
     env_int("DNE_FC_DUO_MIN", 2, 1 << 30, &h->fc_duo_min);
     env_int("DNE_RENDER_BANDS", 1, 12, &h->render_bands);
@@ -1389,10 +1394,11 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
     if (h->duo_now && !logits && order && (gsize == 2 ? es : !es)) {   // table-ordered units: adjacent (group, k-slice) units share their noise rows
         const bool solo = h->duo_solo_now;
         const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 3) / 4, blocks = std::min(items, h->fc_grid);
-        const size_t out_lds = (size_t)gsize * 256 * h->cfg.n_actions * sizeof(float);
+        const size_t out_lds = std::max((size_t)gsize * 256 * h->cfg.n_actions * sizeof(float), (size_t)h->out_lds_kb * 1024);
         if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0));
         else hipLaunchKernelGGL((k_fc_duo<1, false>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0));
         if (after_stream_kernel) hipEventRecord(after_stream_kernel, st);
+        if (out_fused) return;   // the caller runs k_tail_step: policy head + emulator step in one launch
         if (es) hipLaunchKernelGGL((k_out<2, true>), dim3(count), dim3(256), out_lds, st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
         else hipLaunchKernelGGL((k_out<1, false>), dim3(count), dim3(256), out_lds, st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
         return;
@@ -1585,7 +1591,8 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 if (chain && last_fc) HCHECK(h, hipStreamWaitEvent(sst, last_fc, 0));
                 if (pe) { e[1] = ne++; HCHECK(h, hipEventRecord(h->event(e[1]), sst)); }   // after the wait: brackets fc only
                 if (pe) e[2] = ne++;
-                launch_fc(h, lst, cnt, gsize, nullptr, sst, tail, h->duo_now ? h->unit_order + 4 * lo : nullptr,
+                const bool duo_head = duo_win && h->duo_head_fused;   // the table-ordered fc leaves partial sums: head + emulator in one launch
+                launch_fc(h, lst, cnt, gsize, nullptr, sst, tail || duo_head, h->duo_now ? h->unit_order + 4 * lo : nullptr,
                           pe && duo_win ? h->event(e[2]) : nullptr);   // duo: the bracket ends behind k_fc_duo, before k_out
                 if (chain) { last_fc = h->fc_ring[fc_ring_pos++ % h->fc_ring.size()]; HCHECK(h, hipEventRecord(last_fc, sst)); }
                 if (pe && !duo_win) HCHECK(h, hipEventRecord(h->event(e[2]), sst));
@@ -1600,6 +1607,13 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                         hipLaunchKernelGGL(k_env_render, dim3(items * nb), dim3(h->band_threads), 0, sst, E, lst, gsize, 0, nb);
                     } else if (es) TS(true, true, 1024); else TS(false, true, 1024);
 #undef TS
+                } else if (duo_head) {
+                    const FwdArgs A = h->fwd(false);
+                    const int items = cnt * gsize;
+                    if (h->L.kind == DNE_KIND_ES) hipLaunchKernelGGL((k_tail_step<true, false>), dim3(items), dim3(256), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
+                    else hipLaunchKernelGGL((k_tail_step<false, false>), dim3(items), dim3(256), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
+                    if (!(h->dbg_skip & 4))
+                        hipLaunchKernelGGL(k_env_render, dim3(items), dim3(items <= 192 ? 1024 : h->render_threads), 0, sst, E, lst, gsize, 0, 1);
                 } else launch_env_step(h, E, lst, cnt, gsize, tslimit, sst);
                 if (pe) { e[3] = ne++; HCHECK(h, hipEventRecord(h->event(e[3]), sst)); evs.push_back(e); }
                 if (h->debug_sync) {
