@@ -493,7 +493,8 @@ struct dne_handle {
     bool duo_solo_now = false;       // decided per burst by eval_core
     int out_lds_kb = 64;             // DNE_OUT_LDS_KB: k_out's LDS reservation; the 37 KB it needs at 18 actions let four workgroups share a CU with the
                                      // streaming fc and the convolutions and cost 0.9 % of the generation (same-box A/B, 403.3 vs 399.8 ms): two per CU
-    int duo_head_fused = 1;          // DNE_DUO_HEAD_FUSED: behind k_fc_duo the policy head and the emulator step share a launch (k_tail_step) instead of k_out + k_env_logic
+    int duo_head_fused = 0;          // DNE_DUO_HEAD_FUSED: behind k_fc_duo the policy head and the emulator step share a launch (k_tail_step) instead of
+                                     // k_out + k_env_logic; same-box A/B: 402.7 ms fused, 403.3 separate, 399.8 separate with k_out at two workgroups per CU -> off
     int fc_duo_ga = 0;               // DNE_FC_DUO_GA: the table-ordered fc for GA evaluations too (single members, one base vector per parent); measured slower, off
     int duo_lag = 0;                 // DNE_DUO_LAG: extra row batches by which the second unit of a duo trails the first
     int fc_duo = 1, fc_duo_min = 800;   // DNE_FC_DUO / DNE_FC_DUO_MIN: table-ordered fc (k_unit_order + k_fc_duo + k_out) from this many active groups
