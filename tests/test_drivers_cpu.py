@@ -156,3 +156,29 @@ def test_gpu_tree_ga_schedules_resume_and_elite(oracle, tmp_path):
                if len(o.seeds) > 1 and o.seeds[-1][1] == pytest.approx(0.003))
     sb = ga_gpu.model_scale_by(18)
     assert sb.shape == (1008450,) and sb[0] == np.float32(1 / 16.0) and sb[4096] == 0.0 and abs(sb[-19] - 0.1 / 16.0) < 1e-9
+
+
+def test_gpu_tree_ga_large_model_on_the_engine_surface(oracle, tmp_path):
+    """exp['model'] = 'LargeModel' (configurations/ga_atari_config.json): ga_gpu.main picks engine kind DNE_KIND_GA_LARGE and its
+    scale_by (models/dqn.py:25-27 over the LargeModel's shapes); with the oracle behind the engine surface the elite's weights are
+    the reference formula noise[idx0] * scale_by + sum power_k * noise[idx_k] (models/base.py:118-149)."""
+    from oracle_engine import OracleEngine
+    from dne_hip import _lib, es, ga_gpu, policies
+    assert ga_gpu.MODEL_KINDS == {"Model": _lib.KIND_GA, "LargeModel": _lib.KIND_GA_LARGE}
+    spec, P = policies.flat_layout(_lib.KIND_GA_LARGE, 18)
+    assert P == 4052658 and spec["conv3/w"][1] == (3, 3, 64, 64) and spec["fc/w"][1] == (7744, 512)
+    sb = ga_gpu.model_scale_by(18, _lib.KIND_GA_LARGE)
+    assert sb.shape == (P,) and sb[0] == np.float32(1 / 16.0) and sb[spec["conv1/b"][0]] == 0.0
+    assert sb[spec["conv2/w"][0]] == np.float32(1 / np.sqrt(512.0)) and sb[spec["conv3/w"][0]] == np.float32(1 / 24.0)
+    assert sb[spec["fc/w"][0]] == np.float32(1 / 88.0) and abs(sb[spec["out/w"][0]] - 0.1 / np.sqrt(512.0)) < 1e-9
+    exp = {"game": "frostbite", "model": "LargeModel", "num_validation_episodes": 1, "num_test_episodes": 1, "population_size": 4,
+           "episode_cutoff_mode": 5, "timesteps": 10 ** 9, "validation_threshold": 2, "selection_threshold": 2, "mutation_power": 0.002}
+    noise = es.SharedNoiseTable(count=4_300_000)
+    eng = OracleEngine(_lib.KIND_GA_LARGE)
+    test, val, st = ga_gpu.main(str(tmp_path), engine=eng, noise=noise, seed=3, max_iters=2, **exp)
+    assert st.it == 2 and len(st.population) == 4 and eng.P == P and np.isfinite(test)
+    th = eng.ga_rebuild_powers(0, st.elite.seeds)
+    ref = noise.noise[st.elite.seeds[0]:st.elite.seeds[0] + P] * sb
+    for idx, power in st.elite.seeds[1:]:
+        ref = ref + np.float32(power) * noise.noise[idx:idx + P]
+    assert np.array_equal(th, ref.astype(np.float32))
