@@ -199,18 +199,24 @@ class RelayClient:
         self.local_redis = retry_connect(relay_redis_cfg)
         self.results_published = 0
         self._stop = threading.Event()
+        self._task_lock, self._last_task_id = threading.Lock(), -1
 
     def run(self, max_batches=None):
         self.local_redis.set(EXP_KEY, retry_get(self.master_redis, EXP_KEY))
-        self._declare_task_local(*retry_get(self.master_redis, (TASK_ID_KEY, TASK_DATA_KEY)))
+        # dist.py:113-121 reads the current task and then subscribes: a task the master declares in between is lost until the
+        # next one.  Here the subscription comes first and task ids only ever move forward locally, so nothing is missed and an
+        # older task never overwrites a newer one.
         handler = lambda data: self._declare_task_local(*deserialize(data))   # noqa: E731
         if hasattr(self.master_redis, 'subscribe_loop'):
-            t = threading.Thread(target=self.master_redis.subscribe_loop, args=(TASK_CHANNEL, handler, self._stop), daemon=True)
+            ready = threading.Event()
+            t = threading.Thread(target=self.master_redis.subscribe_loop, args=(TASK_CHANNEL, handler, self._stop, ready), daemon=True)
             t.start()
+            ready.wait(30)
         else:                                                                  # the real redis package
             p = self.master_redis.pubsub(ignore_subscribe_messages=True)
             p.subscribe(**{TASK_CHANNEL: lambda msg: handler(msg['data'])})
             p.run_in_thread(sleep_time=0.001)
+        self._declare_task_local(*retry_get(self.master_redis, (TASK_ID_KEY, TASK_DATA_KEY)))
         batches = 0
         while max_batches is None or batches < max_batches:
             results = []
@@ -230,10 +236,14 @@ class RelayClient:
     def _declare_task_local(self, task_id, task_data):
         if isinstance(task_id, bytes):
             task_id = int(task_id)
-        logger.info('[relay] Received task {}'.format(task_id))
-        self.results_published = 0
-        self.local_redis.mset({TASK_ID_KEY: task_id, TASK_DATA_KEY: task_data})
-        self.flush_results()
+        with self._task_lock:
+            if task_id <= self._last_task_id:      # the subscription already delivered this task or a newer one
+                return
+            self._last_task_id = task_id
+            logger.info('[relay] Received task {}'.format(task_id))
+            self.results_published = 0
+            self.local_redis.mset({TASK_ID_KEY: task_id, TASK_DATA_KEY: task_data})
+            self.flush_results()
 
 
 class WorkerClient:

@@ -161,13 +161,16 @@ class Client:
     def lrange(self, key, start, stop):
         return self.c.call("LRANGE", key, start, stop)
 
-    def subscribe_loop(self, channel, handler, stop_event=None):
-        """Blocking: a dedicated connection receives `channel`'s messages and passes each payload to handler."""
+    def subscribe_loop(self, channel, handler, stop_event=None, ready_event=None):
+        """Blocking: a dedicated connection receives `channel`'s messages and passes each payload to handler.  ready_event is set
+        once the server has confirmed the subscription (nothing published after that is missed)."""
         sub = Connection(self.cfg, timeout=self.timeout)
         sub.send("SUBSCRIBE", channel)
         try:
             while stop_event is None or not stop_event.is_set():
                 msg = sub.read()
+                if ready_event is not None and isinstance(msg, list) and len(msg) == 3 and msg[0] == b"subscribe":
+                    ready_event.set()
                 if isinstance(msg, list) and len(msg) == 3 and msg[0] == b"message":
                     handler(msg[2])
         finally:
