@@ -821,8 +821,10 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipFuncSetAttribute((const void *)k_conv12<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
     CH(hipFuncSetAttribute((const void *)k_conv12<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
     CH(hipFuncSetAttribute((const void *)k_unit_order, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CH(hipFuncSetAttribute((const void *)k_lconv_mfma<32, 64, 4, 2, 21, 11, 1, 34>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<32, 4, 2, 11, 34>()));
-    CH(hipFuncSetAttribute((const void *)k_lconv_mfma<64, 64, 3, 1, 11, 11, 1, 68>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<64, 3, 1, 11, 68>()));
+    CH(hipFuncSetAttribute((const void *)k_lconv_mfma<32, 64, 4, 2, 21, 11, 1, 34, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<32, 4, 2, 11, 34>()));
+    CH(hipFuncSetAttribute((const void *)k_lconv_mfma<64, 64, 3, 1, 11, 11, 1, 68, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<64, 3, 1, 11, 68>()));
+    CH(hipFuncSetAttribute((const void *)k_lconv_mfma<32, 64, 4, 2, 21, 11, 1, 34, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<32, 4, 2, 11, 34>()));
+    CH(hipFuncSetAttribute((const void *)k_lconv_mfma<64, 64, 3, 1, 11, 11, 1, 68, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<64, 3, 1, 11, 68>()));
     CH(hipFuncSetAttribute((const void *)k_lout, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 32 * 4));
     CH(hipFuncSetAttribute((const void *)k_out<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 32 * 4));
     CH(hipFuncSetAttribute((const void *)k_out<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 32 * 4));
@@ -1337,8 +1339,13 @@ static void launch_forward(dne_handle *h, const int *list, int count, int gsize,
         constexpr size_t l2 = lconv_mfma_lds_bytes<32, 4, 2, 11, 34>(), l3 = lconv_mfma_lds_bytes<64, 3, 1, 11, 68>();
         hipLaunchKernelGGL(k_lconv1, dim3(count * 2), dim3(256), 0, st, A, list, (const uint8_t *)h->stacks, h->y1);
         const int ns = count <= 128 ? 4 : count <= 256 ? 2 : 1;   // few members: one workgroup per 16-channel tile
-        hipLaunchKernelGGL((k_lconv_mfma<32, 64, 4, 2, 21, 11, 1, 34>), dim3(count * ns), dim3(256), l2, st, A, list, A.L.c2w, A.L.c2b, (const float *)h->y1, h->y2, ns);
-        hipLaunchKernelGGL((k_lconv_mfma<64, 64, 3, 1, 11, 11, 1, 68>), dim3(count * ns), dim3(256), l3, st, A, list, A.L.c3w, A.L.c3b, (const float *)h->y2, h->y3, ns);
+        if (h->members_materialized) {
+            hipLaunchKernelGGL((k_lconv_mfma<32, 64, 4, 2, 21, 11, 1, 34, false>), dim3(count * ns), dim3(256), l2, st, A, list, A.L.c2w, A.L.c2b, (const float *)h->y1, h->y2, ns);
+            hipLaunchKernelGGL((k_lconv_mfma<64, 64, 3, 1, 11, 11, 1, 68, false>), dim3(count * ns), dim3(256), l3, st, A, list, A.L.c3w, A.L.c3b, (const float *)h->y2, h->y3, ns);
+        } else {
+            hipLaunchKernelGGL((k_lconv_mfma<32, 64, 4, 2, 21, 11, 1, 34, true>), dim3(count * ns), dim3(256), l2, st, A, list, A.L.c2w, A.L.c2b, (const float *)h->y1, h->y2, ns);
+            hipLaunchKernelGGL((k_lconv_mfma<64, 64, 3, 1, 11, 11, 1, 68, true>), dim3(count * ns), dim3(256), l3, st, A, list, A.L.c3w, A.L.c3b, (const float *)h->y2, h->y3, ns);
+        }
         return;
     }
     const bool es = h->L.kind == DNE_KIND_ES;

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_lconv1(FwdArgs A, const int *__restrict
 // image sits in LDS with a zero border (SAME padding) and a pixel stride PS chosen so that the 64 operand reads of an MFMA hit
 // 64 different banks (S * PS = 4 mod 64: bank = 4 lp + kq); the member's perturbed 16-column weight tile sits next to it.
 // Each wave owns two position tiles (two independent accumulators cover the dependent-MFMA latency).
-template <int CIN, int COUT, int K, int S, int HIN, int HOUT, int PAD, int PS>
+template <int CIN, int COUT, int K, int S, int HIN, int HOUT, int PAD, int PS, bool NOISE>
 __global__ __launch_bounds__(256) void k_lconv_mfma(FwdArgs A, const int *__restrict__ list, int w_off, int b_off,
                                                     const float *__restrict__ in_all, float *__restrict__ out_all,
                                                     int nsplit /* workgroups per member (1, 2 or 4): each takes NT / nsplit of the 16-channel tiles */) {
@@ -46,13 +46,13 @@ __global__ __launch_bounds__(256) void k_lconv_mfma(FwdArgs A, const int *__rest
     const int64_t off = A.m_off[m];
     const float *base = A.bases + (size_t)A.m_slot[m] * A.base_stride;
     const float *src = in_all + (size_t)m * (HIN * HIN * CIN);
+    // (staging loops unrolled 8 deep: a rolled loop pays one memory round trip per element -- this was the kernel's whole time)
+#pragma unroll 8
     for (int i = tid; i < HP * HP * CIN; i += 256) {
         const int ci = i % CIN, px = (i / CIN) % HP, py = i / (CIN * HP), x = px - PAD, y = py - PAD;
-        float v = 0.0f;
-        if (x >= 0 && x < HIN && y >= 0 && y < HIN) {
-            v = src[((size_t)y * HIN + x) * CIN + ci];
-            v = v > 0.0f ? v : 0.0f;                   // the previous layer's relu
-        }
+        const bool in = x >= 0 && x < HIN && y >= 0 && y < HIN;
+        float v = src[in ? ((size_t)y * HIN + x) * CIN + ci : 0];
+        v = in && v > 0.0f ? v : 0.0f;                 // zero border; the previous layer's relu
         xf[(py * HP + px) * PS + ci] = v;
     }
     const int tA = wv, tB = wv + 4;
@@ -63,13 +63,21 @@ __global__ __launch_bounds__(256) void k_lconv_mfma(FwdArgs A, const int *__rest
     const float *wl = wt + kq * 16 + lp;
     for (int tile = part * (NT / nsplit); tile < (part + 1) * (NT / nsplit); tile++) {
         __syncthreads();                               // the previous tile's readers are done (first pass: nothing to wait for)
+#pragma unroll 8
         for (int i = tid; i < KK * 16; i += 256) {
             const size_t p = (size_t)w_off + (size_t)(i >> 4) * COUT + tile * 16 + (i & 15);
-            float pv = sc * A.noise[off + p];
-            wt[i] = base[p] + pv;
+            float w = base[p];
+            if (NOISE) {                               // (materialised members are plain vectors: no noise row to add)
+                float pv = sc * A.noise[off + p];
+                w = base[p] + pv;
+            }
+            wt[i] = w;
         }
-        float pvb = sc * A.noise[off + b_off + tile * 16 + lp];
-        const float bias = base[b_off + tile * 16 + lp] + pvb;
+        float bias = base[b_off + tile * 16 + lp];
+        if (NOISE) {
+            float pvb = sc * A.noise[off + b_off + tile * 16 + lp];
+            bias = base[b_off + tile * 16 + lp] + pvb;
+        }
         __syncthreads();
         f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -274,6 +282,7 @@ __global__ __launch_bounds__(256) void k_lout(FwdArgs A, const int *__restrict__
         const float t = y4[(size_t)m * 512 + j];
         a4[j] = t > 0.0f ? t : 0.0f;
     }
+#pragma unroll 8
     for (int i = tid; i < 512 * nact; i += 256) {
         float pv = sc * A.noise[off + L.ow + i];
         wo_l[i] = base[L.ow + i] + pv;
