@@ -233,10 +233,26 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
         s.ram_cur[tid] = E.ram_cur[(size_t)m * 128 + tid];
     }
     {
+        // the flat layout is [k][action]; every logit's column becomes an LDS row.  Eight elements per thread are requested before the
+        // first is used: a rolled loop pays one memory round trip per element (18 of them at 18 actions -- most of this kernel's time)
         const float *wb = base + L.ow, *we = A.noise + off + L.ow;
-        for (int i = tid; i < 256 * nact; i += blockDim.x) {   // the flat layout is [k][action]; every logit's column becomes an LDS row
-            float pv = sc * we[i];
-            wo[(i % nact) * WS + i / nact] = wb[i] + pv;
+        const int nw = 256 * nact, stride = blockDim.x;
+        for (int i0 = tid; i0 < nw; i0 += 8 * stride) {
+            float ev[8], bv[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = i0 + j * stride;
+                ev[j] = i < nw ? we[i] : 0.0f;
+                bv[j] = i < nw ? wb[i] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int i = i0 + j * stride;
+                if (i < nw) {
+                    float pv = sc * ev[j];
+                    wo[(i % nact) * WS + i / nact] = bv[j] + pv;
+                }
+            }
         }
     }
     if constexpr (RENDER) synth_load_tables(s, E.T);
@@ -286,7 +302,13 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
         }
         const uint4 *src = (const uint4 *)(E.spec_stacks + ((size_t)spec_pos * SPEC_ACTIONS + best) * OB_BYTES);
         uint4 *dst = (uint4 *)(E.stacks + (size_t)m * OB_BYTES);
-        for (int i = tid; i < OB_BYTES / 16; i += blockDim.x) dst[i] = src[i];
+        for (int i0 = tid; i0 < OB_BYTES / 16; i0 += 8 * blockDim.x) {   // all of a thread's loads in flight before its first store
+            uint4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const int i = i0 + j * blockDim.x; if (i < OB_BYTES / 16) v[j] = src[i]; }
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const int i = i0 + j * blockDim.x; if (i < OB_BYTES / 16) dst[i] = v[j]; }
+        }
         return;
     }
     if (tid == 0) {
