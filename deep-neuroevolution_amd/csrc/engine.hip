@@ -560,6 +560,7 @@ struct dne_handle {
     float *fr1[2] = {nullptr, nullptr}, *fr2[2] = {nullptr, nullptr};   // per-frame batch-norm moments of conv1 / conv2 ([rows][2][C])
     hipEvent_t ev_ref[2] = {nullptr, nullptr};
     int *list_a = nullptr, *list_b = nullptr, *count_dev = nullptr;
+    int *count_host = nullptr;       // pinned: the active count comes back once per burst (a pageable destination makes the copy a staged, synchronous one)
     uint8_t *bc = nullptr; size_t bc_bytes = 0;
     float *mat_out = nullptr; size_t mat_cap = 0;
     float *scratch_f = nullptr; size_t scratch_cap = 0;   // small float scratch (ranks, weights)
@@ -939,6 +940,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
         }
     }
     CH(h->alloc(&h->list_a, M, "list_a")); CH(h->alloc(&h->list_b, M, "list_b")); CH(h->alloc(&h->count_dev, 8, "count_dev"));
+    CH(hipHostMalloc((void **)&h->count_host, 64, hipHostMallocDefault));
     if (cfg->record_bc) {
         h->bc_bytes = cfg->policy_kind == DNE_KIND_ES && !cfg->bc_final_only ? M * (size_t)std::max(cfg->bc_max_steps, 1) * 128 : M * 128;
         CH(h->alloc(&h->bc, h->bc_bytes, "bc"));
@@ -1003,6 +1005,7 @@ extern "C" void dne_destroy(dne_handle *h) {
         if (h->stage_ev[i]) hipEventDestroy(h->stage_ev[i]);
     }
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->count_host) hipHostFree(h->count_host);
     for (hipEvent_t e : h->fc_ring) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_ref) if (e) hipEventDestroy(e);
     if (h->ev_a) hipEventDestroy(h->ev_a);
@@ -1660,8 +1663,9 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
         for (int s = 1; s < nsub; s++) HCHECK(h, hipStreamSynchronize(h->sub_streams[s]));
         hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, (const int32_t *)h->done, gsize, (const int *)cur,
                            total, nxt, h->count_dev);
-        HCHECK(h, hipMemcpyAsync(&total, h->count_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HCHECK(h, hipMemcpyAsync(h->count_host, h->count_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HCHECK(h, hipStreamSynchronize(h->stream));
+        total = *h->count_host;
         std::swap(cur, nxt);
         h->trace("eval: lock-step %d, %d active groups", t, total);
     }
