@@ -2,7 +2,8 @@
 # Run on the MI355X box (gpurun -- 'bash tools/collect_profiles.sh r02p'): everything profiles/ and DESIGN.md sections 4 / 9 quote.
 #   bench line (defaults) and the driver's command (--steps 20 --warmup 5); rocprofv3 kernel stats of the default command;
 #   the two HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE, each in its own run, kernel-trace only) over one full-width lock-step
-#   workload; the matrix-core PMC pass (tools/collect_pmc_mfma.sh); the env-free micro-benchmarks; GA / NS-ES benches;
+#   workload; the matrix-core PMC pass (tools/collect_pmc_mfma.sh); the env-free micro-benchmarks; GA (small network and the GPU tree's
+#   LargeModel, with its kernel stats) / NS-ES benches; the six-game sweep;
 #   population shares; lock-step length profiles; tail latency.
 # Outputs land in gpurun_out/<tag>/; `python tools/refresh_profiles.py gpurun_out/<tag> r02` copies the summaries into profiles/.
 set -u
@@ -21,6 +22,10 @@ bash "$R/tools/collect_pmc_mfma.sh" "$TAG" > /dev/null 2>&1
 python "$R/tools/micro_bench.py" > "$O/micro.json" 2> "$O/micro.err"
 python "$R/tools/ga_bench.py" > "$O/ga_bench.jsonl" 2> "$O/ga_bench.err"
 python "$R/tools/nses_bench.py" > "$O/nses_bench.jsonl" 2> "$O/nses_bench.err"
+python "$R/tools/ga_bench.py" --large > "$O/ga_large_bench.jsonl" 2> "$O/ga_large_bench.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ga_large_stats" -o g -- python "$R/tools/ga_bench.py" --large > /dev/null 2>&1
+cp "$(find "$O/ga_large_stats" -name '*kernel_stats.csv' | head -1)" "$O/ga_large_kernel_stats.csv" 2>/dev/null
+python "$R/tools/six_game_sweep.py" > "$O/six_game_sweep.jsonl" 2> "$O/six_game_sweep.err"
 for p in 2500 1250 624; do python "$R/bench.py" --no-cpu-baseline --pop $p 2>/dev/null | tail -1; done > "$O/population_shares.jsonl"
 python "$R/tools/len_profile.py" --pairs 312 > "$O/len_profile_312.json" 2>/dev/null
 python "$R/tools/len_profile.py" --pairs 2500 > "$O/len_profile_2500.json" 2>/dev/null

@@ -19,7 +19,9 @@ for src, dst in (('bench_default.json', 'bench_default.json'), ('bench_driver_cm
                  ('bench_profiled.json', 'bench_under_rocprofv3.json'), ('micro.json', 'micro.json'), ('ga_bench.jsonl', 'ga_bench.jsonl'),
                  ('nses_bench.jsonl', 'nses_bench.jsonl'), ('population_shares.jsonl', 'population_shares.jsonl'),
                  ('len_profile_312.json', 'len_profile_312_pairs.json'), ('len_profile_2500.json', 'len_profile_2500_pairs.json'),
-                 ('tail_bench.json', 'tail_bench.json'), ('pmc_mfma/summary.json', 'pmc_mfma.json')):
+                 ('tail_bench.json', 'tail_bench.json'), ('pmc_mfma/summary.json', 'pmc_mfma.json'),
+                 ('ga_large_bench.jsonl', 'ga_large_bench.jsonl'), ('ga_large_kernel_stats.csv', 'ga_large_kernel_stats.csv'),
+                 ('six_game_sweep.jsonl', 'six_game_sweep.jsonl')):
     if os.path.exists(os.path.join(R, src)):
         shutil.copy(os.path.join(R, src), os.path.join(P, '%s_%s' % (PFX, dst)))
 ks = glob.glob(R + '/stats/**/*kernel_stats.csv', recursive=True)
