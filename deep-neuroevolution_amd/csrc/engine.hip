@@ -671,6 +671,21 @@ struct dne_handle {
 
 static int rec_reserve(dne_handle *h, int n_global, int per_world);
 
+// the two small scratch arrays (scratch_f floats, scratch_i int64s) hold at least n elements each afterwards; contents are not kept
+static int scratch_reserve(dne_handle *h, size_t n) {
+    if (n <= h->scratch_cap) return 0;
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = h->release(h->scratch_f);
+    if (e == hipSuccess) e = h->release(h->scratch_i);
+    h->scratch_cap = 0;
+    const size_t cap = std::max<size_t>(n, 65536);
+    if (e == hipSuccess) e = h->alloc(&h->scratch_f, cap, "scratch_f");
+    if (e == hipSuccess) e = h->alloc(&h->scratch_i, cap, "scratch_i");
+    if (e != hipSuccess) return h->fail("scratch_reserve(%zu): %s", n, hipGetErrorString(e));
+    h->scratch_cap = cap;
+    return 0;
+}
+
 // Every entry point runs on the handle's device whatever the calling thread's current device is, and puts the
 // caller's device back on the way out.
 struct DeviceGuard {
@@ -1156,7 +1171,7 @@ extern "C" int dne_materialize(dne_handle *h, const int64_t *idx, int n, float s
         HCHECK(h, h->alloc(&h->mat_out, need, "mat_out"));
         h->mat_cap = need;
     }
-    if ((size_t)n > h->scratch_cap) return h->fail("too many pairs");
+    if (scratch_reserve(h, (size_t)n)) return -1;
     HCHECK(h, hipMemcpyAsync(h->scratch_i, idx, n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
     HCHECK(h, hipEventRecord(h->ev_a, h->stream));
     hipLaunchKernelGGL(k_materialize, dim3((h->L.P + 255) / 256, n), dim3(256), 0, h->stream, h->bases, h->noise,
@@ -1316,8 +1331,7 @@ static int ref_pass(dne_handle *h, int n) {
             hipLaunchKernelGGL((k_fc<8, true, true, 4>), dim3((nc + 7) / 8 * 8 * nfg), dim3(256), 0, st, A,
                                (const int *)nullptr, nc, F, m0, (const float *)y2, y3p, (int32_t *)nullptr,
                                (float *)nullptr);
-            hipLaunchKernelGGL((k_bn_stats<256, 1>), dim3(nc), dim3(256), 0, st, A, m0, F, (const float *)y3p,
-                               96, h->L.bn3b, h->L.bn3g);
+            hipLaunchKernelGGL(k_bn3_rows, dim3(nc), dim3(256), 0, st, A, m0, F, (const float *)y3p);
         }
     }
     if (nways > 1) {
@@ -1806,6 +1820,7 @@ extern "C" int dne_ga_set_init_scale(dne_handle *h, const float *scale_by, size_
     if (!h->init_scale) HCHECK(h, h->alloc(&h->init_scale, n, "init_scale"));
     HCHECK(h, hipMemcpy(h->init_scale, scale_by, n * sizeof(float), hipMemcpyHostToDevice));
     h->ga_cache.clear();
+    h->child_slots.clear();          // every slot but 0 is free again -- including the ones set aside for materialised children
     h->free_slots.clear();
     for (int s2 = h->base_cap - 1; s2 >= 1; s2--) h->free_slots.push_back(s2);
     return 0;
@@ -1871,6 +1886,8 @@ static int ga_eval_impl(dne_handle *h, const int32_t *co, const int64_t *seeds, 
         const int len = co[i + 1] - co[i];
         if (len < 1) return h->fail("member %d has an empty seed chain", i);
         const int64_t *c = seeds + co[i];
+        for (int j = 0; j < len; j++)
+            if (check_noise_range(h, c[j], h->L.P)) return -1;
         const float *pw = powers ? powers + co[i] : nullptr;
         if (len == 1) { prefix[i] = key_of(c, pw, 1); off[i] = c[0]; sc[i] = 0.0f; }
         else { prefix[i] = key_of(c, pw, len - 1); off[i] = c[len - 1]; sc[i] = powers ? pw[len - 1] : sigma; }
@@ -1909,7 +1926,7 @@ static int ga_eval_impl(dne_handle *h, const int32_t *co, const int64_t *seeds, 
             }
         const int nr = (int)rslot.size();
         if (nr > 0) {
-            if ((size_t)nr > h->scratch_cap) return h->fail("too many fresh genomes");
+            if (scratch_reserve(h, (size_t)nr)) return -1;
             int32_t *d_slot = (int32_t *)h->scratch_f;
             HCHECK(h, hipMemcpyAsync(d_slot, rslot.data(), nr * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
             HCHECK(h, hipMemcpyAsync(h->scratch_i, roff.data(), nr * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
@@ -1982,7 +1999,7 @@ static int ga_eval_impl(dne_handle *h, const int32_t *co, const int64_t *seeds, 
         }
         const int nm = (int)mp.size();
         if (nm > 0) {
-            if ((size_t)3 * nm > h->scratch_cap) return h->fail("too many children to materialise");
+            if (scratch_reserve(h, (size_t)3 * nm)) return -1;
             int32_t *d_ps = (int32_t *)h->scratch_f, *d_cs = d_ps + nm;
             float *d_sc = h->scratch_f + 2 * nm;
             HCHECK(h, hipMemcpyAsync(d_ps, mp.data(), nm * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
@@ -2133,12 +2150,7 @@ static int rec_reserve(dne_handle *h, int n_global, int per_world) {
         h->rec_wire_cap = wire;
     }
     // scratch for processed returns [2N] + raw copy [2N] + weights [N]
-    if ((size_t)5 * n_global + 64 > h->scratch_cap) {
-        HCHECK(h, h->release(h->scratch_f)); HCHECK(h, h->release(h->scratch_i));
-        h->scratch_cap = (size_t)5 * n_global + 64;
-        HCHECK(h, h->alloc(&h->scratch_f, h->scratch_cap, "scratch_f")); HCHECK(h, h->alloc(&h->scratch_i, h->scratch_cap, "scratch_i"));
-    }
-    return 0;
+    return scratch_reserve(h, (size_t)5 * n_global + 64);
 }
 
 struct Rccl {   // the few entry points of librccl.so the exchange needs

@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int memb
 }
 
 // bn3 statistics from the four k-slice partials: y3 = ((p0+p1)+(p2+p3)) + bias per frame, then the batch
-// moments over the F frames in frame order (same order as k_bn_stats<256, 1>); one thread per column.
+// moments over the F frames in frame order (same order as k_bn3_rows); one thread per column.
 __global__ __launch_bounds__(256) void k_bn3_partials(FwdArgs A, int member0, int F, const float *__restrict__ y3p) {
     const int mloc = blockIdx.x, member = member0 + mloc, j = threadIdx.x;
     const Layout &L = A.L;
@@ -1851,74 +1851,39 @@ __global__ __launch_bounds__(256) void k_bn_finalize(FwdArgs A, int member0, int
     A.bn_mom[(size_t)member * 608 + bn_off + C + c] = var;
 }
 
-// -------------------------------------------------------------- virtual batch norm statistics
-// tf.contrib.layers.batch_norm(is_training=True, decay=0): batch moments over (N, H, W), biased
-// variance, written as per-channel scale = gamma * rsqrt(var + 1e-3), shift = beta - mean * scale
-// (tf.nn.batch_normalization).  Summation order = the oracle's: per frame sequential over positions,
-// then sequential over frames.  One workgroup per member of the chunk.
-template <int C, int NPOS>
-__global__ __launch_bounds__(256) void k_bn_stats(FwdArgs A, int member0, int F, const float *__restrict__ y,
-                                                  int bn_off, int beta_off, int gamma_off) {
-    extern __shared__ float bn_part[];   // [F][C] when NPOS > 1
-    __shared__ float mean_s[C];
-    const int mloc = blockIdx.x, member = member0 + mloc, tid = threadIdx.x;
-    const float *ym = y + (size_t)mloc * F * NPOS * C;
-    const float count = (float)(F * NPOS);
-    if (NPOS > 1) {
-        for (int i = tid; i < F * C; i += 256) {
-            const int n = i / C, c = i % C;
-            const float *p = ym + (size_t)n * NPOS * C + c;
-            float s = 0.0f;
-            for (int q = 0; q < NPOS; q++) s = s + p[(size_t)q * C];
-            bn_part[i] = s;
-        }
-        __syncthreads();
+// -------------------------------------------------------------- virtual batch norm statistics of the fc layer, generic batch sizes
+// tf.contrib.layers.batch_norm(is_training=True, decay=0): batch moments over the F reference frames, biased variance, written
+// as per-column scale = gamma * rsqrt(var + 1e-3), shift = beta - mean * scale (tf.nn.batch_normalization); two passes in frame
+// order like the oracle's bn_finish.  y: [n_local][F][256] finished fc rows (the reference batch sizes the matrix-core fc does
+// not take: k_fc<8, true> wrote them); the convolution layers' moments come out of the convolution epilogues (k_bn_finalize).
+__global__ __launch_bounds__(256) void k_bn3_rows(FwdArgs A, int member0, int F, const float *__restrict__ y) {
+    const int mloc = blockIdx.x, member = member0 + mloc, j = threadIdx.x;
+    const Layout &L = A.L;
+    const float *ym = y + (size_t)mloc * F * 256 + j;
+    const float count = (float)F;
+    float tot = 0.0f;
+    for (int n = 0; n < F; n++) tot = tot + (0.0f + ym[(size_t)n * 256]);
+    const float mean = tot / count;
+    float totq = 0.0f;
+    for (int n = 0; n < F; n++) {
+        const float d = ym[(size_t)n * 256] - mean;
+        totq = totq + __builtin_fmaf(d, d, 0.0f);
     }
-    if (tid < C) {
-        float tot = 0.0f;
-        for (int n = 0; n < F; n++) tot = tot + (NPOS > 1 ? bn_part[n * C + tid] : (0.0f + ym[(size_t)n * C + tid]));
-        mean_s[tid] = tot / count;
-    }
-    __syncthreads();
-    if (NPOS > 1) {
-        for (int i = tid; i < F * C; i += 256) {
-            const int n = i / C, c = i % C;
-            const float *p = ym + (size_t)n * NPOS * C + c;
-            const float mean = mean_s[c];
-            float qv = 0.0f;
-            for (int q = 0; q < NPOS; q++) {
-                float d = p[(size_t)q * C] - mean;
-                qv = __builtin_fmaf(d, d, qv);
-            }
-            bn_part[i] = qv;
-        }
-        __syncthreads();
-    }
-    if (tid < C) {
-        const float mean = mean_s[tid];
-        float totq = 0.0f;
-        for (int n = 0; n < F; n++) {
-            float qv;
-            if (NPOS > 1) qv = bn_part[n * C + tid];
-            else { float d = ym[(size_t)n * C + tid] - mean; qv = __builtin_fmaf(d, d, 0.0f); }
-            totq = totq + qv;
-        }
-        const float var = totq / count;
-        const float *base = A.bases + (size_t)A.m_slot[member] * A.base_stride;
-        const float *eps = A.noise + A.m_off[member];
-        const float sc = A.m_scale[member];
-        float pb = sc * eps[beta_off + tid];
-        const float beta = base[beta_off + tid] + pb;
-        float pg = sc * eps[gamma_off + tid];
-        const float gamma = base[gamma_off + tid] + pg;
-        const float inv = 1.0f / sqrtf(var + 1e-3f);
-        const float s = inv * gamma;
-        const float ms = mean * s;
-        A.bn[(size_t)member * 608 + bn_off + tid] = s;
-        A.bn[(size_t)member * 608 + bn_off + C + tid] = beta - ms;
-        A.bn_mom[(size_t)member * 608 + bn_off + tid] = mean;
-        A.bn_mom[(size_t)member * 608 + bn_off + C + tid] = var;
-    }
+    const float var = totq / count;
+    const float *base = A.bases + (size_t)A.m_slot[member] * A.base_stride;
+    const float *eps = A.noise + A.m_off[member];
+    const float sc = A.m_scale[member];
+    float pb = sc * eps[L.bn3b + j];
+    const float beta = base[L.bn3b + j] + pb;
+    float pg = sc * eps[L.bn3g + j];
+    const float gamma = base[L.bn3g + j] + pg;
+    const float inv = 1.0f / sqrtf(var + 1e-3f);
+    const float s = inv * gamma;
+    const float ms = mean * s;
+    A.bn[(size_t)member * 608 + 96 + j] = s;
+    A.bn[(size_t)member * 608 + 352 + j] = beta - ms;
+    A.bn_mom[(size_t)member * 608 + 96 + j] = mean;
+    A.bn_mom[(size_t)member * 608 + 352 + j] = var;
 }
 
 }  // namespace dne

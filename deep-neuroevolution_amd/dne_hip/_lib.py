@@ -56,7 +56,7 @@ class Profile(C.Structure):
 
 def build(force=False):
     """Compile libdne_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("engine.hip", "forward.h", "reduce.h", "env_synth.h")]
+    srcs = [os.path.join(_CSRC, f) for f in ("engine.hip", "forward.h", "forward_large.h", "reduce.h", "env_synth.h")]
     srcs.append(os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include", "dne_hip.h"))
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
         subprocess.check_call(["make", "-C", _CSRC, "-s"])

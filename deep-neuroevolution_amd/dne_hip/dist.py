@@ -6,8 +6,10 @@ Two carriers behind the same methods:
   * Redis -- the reference's own deployment.  The `redis` package is used when importable; otherwise the small RESP
     client in resp.py speaks to the server directly (this image has neither the package nor a server).
   * an in-process broker -- master and GPU worker(s) as threads of one process, no server, nothing pickled.
-    Chosen with redis_cfg['transport'] = 'inprocess', or automatically when no Redis answers at the address
-    (transport 'auto', the default; 'redis' insists and retries like dist.py:27-43).
+    Only on request: redis_cfg['transport'] = 'inprocess' (or DNE_TRANSPORT=inprocess in the environment).
+A configuration that names a server (host / unix_socket_path) means Redis and behaves like the reference: 300 connection
+attempts, then the error (dist.py:27-43) -- a worker that cannot reach its master must not quietly wait on a private broker.
+transport = 'auto' (one attempt, then the in-process broker, with a warning) exists for single-process experiments.
 """
 import logging
 import os
@@ -88,16 +90,35 @@ def retry_get(r, key, tries=300, base_delay=4.):
 
 def _carrier(redis_cfg):
     """-> ('redis', connection) or ('inprocess', broker)"""
-    mode = redis_cfg.get('transport', 'auto') if isinstance(redis_cfg, dict) else 'inprocess'
+    if not isinstance(redis_cfg, dict):
+        return 'inprocess', _broker(redis_cfg)
+    names_server = any(redis_cfg.get(k) for k in ('host', 'unix_socket_path', 'port'))
+    mode = redis_cfg.get('transport') or os.environ.get('DNE_TRANSPORT') or ('redis' if names_server else 'inprocess')
     if mode == 'inprocess':
         return 'inprocess', _broker(redis_cfg)
     if mode == 'redis':
         return 'redis', retry_connect(redis_cfg)
+    if mode != 'auto':
+        raise ValueError('unknown transport {!r} (redis, inprocess, auto)'.format(mode))
+    _, conn_err = _redis_module()
     try:                                  # auto: one attempt, then the in-process broker
         return 'redis', retry_connect(redis_cfg, tries=1, connect_timeout=2.0)
-    except Exception as e:
-        logger.info('no Redis at {} ({}): using the in-process broker'.format(redis_cfg, e))
+    except (conn_err, ConnectionError, OSError) as e:
+        logger.warning('no Redis at {} ({}): transport "auto" falls back to the in-process broker -- only threads of THIS '
+                       'process can meet there'.format(redis_cfg, e))
         return 'inprocess', _broker(redis_cfg)
+
+
+def _wait_inprocess(cv, ready, what):
+    """Block on the in-process broker until ready() -- called with cv held.  Nobody outside this process can ever satisfy the
+    wait, so it is bounded (DNE_INPROCESS_TIMEOUT seconds, default 1200: 300 tries x 4 s of dist.py:46-64) and ends in the
+    reference's error instead of a silent hang."""
+    deadline = time.time() + float(os.environ.get('DNE_INPROCESS_TIMEOUT', '1200'))
+    while not ready():
+        left = deadline - time.time()
+        if left <= 0:
+            raise RuntimeError('{} not set (in-process broker: no master thread in this process declared it)'.format(what))
+        cv.wait(min(left, 5.0))
 
 
 _brokers = {}
@@ -267,8 +288,7 @@ class WorkerClient:
         if self.kind == 'redis':
             return deserialize(retry_get(self.local, EXP_KEY))
         with self.master.cv:
-            while self.master.exp is None:
-                self.master.cv.wait()
+            _wait_inprocess(self.master.cv, lambda: self.master.exp is not None, EXP_KEY)
             return self.master.exp
 
     def get_archive(self):
@@ -291,8 +311,7 @@ class WorkerClient:
                 task_id = int(retry_get(self.local, TASK_ID_KEY))
             return self.cached_task_id, self.cached_task_data
         with self.master.cv:
-            while self.master.task_data is None:
-                self.master.cv.wait()
+            _wait_inprocess(self.master.cv, lambda: self.master.task_data is not None, TASK_DATA_KEY)
             return self.master.task_id, self.master.task_data
 
     def push_result(self, task_id, result):

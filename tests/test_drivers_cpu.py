@@ -22,7 +22,7 @@ def test_ga_master_worker(oracle, tmp_path):
     exp = _ga_exp(children=6, parents=3, tslimit=25)
     noise = es.SharedNoiseTable(count=2_500_000)
     me, we = OracleEngine(1), OracleEngine(1)
-    cfg = {"unix_socket_path": "/tmp/test_ga.sock"}
+    cfg = {"unix_socket_path": "/tmp/test_ga.sock", "transport": "inprocess"}
     out = {}
     tm = threading.Thread(target=lambda: out.update(r=ga.run_master(cfg, str(tmp_path), exp, engine=me, noise=noise, max_iters=3)), daemon=True)
     tm.start()
@@ -53,7 +53,7 @@ def test_nses_master_worker(oracle, tmp_path):
            "optimizer": {"args": {"stepsize": 0.01}, "type": "adam"}, "policy": {"args": {}, "type": "ESAtariPolicy"}}
     noise = es.SharedNoiseTable(count=2_500_000)
     me, we = OracleEngine(0, ref_count=16, bc_max_steps=10), OracleEngine(0, ref_count=16, bc_max_steps=10)
-    cfg = {"unix_socket_path": "/tmp/test_ns.sock"}
+    cfg = {"unix_socket_path": "/tmp/test_ns.sock", "transport": "inprocess"}
     out = {}
     tm = threading.Thread(target=lambda: out.update(r=nses.run_master(cfg, str(tmp_path), exp, engine=me, noise=noise, max_iters=2)), daemon=True)
     tm.start()

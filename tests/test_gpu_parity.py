@@ -357,7 +357,7 @@ def test_ga_driver_on_device(hip, oracle, small_noise, tmp_path):
     noise = es.SharedNoiseTable(count=small_noise.size)
     me = hip.Engine(hip.KIND_GA, NACT, max_members=16)
     we = hip.Engine(hip.KIND_GA, NACT, max_members=16)
-    cfg = {"unix_socket_path": "/tmp/gpu_ga.sock"}
+    cfg = {"unix_socket_path": "/tmp/gpu_ga.sock", "transport": "inprocess"}
     out = {}
     tm = threading.Thread(target=lambda: out.update(r=ga.run_master(cfg, str(tmp_path), exp, engine=me, noise=noise, max_iters=2)), daemon=True)
     tm.start()
@@ -417,7 +417,7 @@ def test_nses_driver_on_device(hip, oracle, small_noise, tmp_path):
     noise = es.SharedNoiseTable(count=small_noise.size)
     mk = lambda: hip.Engine(hip.KIND_ES, NACT, max_members=8, ref_count=NREF, record_bc=True, bc_max_steps=tsl)
     me, we = mk(), mk()
-    cfg = {"unix_socket_path": "/tmp/gpu_ns.sock"}
+    cfg = {"unix_socket_path": "/tmp/gpu_ns.sock", "transport": "inprocess"}
     out, pushed = {}, []
     orig_push = dist.WorkerClient.push_result
 

@@ -104,7 +104,7 @@ def test_run_master_run_worker_in_process(oracle, small_noise, tmp_path):
     exp = _exp(pop=8, tslimit=12)
     noise = es.SharedNoiseTable(count=2_500_000)
     master_engine, worker_engine = OracleEngine(0, ref_count=16), OracleEngine(0, ref_count=16)
-    cfg = {"unix_socket_path": "/tmp/test_master.sock"}
+    cfg = {"unix_socket_path": "/tmp/test_master.sock", "transport": "inprocess"}
     out = {}
 
     def master():

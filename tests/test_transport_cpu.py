@@ -83,8 +83,8 @@ def test_es_over_redis_protocol_matches_in_process(oracle, tmp_path):
     finally:
         srv.close()
     dist.reset_brokers()
-    th_local = _run_es({"unix_socket_path": "/tmp/dne_test_m.sock"}, {"unix_socket_path": "/tmp/dne_test_relay.sock"},
-                       {"unix_socket_path": "/tmp/dne_test_m.sock"}, tmp_path / "b")
+    local = {"unix_socket_path": "/tmp/dne_test_m.sock", "transport": "inprocess"}
+    th_local = _run_es(local, {"unix_socket_path": "/tmp/dne_test_relay.sock", "transport": "inprocess"}, dict(local), tmp_path / "b")
     assert np.array_equal(th_redis, th_local)
 
 
@@ -213,3 +213,31 @@ print("reused")
     from dne_hip import es, ga
     assert es.Result.__module__ == "es_distributed.es" and ga.GATask.__module__ == "es_distributed.ga"
     assert getattr(sys.modules["es_distributed.es"], "Result") is es.Result
+
+
+def test_a_named_server_means_redis_and_the_inprocess_wait_is_bounded(monkeypatch):
+    """A configuration that names a server and says nothing else must behave like the reference (retry, then raise:
+    dist.py:27-43) -- not fall back to a private in-process broker on which a worker would wait forever.  The in-process
+    broker is opt-in, and its waits end in the reference's '... not set' error."""
+    from dne_hip import dist
+    calls = []
+
+    def fake_connect(cfg, tries=300, base_delay=4., connect_timeout=None):
+        calls.append((dict(cfg), tries))
+        raise dist._redis_module()[1]("no server")
+    monkeypatch.setattr(dist, "retry_connect", fake_connect)
+    monkeypatch.delenv("DNE_TRANSPORT", raising=False)
+    for cfg in ({"unix_socket_path": "/tmp/dne_nobody_listens.sock"}, {"host": "127.0.0.1", "port": 1}):
+        with pytest.raises(Exception, match="no server"):
+            dist.MasterClient(cfg)
+        assert calls[-1][1] == 300                               # the reference's patience, not a single probe
+    with pytest.raises(ValueError):
+        dist.MasterClient({"host": "x", "transport": "carrier-pigeon"})
+    kind, _ = dist._carrier({"host": "127.0.0.1", "port": 1, "transport": "auto"})   # explicit: one probe, then in-process
+    assert kind == "inprocess" and calls[-1][1] == 1
+    dist.reset_brokers()
+    monkeypatch.setenv("DNE_INPROCESS_TIMEOUT", "0.3")
+    w = dist.WorkerClient({"transport": "inprocess"}, {"transport": "inprocess"})
+    with pytest.raises(RuntimeError, match="es:exp not set"):
+        w.get_experiment()
+    dist.reset_brokers()
