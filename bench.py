@@ -2,7 +2,12 @@
 """bench.py -- env-steps/sec/generation of the ES hot path (BASELINE.json metric) on N MI355X GPUs.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 needs no wrapper: this process then launches the N ranks itself, one per device (RANK / LOCAL_RANK / WORLD_SIZE in their
+environment, the RCCL id and the ranks' agreement on the carrier travelling through pipes it owns) -- the launcher side of
+gpu_implementation/neuroevolution/concurrent_worker.py:129-142, which starts one worker per visible device.  Under an
+external launcher (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N) the ranks it started are used as
+they are and meet through a private directory keyed by the launcher's pid and MASTER_PORT.
 
 A "step" is one ES generation of the workload named in config.workload: sample the noise indices, evaluate
 every antithetic pair of the population (reset, virtual-batch-norm reference pass, lock-step act -> env.step
@@ -12,11 +17,16 @@ sum -> Adam on every rank.  The population (pop 5000 = 2500 pairs) is sharded ro
 Inputs (noise table, theta, reference batch) are resident in HBM before the timed region.
 value = sum of episode lengths over all ranks and timed generations / max-over-ranks wall time (es.py:332,341).
 
-This process never imports torch: the engine is reached through ctypes, device synchronisation is
-hipDeviceSynchronize inside the C ABI, and for N > 1 the exchange, the barrier and the max/sum over ranks are
-RCCL calls behind dne_comm_* (the ranks find each other through RANK / WORLD_SIZE / MASTER_PORT of the launcher;
-the 128-byte RCCL id travels through a file in /tmp, all ranks being on one node).  So the HIP runtime in this
-process is the one libdne_hip.so was built against (/opt/rocm), the same one the GPU tests run on.
+After the headline region the same command times BASELINE.json's other configurations (tools/workloads.py: Deep GA on both
+networks, the NS-ES meta-population loop, the six-game loop, the 2-worker CPU reference path) and reports them under "extra",
+each with its own roofline / CPU baseline.  Default: on at N = 1, off at N > 1 (--extra all turns them on there; they then run
+sharded over the same ranks and borrow the headline engine's communicator).
+
+The ranks never import torch on the RCCL path: the engine is reached through ctypes, device synchronisation is
+hipDeviceSynchronize inside the C ABI, and the exchange, the barrier and the max / sum over ranks are RCCL calls behind
+dne_comm_*.  So the HIP runtime in the process is the one libdne_hip.so was built against (/opt/rocm), the same one the GPU
+tests run on.  If the ranks cannot build an RCCL communicator they agree -- all of them, explicitly -- on carrying the same
+32-byte records over gloo instead; the JSON line says which carrier ran ("comm").
 
 Environment: ALE and ROMs do not exist in this image, so the emulator under wrap_deepmind is the
 Frostbite-shaped SynthAtari fixture -- stated in "data".
@@ -24,13 +34,18 @@ Frostbite-shaped SynthAtari fixture -- stated in "data".
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "deep-neuroevolution_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 ALG_BYTES_PER_ENV_STEP = 4 * 1009058 + 28224   # all member weights once + the u8 observation stack
 HBM_PEAK = 8.0e12                              # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -46,7 +61,8 @@ FC_KERNELS = {   # the kernel behind the profiled ("full") fc launches of one ev
     1: "dne::k_fc<2, false, true, 4> (streaming fc + bn + out + argmax, one pair per work item: every window with > 96 active "
        "pairs; the rank's share is too small for k_fc2)",
 }
-PMC_PROFILE = os.path.join("profiles", "r02_pmc.json")
+PMC_PROFILES = (os.path.join("profiles", "r03_pmc.json"), os.path.join("profiles", "r02_pmc.json"), os.path.join("profiles", "r01_pmc.json"))
+EXTRAS = ("ga", "ga_large", "nses", "sweep", "config1")
 
 EXP = {
     "config": {"calc_obstat_prob": 0.0, "episodes_per_batch": 5000, "eval_prob": 0.0, "l2coeff": 0.005,
@@ -70,106 +86,149 @@ def crumb(msg):
 def cpu_baseline(noise, theta, ref, sigma, tslimit, n_actions):
     """The CPU oracle, structured like the reference workers (one single-threaded process per core, one
     antithetic pair at a time, batch-1 forwards, a reference pass per episode: es.py:366-439, launch.py:117),
-    timed on a bounded sample of generation 0 of the same workload.  Checker only -- never the product path.
-    The reference's workers never idle (they loop over tasks), so the rate is steps per busy core-second
-    times the core count: sum(steps) / (sum(worker busy seconds) / cores)."""
-    import multiprocessing as mp
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as O
-    O.lib()
-    cores = os.cpu_count() or 1
-    from dne_hip import es
-    _, idx, seeds = es.generation_inputs(noise.size, theta.size, 2500, 0, 0, 1)
-    n = min(2 * cores, 2500)
-    global _BASE
-    _BASE = (noise, theta, ref, sigma, tslimit, n_actions, idx, seeds)
-    ctx = mp.get_context("fork")
-    t0 = time.time()
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_pair, range(n), chunksize=1)
-    wall = time.time() - t0
-    steps = int(sum(r[0] for r in res))
-    busy = float(sum(r[1] for r in res))
-    return {"value": steps / (busy / cores), "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "generation 0, first %d antithetic pairs (%d full episodes, %d env-steps) over %d single-threaded "
-                      "worker processes; %.1f busy core-seconds, %.1f s wall (wall-clock rate incl. stragglers and "
-                      "process start-up: %.0f steps/s)" % (n, 2 * n, steps, cores, busy, wall, steps / wall)}
-
-
-def _cpu_pair(i):
-    os.environ["OMP_NUM_THREADS"] = "1"
-    import oracle as O
-    noise, theta, ref, sigma, tslimit, n_actions, idx, seeds = _BASE
-    L = O.layout(O.KIND_ES, n_actions)
-    t0 = time.time()
-    _, _, ln = O.es_eval(L, theta, noise, idx[i:i + 1], sigma, tslimit, ref, seeds[2 * i:2 * i + 2])
-    return int(ln.sum()), time.time() - t0
+    timed on a bounded sample of generation 0 of the same workload (tools/workloads.py:cpu_es, which imports the oracle).
+    Checker only -- never the product path."""
+    import workloads
+    return workloads.cpu_es(noise, theta, ref, sigma, tslimit, n_actions)
 
 
 FC_KERNEL_TAG = {3: "k_fc_duo", 2: "k_fc2", 1: "k_fc<"}
 
 
-def _pmc_traffic(kind):
+def _pmc_traffic(kind, units_per_launch):
     """HBM bytes per env-step of the streaming fc kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled for the
     16-byte streaming loads as MI355X_MICROARCH.md prescribes, plus WRITE_SIZE; collected by tools/collect_profiles.sh in
-    separate --pmc runs of a full-width workload).  It is a property of the kernel measured under the profiler, NOT a
-    measurement of this run: bench.py cannot read hardware counters in-process.  (None, None) if no profile is committed."""
-    for rel in (PMC_PROFILE, os.path.join("profiles", "r01_pmc.json")):
+    separate --pmc runs).  Round 3's file holds several regimes (window sizes): the one whose units per launch is closest to
+    this run's is used.  It is a property of the kernel measured under the profiler, NOT a measurement of this run: bench.py
+    cannot read hardware counters in-process.  (None, None, None) if no profile is committed."""
+    for rel in PMC_PROFILES:
         p = os.path.join(ROOT, rel)
-        if os.path.exists(p):
-            try:
-                k = json.load(open(p))["k_fc_step"]
-                if FC_KERNEL_TAG.get(kind, "?") in k["kernel"]:   # counters of another kernel say nothing about this one
-                    return float(k["hbm_bytes_per_unit"]), rel
-            except Exception:
-                pass
-    return None, None
-
-
-def rccl_rendezvous(_lib, engine, rank, world):
-    """All ranks are children of one launcher on one node: rank 0 draws the RCCL id and publishes it through a file
-    keyed by the launcher's pid and MASTER_PORT; the others wait for it.  Then every rank joins the communicator."""
-    path = os.environ.get("DNE_RCCL_ID_FILE") or "/tmp/dne_rccl_id.%s.%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
-    if rank == 0:
+        if not os.path.exists(p):
+            continue
         try:
-            uid = _lib.comm_unique_id()
-        except _lib.DneError:
-            uid = None
-        with open(path + ".tmp", "wb") as f:
-            f.write(uid if uid is not None else b"!")   # a one-byte file tells the waiting ranks that there will be no id
-        os.replace(path + ".tmp", path)
-        if uid is None:
-            raise _lib.DneError("rank 0 could not open RCCL")
-    else:
-        deadline = time.time() + 600
+            d = json.load(open(p))
+            regimes = d.get("regimes")
+            if regimes:
+                ok = [r for r in regimes if FC_KERNEL_TAG.get(kind, "?") in r["kernel"]]
+                if ok:
+                    best = min(ok, key=lambda r: abs(np.log(max(r["units_per_launch"], 1.0) / max(units_per_launch, 1.0))))
+                    return float(best["hbm_bytes_per_unit"]), rel, best.get("regime")
+            k = d["k_fc_step"]
+            if FC_KERNEL_TAG.get(kind, "?") in k["kernel"]:   # counters of another kernel say nothing about this one
+                return float(k["hbm_bytes_per_unit"]), rel, "one full-width window (DNE_NSUB=1, 2500 pairs)"
+        except Exception:
+            pass
+    return None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ rendezvous of the ranks
+class PipeRendezvous:
+    """Self-launched ranks: one line of JSON per message over the pair of pipes the launcher handed to this rank."""
+
+    def __init__(self, fds):
+        r, w = (int(x) for x in fds.split(","))
+        self.r, self.w = os.fdopen(r, "r"), os.fdopen(w, "w")
+
+    def _send(self, obj):
+        self.w.write(json.dumps(obj) + "\n"); self.w.flush()
+
+    def _recv(self):
+        line = self.r.readline()
+        if not line:
+            raise SystemExit("rank %d: the launcher closed the control pipe" % _RANK)
+        return json.loads(line)
+
+    def exchange_uid(self, rank, uid, err):
+        if rank == 0:
+            self._send({"uid": uid.hex() if uid else None, "err": err})
+        m = self._recv()
+        return (bytes.fromhex(m["uid"]) if m.get("uid") else None), m.get("err")
+
+    def vote(self, rank, world, ok, err):
+        self._send({"ok": bool(ok), "err": err})
+        return self._recv()
+
+    def done(self, rank):
+        pass
+
+
+class FileRendezvous:
+    """Ranks of an external launcher (torch.distributed.run): files in a directory only they can name -- the launcher's pid,
+    MASTER_PORT and its run id -- and only this user can read.  Files older than this launch are ignored."""
+
+    def __init__(self, world):
+        key = "%s.%s.%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
+        self.dir = os.environ.get("DNE_RDV_DIR") or os.path.join("/tmp", "dne_rdv.%d.%s" % (os.getuid(), key))
+        os.makedirs(self.dir, mode=0o700, exist_ok=True)
+        self.fresh = _T0 - 300
+
+    def _put(self, name, obj):
+        p = os.path.join(self.dir, name)
+        with open(p + ".tmp", "w") as f:
+            json.dump(obj, f)
+        os.replace(p + ".tmp", p)
+
+    def _get(self, name, timeout, what):
+        p, deadline = os.path.join(self.dir, name), time.time() + timeout
         while True:
             try:
-                uid = open(path, "rb").read()
-                if len(uid) == 128:
-                    break
-                if len(uid) == 1:
-                    raise _lib.DneError("rank 0 could not open RCCL")
-            except OSError:
+                if os.path.getmtime(p) >= self.fresh:
+                    return json.load(open(p))
+            except (OSError, ValueError):
                 pass
             if time.time() > deadline:
-                raise SystemExit("rank %d: no RCCL id at %s after 600 s" % (rank, path))
+                return None
             time.sleep(0.01)
-    engine.comm_init(rank, world, uid)
-    engine.barrier()
-    if rank == 0:
+
+    def exchange_uid(self, rank, uid, err):
+        if rank == 0:
+            for f in os.listdir(self.dir):               # leftovers of a crashed launch with the same key
+                try:
+                    os.unlink(os.path.join(self.dir, f))
+                except OSError:
+                    pass
+            self._put("uid", {"uid": uid.hex() if uid else None, "err": err})
+        m = self._get("uid", 600, "the RCCL id")
+        if m is None:
+            return None, "rank %d: no RCCL id from rank 0 after 600 s" % rank
+        return (bytes.fromhex(m["uid"]) if m.get("uid") else None), m.get("err")
+
+    def vote(self, rank, world, ok, err):
+        self._put("vote.%d" % rank, {"ok": bool(ok), "err": err})
+        votes = [self._get("vote.%d" % r, 400, "rank %d's vote" % r) for r in range(world)]
+        errors = ["rank %d: %s" % (r, (v or {}).get("err") or "no answer") for r, v in enumerate(votes) if not (v and v["ok"])]
+        return {"carrier": "gloo" if errors else "rccl", "errors": errors}
+
+    def done(self, rank):
+        if rank == 0:
+            shutil.rmtree(self.dir, ignore_errors=True)
+
+
+def comm_init_bounded(engine, rank, world, uid, timeout):
+    """ncclCommInitRank is a collective: if another rank never arrives it blocks.  It runs on its own host thread and this one
+    waits `timeout` seconds; a rank that gives up votes against RCCL and every rank then takes the other carrier."""
+    res = {}
+
+    def run():
         try:
-            os.unlink(path)
-        except OSError:
-            pass
+            engine.comm_init(rank, world, uid)
+            res["ok"] = True
+        except Exception as e:      # DneError with RCCL's own text
+            res["err"] = str(e)
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(timeout)
+    if t.is_alive():
+        return False, "ncclCommInitRank did not return within %d s" % timeout, True
+    return bool(res.get("ok")), res.get("err"), False
 
 
+# ------------------------------------------------------------------------------------------------ launchers
 def supervise():
     """N = 1 only: run the benchmark proper in a child process.  A GPU memory-access fault is raised by the HSA runtime as an
     abort of the whole process -- no exception, no JSON (the fate of round 1's driver run).  The child's breadcrumbs name the
     stage it died in; one retry with the engine's own trace on (DNE_TRACE=1) then either yields a complete, separately timed
     run -- reported with "attempts": 2 and the first attempt's last stage -- or a second, more detailed failure."""
-    import subprocess
-    import threading
     first = None
     for attempt in (1, 2):
         env = dict(os.environ, DNE_BENCH_CHILD="1")
@@ -210,60 +269,196 @@ def supervise():
     return rc if rc > 0 else 128 - rc
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pop", type=int, default=5000)
-    ap.add_argument("--tslimit", type=int, default=5000)
-    ap.add_argument("--noise-count", type=int, default=250_000_000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile-events", action="store_true")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "gloo"],
-                    help="exchange for N > 1: rccl = dne_comm_* (RCCL over xGMI behind the C ABI); gloo = torch.distributed on the "
-                         "host, only to exercise the multi-rank path on a box with fewer GPUs than ranks")
-    ap.add_argument("--single-device", action="store_true", help="testing aid: every rank uses GPU 0 (needs --transport gloo)")
-    ap.add_argument("--no-supervisor", action="store_true", help="N = 1: run in this process (no child, no retry)")
-    args = ap.parse_args()
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_supervisor and not os.environ.get("DNE_BENCH_CHILD"):
-        sys.exit(supervise())
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
+
+def launch_ranks(args, child_argv=None, check_devices=True):
+    """--gpus N > 1 without an external launcher: start the N ranks (one per device, or all on device 0 with --single-device),
+    carry the RCCL id from rank 0 to the others and the ranks' votes on the carrier back and forth, wait for them.  Rank 0
+    prints the JSON line; every rank's breadcrumbs go to this process's stderr."""
+    n = args.gpus
+    need = 1 if args.single_device else n
+    ndev = need
+    if check_devices:
+        from dne_hip import _lib
+        try:
+            ndev = _lib.device_count()
+        except _lib.DneError as e:
+            ndev = 0
+            crumb("device count unavailable: %s" % e)
+    if ndev < need:
+        sys.stderr.write("bench.py --gpus %d needs %d HIP devices, this box shows %d.  RCCL takes one rank per device; to exercise the "
+                         "%d-rank path on fewer devices run:  python bench.py --gpus %d --single-device --transport gloo\n"
+                         % (n, need, ndev, n, n))
+        return 2
+    if args.single_device and args.transport == "rccl":
+        sys.stderr.write("bench.py: --single-device puts every rank on device 0, which RCCL refuses; add --transport gloo\n")
+        return 2
+    port = _free_port()
+    procs, to_child, from_child = [], [], []
+    for r in range(n):
+        p2c_r, p2c_w = os.pipe()
+        c2p_r, c2p_w = os.pipe()
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), DNE_BENCH_CHILD="1", DNE_CTRL_FDS="%d,%d" % (p2c_r, c2p_w), DNE_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: what RCCL's peer-to-peer setup needs on this driver
+        procs.append(subprocess.Popen(child_argv or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      pass_fds=(p2c_r, c2p_w), stdout=None if r == 0 else subprocess.DEVNULL))
+        os.close(p2c_r); os.close(c2p_w)
+        to_child.append(os.fdopen(p2c_w, "w")); from_child.append(os.fdopen(c2p_r, "r"))
+
+    def recv(r):
+        try:
+            line = from_child[r].readline()
+            return json.loads(line) if line else None
+        except (OSError, ValueError):
+            return None
+
+    def send_all(obj):
+        for w in to_child:
+            try:
+                w.write(json.dumps(obj) + "\n"); w.flush()
+            except (OSError, ValueError):
+                pass
+
+    def control():
+        if args.transport != "rccl":
+            return
+        m = recv(0) or {"uid": None, "err": "rank 0 ended before it produced an RCCL id"}
+        send_all(m)
+        votes = [recv(r) for r in range(n)]
+        errors = ["rank %d: %s" % (r, (v or {}).get("err") or "ended without voting") for r, v in enumerate(votes) if not (v and v.get("ok"))]
+        send_all({"carrier": "gloo" if errors else "rccl", "errors": errors})
+    ct = threading.Thread(target=control, daemon=True)
+    ct.start()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                sys.stderr.write("[bench launcher] rank %d ended with rc %d: stopping the other ranks\n" % (r, code))
+                time.sleep(2.0)
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ the extra workloads
+def run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, transport_records, tslimit, want_cpu, small):
+    """BASELINE configs 1, 3, 4, 5 (tools/workloads.py), each timed on its own; a failure of one is reported in its slot.
+    small (--extra-small, the tests): the same code paths at a population of 96 / 48 children / two games."""
+    import workloads as W
+    out = {}
+    shared = dict(device_id=local_rank, rank=rank, world=world, comm_from=engine if transport_bytes is None else None, tslimit=tslimit)
+    ga_kw = dict(children=48, parents=6, generations=2) if small else {}
+    ns_kw = dict(pop=96, archive_extra=2, iterations=1) if small else {}
+    sw_kw = dict(pop=96, games=["frostbite", "asteroids"]) if small else {}
+
+    def leg(name, fn):
+        if name not in which:
+            return
+        crumb("extra: %s" % name)
+        t0 = time.time()
+        try:
+            out[name] = fn()
+            out[name]["bench_wall_s"] = time.time() - t0
+        except Exception as e:     # an extra never costs the headline line
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    leg("ga", lambda: W.ga_small(noise, transport=transport_bytes, **shared, **ga_kw))
+    if world == 1:
+        leg("ga_large", lambda: W.ga_large(noise, device_id=local_rank, tslimit=tslimit, **ga_kw))
+    leg("nses", lambda: W.nses(noise, transport=transport_bytes, **shared, **ns_kw))
+    leg("sweep", lambda: W.six_games(noise, transport=transport_records, **shared, **sw_kw))
+    if rank == 0 and want_cpu:
+        if "ga" in out and "error" not in out["ga"]:
+            crumb("extra: ga cpu baseline")
+            out["ga"]["cpu_baseline"] = W.cpu_ga(noise.noise, 0.005, tslimit, 18, children=ga_kw.get("children", 1000))
+        leg("config1", lambda: W.config1_cpu(noise.noise, tslimit=tslimit, sample_pairs=2 if small else 8))
+    return out
+
+
+def _gloo_allgather_bytes(buf, world):
+    """host all-gather of one numpy record array per rank (the GA / NS-ES drivers' `transport`)"""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(buf).view(np.uint8).reshape(-1).copy())
+    out = torch.empty(world * t.numel(), dtype=torch.uint8)
+    dist.all_gather_into_tensor(out, t)
+    return out.numpy().view(buf.dtype)
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.single_device:
         local_rank = 0
-
+    launcher = os.environ.get("DNE_LAUNCHER") or ("external (RANK / WORLD_SIZE found in the environment)" if world > 1 else "none")
     crumb("start: world %d, steps %d, warmup %d" % (world, args.steps, args.warmup))
     from dne_hip import _lib, es, policies   # loads libdne_hip.so (and with it /opt/rocm's HIP runtime) first
     n_pairs = args.pop // 2
     config = es.Config(**EXP["config"])
     my_pairs = len(es.shard_pairs(n_pairs, rank, world))
     try:
+        ndev = _lib.device_count()
+        if local_rank >= max(ndev, 1):
+            raise _lib.DneError("rank %d wants device %d, this box shows %d" % (rank, local_rank, ndev))
         engine = _lib.Engine(_lib.KIND_ES, 18, max_members=2 * my_pairs, ref_count=128, device_id=local_rank,
                              profile_events=not args.no_profile_events)
     except _lib.DneError as e:
-        raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback (%s)" % e)
+        raise SystemExit("bench.py needs %d MI355X device(s): the HIP engine has no CPU fallback (%s)" % (1 if args.single_device else world, e))
     crumb("engine created on device %d (%d pairs)" % (local_rank, my_pairs))
-    transport = None
-    use_gloo = world > 1 and args.transport == "gloo"
-    if world > 1 and args.transport == "rccl":
-        try:
-            rccl_rendezvous(_lib, engine, rank, world)
-            crumb("RCCL communicator ready")
-        except _lib.DneError as e:
-            # ncclCommInitRank fails on every rank or on none (same library, same topology): all ranks take the host path
-            # together.  The records are 32 bytes per pair, so the carrier decides nothing about the result, only ~1 ms of latency.
-            crumb("RCCL communicator could not be created (%s): falling back to the gloo carrier for the 32-byte records" % e)
-            use_gloo = True
-    if use_gloo:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        transport = es.allgather_records
+    comm = {"carrier": "none (one rank)", "launcher": launcher}
+    transport = transport_bytes = None
+    hung_init = False
+    rdv = None
+    if world > 1:
+        rdv = PipeRendezvous(os.environ["DNE_CTRL_FDS"]) if os.environ.get("DNE_CTRL_FDS") else FileRendezvous(world)
+        use_gloo = args.transport == "gloo"
+        if not use_gloo:
+            uid = err = None
+            if rank == 0:
+                try:
+                    uid = _lib.comm_unique_id()
+                except _lib.DneError as e:
+                    err = "rank 0 could not open RCCL: %s" % e
+            uid, err = rdv.exchange_uid(rank, uid, err)
+            ok = False
+            if uid is not None:
+                ok, err, hung_init = comm_init_bounded(engine, rank, world, uid, args.rccl_init_timeout)
+            decision = rdv.vote(rank, world, ok, err)
+            if decision["carrier"] == "rccl":
+                engine.barrier()
+                r_, n_, is_ = engine.comm_info()
+                comm.update({"carrier": "rccl", "nccl_comm_count": n_, "nccl_user_rank": r_})
+                crumb("RCCL communicator ready: ncclCommCount %d, ncclCommUserRank %d" % (n_, r_))
+            else:
+                # every rank takes this branch together (the launcher, or the vote files, handed all of them the same decision).
+                # The records are 32 bytes per pair: the carrier decides nothing about the result, only ~1 ms of latency.
+                engine.comm_abort()
+                use_gloo = True
+                comm["rccl_error"] = decision["errors"]
+                crumb("no RCCL communicator (%s): the 32-byte records travel over gloo" % "; ".join(decision["errors"]))
+        if use_gloo:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            transport, transport_bytes = es.allgather_records, _gloo_allgather_bytes
+            comm["carrier"] = "gloo"
     t0 = time.time()
     noise = es.SharedNoiseTable(count=args.noise_count)
     crumb("noise table sampled (%d floats)" % noise.noise.size)
@@ -327,6 +522,16 @@ def main():
     engine.check_redzones()   # raises if any kernel of the run wrote outside its device buffer
     crumb("red zones intact")
 
+    which = [x for x in (args.extra.split(",") if args.extra not in ("", "none", "all", "default") else
+                         (EXTRAS if args.extra == "all" or (args.extra == "default" and world == 1) else ())) if x]
+    for x in which:
+        if x not in EXTRAS:
+            raise SystemExit("--extra: unknown workload %r (choose from %s)" % (x, ", ".join(EXTRAS)))
+    extra = None
+    if which:
+        extra = run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, transport, args.tslimit,
+                           not args.no_cpu_baseline, args.extra_small)
+
     if rank == 0:
         value = total_steps / wall
         out = {
@@ -338,13 +543,15 @@ def main():
             "config": {"workload": "FrostbiteNoFrameskip-v4 ES pop=%d (N=%d antithetic pairs), Nature-CNN ESAtariPolicy "
                                    "(P=1009058, virtual batch norm over 128 reference frames), 84x84x4 u8, sigma=0.02, "
                                    "tslimit=%d, centered_rank + Adam(0.01) + l2 0.005" % (args.pop, n_pairs, args.tslimit),
-                       "pairs_per_gpu": my_pairs, "parallelism": "population sharded round-robin over %d GPU(s), "
-                                                                 "RCCL all-gather of 32-byte records, redundant update" % world},
+                       "pairs_per_gpu": my_pairs,
+                       "parallelism": "population sharded round-robin over %d GPU(s); all-gather of 32-byte records over %s; "
+                                      "redundant update on every rank" % (world, comm["carrier"])},
+            "comm": comm,
         }
-        per_unit, src = _pmc_traffic(fc_kind)
         if fc_ms > 0:
             avg_ms = fc_ms / fc_launches
             units_per_launch = fc_units / fc_launches
+            per_unit, src, regime = _pmc_traffic(fc_kind, units_per_launch)
             achieved = units_per_launch * ALG_BYTES_PER_ENV_STEP / (avg_ms * 1e-3)
             traffic = per_unit * units_per_launch if per_unit else None
             out["roofline"] = {
@@ -352,9 +559,10 @@ def main():
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                 "frac_algorithmic": achieved / HBM_PEAK,
                 "frac_counter": (traffic / (avg_ms * 1e-3) / HBM_PEAK) if traffic else None,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_regime": regime,
                 "traffic_source": ("%s: PMC bytes per env-step of this kernel from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + "
-                                   "WRITE_SIZE), scaled to this run's units per launch -- not measured in this run" % src) if src else None,
+                                   "WRITE_SIZE) at the regime named in traffic_regime, scaled to this run's units per launch -- not "
+                                   "measured in this run" % src) if src else None,
                 "algorithmic_bytes_per_unit": ALG_BYTES_PER_ENV_STEP, "unit_def": "one env-step of one member",
                 "units_per_launch": units_per_launch, "avg_launch_ms": avg_ms, "launches": int(fc_launches),
                 "note": "frac = frac_algorithmic = SURVEY 8d bytes (every member's weights once per env-step) / launch time / 8 TB/s; "
@@ -396,14 +604,56 @@ def main():
                                         "ms_per_generation": stage["ref_ms"] / args.steps}
         out["setup_s"] = {"noise_table": t_noise}
         out["theta_abs_sum_after"] = theta_sum
+        if extra is not None:
+            out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             crumb("cpu baseline")
             out["cpu_baseline"] = cpu_baseline(noise.noise, theta0, ref, config.noise_stdev, args.tslimit, 18)
         print(json.dumps(out), flush=True)
     if transport is not None:
+        dist.barrier()
         dist.destroy_process_group()
-    engine.close()
+    elif world > 1:
+        engine.barrier()
+    if rdv is not None:
+        rdv.done(rank)
     crumb("done")
+    if hung_init:       # a thread of this process is still inside ncclCommInitRank: leave without waiting for it
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
+    engine.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pop", type=int, default=5000)
+    ap.add_argument("--tslimit", type=int, default=5000)
+    ap.add_argument("--noise-count", type=int, default=250_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-events", action="store_true")
+    ap.add_argument("--extra", default="default",
+                    help="BASELINE configs timed after the headline region: comma list of %s, or all / none; default = all at N = 1, "
+                         "none at N > 1" % ", ".join(EXTRAS))
+    ap.add_argument("--extra-small", action="store_true", help="testing aid: the extra workloads at a population of 96")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "gloo"],
+                    help="exchange for N > 1: rccl = dne_comm_* (RCCL over xGMI behind the C ABI); gloo = torch.distributed on the "
+                         "host, only to exercise the multi-rank path on a box with fewer GPUs than ranks")
+    ap.add_argument("--single-device", action="store_true", help="testing aid: every rank uses GPU 0 (needs --transport gloo)")
+    ap.add_argument("--rccl-init-timeout", type=int, default=int(os.environ.get("DNE_RCCL_INIT_TIMEOUT", "180")))
+    ap.add_argument("--no-supervisor", action="store_true", help="N = 1: run in this process (no child, no retry)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    launched = "WORLD_SIZE" in os.environ or os.environ.get("DNE_BENCH_CHILD")
+    if not launched:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args))
+        if not args.no_supervisor:
+            sys.exit(supervise())
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -598,6 +598,8 @@ struct dne_handle {
     long long *nov_out = nullptr; size_t nov_out_cap = 0; int32_t *nov_len = nullptr; size_t nov_len_cap = 0;   // GA: the seed offsets of the chain being rebuilt
     // RCCL communicator (dne_comm_init); the library is opened on demand
     void *rccl_lib = nullptr; void *comm = nullptr; int comm_rank = 0, comm_size = 1;
+    bool comm_borrowed = false;      // dne_comm_share: the communicator belongs to another handle of this process
+    bool comm_off = false;           // dne_comm_abort: this handle takes no part in RCCL any more (a late dne_comm_init result is dropped)
     double *comm_scratch = nullptr;
 
     template <typename T>
@@ -2157,6 +2159,9 @@ struct Rccl {   // the few entry points of librccl.so the exchange needs
     ncclResult_t (*GetUniqueId)(ncclUniqueId *);
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
     ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*CommAbort)(ncclComm_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int *);
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *);
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     const char *(*GetErrorString)(ncclResult_t);
@@ -2171,6 +2176,7 @@ static const char *rccl_open() {   // nullptr on success, else the reason
     if (!lib) return dlerror();
 #define SYM(field, name) do { *(void **)&g_rccl.field = dlsym(lib, name); if (!g_rccl.field) return "librccl.so.1 lacks " name; } while (0)
     SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+    SYM(CommAbort, "ncclCommAbort"); SYM(CommCount, "ncclCommCount"); SYM(CommUserRank, "ncclCommUserRank");
     SYM(AllGather, "ncclAllGather"); SYM(AllReduce, "ncclAllReduce"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     g_rccl.lib = lib;
@@ -2201,14 +2207,61 @@ extern "C" int dne_comm_init(dne_handle *h, int rank, int nranks, const void *un
     ncclComm_t c = nullptr;
     h->trace("comm init: rank %d of %d", rank, nranks);
     NCHECK(h, g_rccl.CommInitRank(&c, nranks, id, rank));
+    if (h->comm_off) {   // the caller gave up on this initialisation (dne_comm_abort from another thread) while it was in flight
+        g_rccl.CommAbort(c);
+        return h->fail("dne_comm_init: communicator dropped, dne_comm_abort was called meanwhile");
+    }
     h->comm = c; h->comm_rank = rank; h->comm_size = nranks;
     HCHECK(h, h->alloc(&h->comm_scratch, 64, "comm_scratch"));
     h->trace("comm ready");
     return 0;
 }
 
+extern "C" int dne_comm_info(dne_handle *h, int *rank, int *nranks, int *is_rccl) {
+    int r = 0, n = 1;
+    if (h->comm) {
+        NCHECK(h, g_rccl.CommUserRank((ncclComm_t)h->comm, &r));
+        NCHECK(h, g_rccl.CommCount((ncclComm_t)h->comm, &n));
+    }
+    if (rank) *rank = r;
+    if (nranks) *nranks = n;
+    if (is_rccl) *is_rccl = h->comm ? 1 : 0;
+    return 0;
+}
+
+extern "C" int dne_device_count(int *count) {
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess && e != hipErrorNoDevice) { g_create_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); return -1; }
+    *count = e == hipSuccess ? n : 0;
+    return 0;
+}
+
 static void comm_destroy(dne_handle *h) {
-    if (h->comm) { g_rccl.CommDestroy((ncclComm_t)h->comm); h->comm = nullptr; }
+    if (h->comm && !h->comm_borrowed) g_rccl.CommDestroy((ncclComm_t)h->comm);
+    h->comm = nullptr;
+}
+
+// Several engines of one process (one per workload, all on the same device) take part in the collectives of one communicator:
+// `h` borrows the communicator `owner` built with dne_comm_init.  The calls of a process are issued by one host thread, engine
+// after engine, so their order is the same on every rank; the owner must outlive the borrower's last collective.
+extern "C" int dne_comm_share(dne_handle *h, dne_handle *owner) {
+    if (!owner || !owner->comm) return h->fail("dne_comm_share: the other handle has no communicator");
+    if (h->comm) return h->fail("dne_comm_share: communicator already initialised");
+    if (h->cfg.device_id != owner->cfg.device_id) return h->fail("dne_comm_share: the two handles are on different devices");
+    DeviceGuard dg(h);
+    h->comm = owner->comm; h->comm_rank = owner->comm_rank; h->comm_size = owner->comm_size; h->comm_borrowed = true;
+    HCHECK(h, h->alloc(&h->comm_scratch, 64, "comm_scratch"));
+    return 0;
+}
+
+// Give up on RCCL for this handle (the ranks agreed on another carrier): an existing communicator is aborted, one that a
+// still-running dne_comm_init on another thread produces later is dropped.  Afterwards the handle behaves like a single rank.
+extern "C" int dne_comm_abort(dne_handle *h) {
+    h->comm_off = true;
+    if (h->comm && !h->comm_borrowed && g_rccl.lib) g_rccl.CommAbort((ncclComm_t)h->comm);
+    h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1;
+    return 0;
 }
 
 // element-wise sum (op 0) or max (op 1) of n <= 64 doubles over all ranks; with n = 0 it is the barrier of bench.py

@@ -40,6 +40,14 @@ def comm_unique_id():
     return bytes(buf.raw)
 
 
+def device_count():
+    """HIP devices visible to this process (0 without a GPU)"""
+    n = C.c_int(0)
+    if load().dne_device_count(C.byref(n)) != 0:
+        raise DneError(load().dne_last_error(None).decode())
+    return n.value
+
+
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("device_id", "policy_kind", "n_actions", "max_members", "ref_count",
                                          "ref_chunk", "record_bc", "bc_max_steps", "profile_events", "bc_final_only")] + \
@@ -369,6 +377,21 @@ class Engine:
         buf = (C.c_char * 128).from_buffer_copy(unique_id)
         self._ck(self.lib.dne_comm_init(self.h, int(rank), int(nranks), buf))
         self.comm_size = int(nranks)
+
+    def comm_share(self, owner):
+        """take part in the RCCL communicator another engine of this process (same device) built with comm_init"""
+        self._ck(self.lib.dne_comm_share(self.h, owner.h))
+        self.comm_size = owner.comm_size
+
+    def comm_abort(self):
+        self._ck(self.lib.dne_comm_abort(self.h))
+        self.comm_size = 1
+
+    def comm_info(self):
+        """(rank, nranks, is_rccl) as the communicator itself reports them (ncclCommUserRank / ncclCommCount)"""
+        r, n, k = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self.lib.dne_comm_info(self.h, C.byref(r), C.byref(n), C.byref(k)))
+        return r.value, n.value, bool(k.value)
 
     def comm_allreduce(self, values, op="sum"):
         v = np.array(values, np.float64).reshape(-1)

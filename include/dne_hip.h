@@ -176,6 +176,15 @@ int dne_es_update(dne_handle *h, const int64_t *idx, const float *returns_n2, co
  * librccl.so.1 is opened on demand, single-GPU use never touches it. */
 int dne_comm_unique_id(void *out128);
 int dne_comm_init(dne_handle *h, int rank, int nranks, const void *unique_id128);
+/* what the communicator itself reports (ncclCommUserRank / ncclCommCount); without a communicator: rank 0 of 1, *is_rccl = 0.
+ * The launcher side of gpu_implementation/neuroevolution/concurrent_worker.py:129-142 (one worker per visible device) asks
+ * dne_device_count for the number of HIP devices this process can see. */
+int dne_comm_info(dne_handle *h, int *rank, int *nranks, int *is_rccl);
+int dne_device_count(int *count);
+/* a second engine of the same process and device (another workload) takes part in the owner's communicator */
+int dne_comm_share(dne_handle *h, dne_handle *owner);
+/* leave RCCL for good (the ranks agreed on another carrier, or an initialisation hangs on another thread) */
+int dne_comm_abort(dne_handle *h);
 /* sum (op 0) / max (op 1) of n <= 64 doubles over all ranks, then a device synchronise; n = 0: barrier */
 int dne_comm_allreduce(dne_handle *h, double *inout, int n, int op);
 /* generic all-gather of `bytes` host bytes per rank (the GA's 32-byte child records: parent index, fresh seed, return,

@@ -111,3 +111,30 @@ def test_deep_ga_driver_with_large_model(oracle, big_noise, tmp_path):
         assert state2.it == 3
     finally:
         e.close()
+
+
+def test_second_larger_run_on_one_engine_keeps_parents_intact(oracle, big_noise):
+    """Two runs on ONE engine, the second with more parents than the first reserved slots for: dne_ga_set_init_scale (every
+    ga_gpu.main) frees all base slots, including the ones set aside for materialised children -- those must not stay reserved for
+    children AND be handed to parents, or k_materialize_children writes a child over a live parent vector."""
+    from dne_hip import _lib, ga_gpu
+    e = _lib.Engine(_lib.KIND_GA_LARGE, NACT, max_members=16)
+    try:
+        e.noise_upload(big_noise)
+        O = oracle
+        L = O.layout(O.KIND_GA_LARGE, NACT)
+        sb = ga_gpu.model_scale_by(NACT, _lib.KIND_GA_LARGE)
+        e.ga_set_init_scale(sb)
+        seeds = np.arange(16, dtype=np.uint32) + 40
+        first = [(100_000 + 1000 * (i % 2), (7 + i, 0.002)) for i in range(6)]                # 2 parents, 6 materialised children
+        e.ga_eval_powers(first, 20, seeds[:6])
+        e.ga_set_init_scale(sb)                                                                 # what a second ga_gpu.main does
+        second = [(200_000 + 50_000 * (i % 7), (900 + i, 0.003)) for i in range(14)]          # 7 parents, 14 children
+        ret, sg, ln = e.ga_eval_powers(second, 30, seeds[:14])
+        for i, g in enumerate(second):
+            assert (ret[i], sg[i], ln[i]) == O.rollout(L, O.ga_gpu_rebuild(big_noise, g, sb), None, seeds[i], 30)[:3], i
+        with pytest.raises(_lib.DneError, match="noise index"):                                # a corrupt seed fails cleanly, before any kernel
+            e.ga_eval_powers([(100, (8_999_999, 0.002))], 5, seeds[:1])
+        assert e.check_redzones() == 0
+    finally:
+        e.close()

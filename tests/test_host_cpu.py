@@ -35,14 +35,25 @@ def test_engine_fails_loudly_without_gpu():
 
 
 def test_product_does_not_import_the_oracle():
+    import ast
     pkg = os.path.join(ROOT, "deep-neuroevolution_amd")
     for dp, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "dne_oracle" not in src and "libdne_oracle" not in src, f
+    # bench.py reaches the oracle only through the CPU-baseline legs of tools/workloads.py (cpu_es / cpu_ga / config1_cpu and
+    # their pool workers); nothing that runs on the GPU imports it
     bench = open(os.path.join(ROOT, "bench.py")).read()
-    assert bench.count("import oracle") == 2 and "def cpu_baseline" in bench   # only inside the cpu_baseline leg
+    assert "import oracle" not in bench and "def cpu_baseline" in bench
+    tree = ast.parse(open(os.path.join(ROOT, "tools", "workloads.py")).read())
+    users = set()
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        for node in ast.walk(fn):
+            if isinstance(node, ast.Import) and any(a.name == "oracle" for a in node.names):
+                users.add(fn.name)
+    assert users and all("cpu" in name or name == "_pool_rate" for name in users), users
+    assert not any(isinstance(n, ast.Import) and any(a.name == "oracle" for a in n.names) for n in tree.body)
 
 
 def test_flat_layout_and_init_match_oracle(oracle):
