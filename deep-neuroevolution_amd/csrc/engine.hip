@@ -46,6 +46,7 @@ struct EnvArgs {
     uint8_t *bc;
     int bc_mode;                     // 0 none, 1 RAM per step (ES, policies.py:410,418), 2 final RAM (GA, policies.py:510)
     int bc_max_steps;
+    int immortal;                    // DNE_DEBUG_IMMORTAL (timing experiments only): game over does not end the episode, only tslimit does
     // speculative tail (k_env_spec / k_env_render_spec / k_tail_select): the outcome of EVERY action from the current state,
     // indexed by (position in the active list, action)
     uint8_t *spec_prev, *spec_cur;   // [SPEC_CAP * 32][128] RAM rows before / after the step's last frame
@@ -130,7 +131,7 @@ __device__ __forceinline__ void env_commit(const EnvArgs &E, int m, const uint32
     E.len[m] = t + 1;
     E.stepped[m] = 1;
     if (E.step_counter) atomicAdd(E.step_counter, 1);
-    if (over || t + 1 >= tslimit) E.done[m] = 1;             // policies.py:401,424-425
+    if ((over && !E.immortal) || t + 1 >= tslimit) E.done[m] = 1;   // policies.py:401,424-425
 }
 
 // one wrapped step of member m (atari_wrappers.py:88-107 skip-4) + its bookkeeping; the caller is a single lane
@@ -187,28 +188,24 @@ __global__ __launch_bounds__(1024) void k_env_render(EnvArgs E, const int *__res
 // chosen action on one lane, and renders the new observation -- k_out + k_env_logic + k_env_render in one launch.
 struct RamLds { uint8_t ram_prev[128], ram_cur[128]; };
 
-constexpr int HEAD_WS = 260;   // row stride of the transposed output weights (16-byte aligned, spreads banks)
 template <bool RENDER>
 struct HeadLds {
     __attribute__((aligned(16))) std::conditional_t<RENDER, EnvLds, RamLds> s;
-    __attribute__((aligned(16))) float a3[256];
+    float red[4][1][OUT_NA];
     float lg[32];
-    __attribute__((aligned(16))) float wo[32 * HEAD_WS];   // [action][k]
 };
 
-// The policy head + emulator step of one member, by one workgroup (>= 256 threads).  Everything that does not depend on the fc
-// partial sums (the output-layer weights, the RAM rows, the resize tables) is issued before wait() -- a hook a producer /
-// consumer variant would block in; the kernels in use pass NoWait.
+// The policy head + emulator step of one member, by one workgroup (>= 256 threads; the first 256 are the output layer's 256
+// inputs: forward.h out_products / out_wave_sums).  Everything that does not depend on the fc partial sums (this thread's
+// output-layer weights, the RAM rows, the resize tables) is issued before wait() -- a hook a producer / consumer variant would
+// block in; the kernels in use pass NoWait.
 template <bool HAS_BN, bool RENDER, typename WaitFn>
 __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, const EnvArgs &E, int m, int tslimit,
                                           const float *__restrict__ y3t, float *__restrict__ y3, int32_t *__restrict__ actions,
                                           WaitFn wait, int spec_pos = -1 /* >= 0: adopt the speculated outcome at this list position */) {
-    constexpr int WS = HEAD_WS;
     auto &s = H.s;
-    float (&a3)[256] = H.a3;
     float (&lg)[32] = H.lg;
-    float (&wo)[32 * HEAD_WS] = H.wo;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const Layout &L = A.L;
     const int nact = L.nact;
     const float sc = A.m_scale[m];
@@ -232,64 +229,52 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
         s.ram_prev[tid] = E.ram_prev[(size_t)m * 128 + tid];
         s.ram_cur[tid] = E.ram_cur[(size_t)m * 128 + tid];
     }
-    {
-        // the flat layout is [k][action]; every logit's column becomes an LDS row.  Eight elements per thread are requested before the
-        // first is used: a rolled loop pays one memory round trip per element (18 of them at 18 actions -- most of this kernel's time)
-        const float *wb = base + L.ow, *we = A.noise + off + L.ow;
-        const int nw = 256 * nact, stride = blockDim.x;
-        for (int i0 = tid; i0 < nw; i0 += 8 * stride) {
-            float ev[8], bv[8];
+    // this thread's row of the output layer (k = tid): nact consecutive weights of the base vector and of the noise slice
+    float wth[OUT_NA], wep[OUT_NA];
+    float fbt = 0.0f, fbe = 0.0f, s3 = 1.0f, h3 = 0.0f;
+    if (tid < 256) {
+        const float *wb = base + L.ow + tid * nact, *we = A.noise + off + L.ow + tid * nact;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int i = i0 + j * stride;
-                ev[j] = i < nw ? we[i] : 0.0f;
-                bv[j] = i < nw ? wb[i] : 0.0f;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int i = i0 + j * stride;
-                if (i < nw) {
-                    float pv = sc * ev[j];
-                    wo[(i % nact) * WS + i / nact] = bv[j] + pv;
-                }
-            }
+        for (int a = 0; a < OUT_NA; a++) {
+            wth[a] = a < nact ? wb[a] : 0.0f;
+            wep[a] = a < nact ? we[a] : 0.0f;
         }
+        fbt = base[L.fcb + tid]; fbe = A.noise[off + L.fcb + tid];
+        if (HAS_BN) { s3 = A.bn[(size_t)m * 608 + 96 + tid]; h3 = A.bn[(size_t)m * 608 + 352 + tid]; }
     }
     if constexpr (RENDER) synth_load_tables(s, E.T);
-    float fb = 0.0f;
-    if (tid < 256) {
-        float pvb = sc * A.noise[off + L.fcb + tid];
-        fb = base[L.fcb + tid] + pvb;
-    }
     if (!wait()) return;
     if (tid < 256) {
         const float *p = y3t + (size_t)m * 4 * 256 + tid;
         const float s01 = p[0] + p[256];
         const float s23 = p[512] + p[768];
         float t = s01 + s23;
+        float pvb = sc * fbe;
+        const float fb = fbt + pvb;
         t = t + fb;
         y3[(size_t)m * 256 + tid] = t;
         if (HAS_BN) {
-            t = t * A.bn[(size_t)m * 608 + 96 + tid];
-            t = t + A.bn[(size_t)m * 608 + 352 + tid];
+            t = t * s3;
+            t = t + h3;
         }
-        a3[tid] = t > 0.0f ? t : 0.0f;
+        const float x = t > 0.0f ? t : 0.0f;
+        float pr[1][OUT_NA];
+#pragma unroll
+        for (int a = 0; a < OUT_NA; a++) {
+            float pv = sc * wep[a];
+            float w = wth[a] + pv;
+            pr[0][a] = x * w;
+        }
+        out_wave_sums<1>(pr, nact, H.red[wv], lane);
     }
     __syncthreads();
     if (tid < nact) {
-        float acc = 0.0f;
-        const f32x4 *wr = (const f32x4 *)&wo[tid * WS], *ar = (const f32x4 *)a3;
-#pragma unroll 8
-        for (int k4 = 0; k4 < 64; k4++) {
-            const f32x4 w = wr[k4], x = ar[k4];
-            acc = __builtin_fmaf(x[0], w[0], acc);
-            acc = __builtin_fmaf(x[1], w[1], acc);
-            acc = __builtin_fmaf(x[2], w[2], acc);
-            acc = __builtin_fmaf(x[3], w[3], acc);
-        }
+        const float s01 = H.red[0][0][tid] + H.red[1][0][tid];
+        const float s23 = H.red[2][0][tid] + H.red[3][0][tid];
+        const float t = s01 + s23;
         float pv = sc * A.noise[off + L.ob + tid];
         const float bias = base[L.ob + tid] + pv;
-        lg[tid] = acc + bias;
+        lg[tid] = t + bias;
     }
     __syncthreads();
     if (spec_pos >= 0) {   // the emulator + renderer outcome of every action is on the table: every thread finds the policy's
@@ -504,6 +489,7 @@ struct dne_handle {
     hipStream_t stream = nullptr;
     std::vector<hipStream_t> sub_streams;   // sub-batch streams (sub_streams[0] == stream)
     int dbg_skip = 0;   // DNE_DEBUG_SKIP bitmask (timing experiments only): 1 conv1, 2 conv2, 4 render
+    int dbg_immortal = 0;   // DNE_DEBUG_IMMORTAL (timing experiments only): every member lives until tslimit -- a lock-step keeps its width
     int render_threads = 256;
     int conv1_fpw = 8;               // reference pass: frames per conv1 workgroup (DNE_CONV1_FPW: 1, 2, 4, 8)
     int conv_fused = 1, conv_fused_min = 129;   // DNE_CONV_FUSED / DNE_CONV_FUSED_MIN: conv1 + conv2 in one kernel from this many members
@@ -513,8 +499,8 @@ struct dne_handle {
     bool fc2_now = false;            // decided per burst by eval_core
     int duo_solo_below = 1500;       // DNE_DUO_SOLO_BELOW: with fewer active groups (all windows) every wave takes one unit instead of two (sparse table: little to share, and twice the waves)
     bool duo_solo_now = false;       // decided per burst by eval_core
-    int out_lds_kb = 64;             // DNE_OUT_LDS_KB: k_out's LDS reservation; the 37 KB it needs at 18 actions let four workgroups share a CU with the
-                                     // streaming fc and the convolutions and cost 0.9 % of the generation (same-box A/B, 403.3 vs 399.8 ms): two per CU
+    int out_lds_kb = 0;              // DNE_OUT_LDS_KB: an unused LDS reservation that bounds k_out's workgroups per CU (round 2's k_out staged 37 KB of output
+                                     // weights and ran best at two workgroups per CU = 64 KB; round 3's stages nothing)
     int duo_head_fused = 0;          // DNE_DUO_HEAD_FUSED: behind k_fc_duo the policy head and the emulator step share a launch (k_tail_step) instead of
                                      // k_out + k_env_logic; same-box A/B: 402.7 ms fused, 403.3 separate, 399.8 separate with k_out at two workgroups per CU -> off
     int fc_duo_ga = 0;               // DNE_FC_DUO_GA: the table-ordered fc for GA evaluations too (single members, one base vector per parent); measured slower, off
@@ -657,7 +643,7 @@ struct dne_handle {
         EnvArgs E;
         E.ram_prev = ram_prev; E.ram_cur = ram_cur; E.stacks = stacks; E.T = tables;
         E.ret = ret; E.sign = sign; E.step_reward = step_reward; E.len = len; E.done = done; E.stepped = stepped; E.action = action; E.step_counter = nullptr;
-        E.bc = bc; E.bc_mode = bc ? bc_mode : 0; E.bc_max_steps = cfg.bc_max_steps;
+        E.bc = bc; E.bc_mode = bc ? bc_mode : 0; E.bc_max_steps = cfg.bc_max_steps; E.immortal = dbg_immortal;
         E.spec_prev = spec_prev; E.spec_cur = spec_cur; E.spec_rw = spec_rw; E.spec_stacks = spec_stacks; E.spec_y1 = spec_y1;
         return E;
     }
@@ -865,15 +851,15 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipFuncSetAttribute((const void *)k_lconv_mfma<64, 64, 3, 1, 11, 11, 1, 68, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<64, 3, 1, 11, 68>()));
     CH(hipFuncSetAttribute((const void *)k_lconv_mfma<32, 64, 4, 2, 21, 11, 1, 34, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<32, 4, 2, 11, 34>()));
     CH(hipFuncSetAttribute((const void *)k_lconv_mfma<64, 64, 3, 1, 11, 11, 1, 68, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<64, 3, 1, 11, 68>()));
-    CH(hipFuncSetAttribute((const void *)k_lout, hipFuncAttributeMaxDynamicSharedMemorySize, 512 * 32 * 4));
-    CH(hipFuncSetAttribute((const void *)k_out<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 32 * 4));
-    CH(hipFuncSetAttribute((const void *)k_out<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 32 * 4));
-    CH(hipFuncSetAttribute((const void *)k_out<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 32 * 4));
-    CH(hipFuncSetAttribute((const void *)k_out<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 32 * 4));
+    CH(hipFuncSetAttribute((const void *)k_out<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));   // the DNE_OUT_LDS_KB reservation
+    CH(hipFuncSetAttribute((const void *)k_out<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CH(hipFuncSetAttribute((const void *)k_out<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CH(hipFuncSetAttribute((const void *)k_out<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
     env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
     env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
     env_int("DNE_DEBUG_SKIP", 0, 7, &h->dbg_skip);
+    env_int("DNE_DEBUG_IMMORTAL", 0, 1, &h->dbg_immortal);
     env_int("DNE_RENDER_THREADS", 256, 1024, &h->render_threads); h->render_threads = wg_size(h->render_threads);
     env_int("DNE_BAND_THREADS", 256, 1024, &h->band_threads); h->band_threads = wg_size(h->band_threads);
     env_int("DNE_TAIL_FUSED_MAX", 0, 1 << 20, &h->tail_fused_max);
@@ -1425,7 +1411,7 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
             if (h->fc_rb == 8) hipLaunchKernelGGL((k_lfc<false, 8>), lg, dim3(256), 0, st, A, list, 2 * count, (const float *)h->y3, h->y3t);
             else hipLaunchKernelGGL((k_lfc<false, 4>), lg, dim3(256), 0, st, A, list, 2 * count, (const float *)h->y3, h->y3t);
         } else hipLaunchKernelGGL((k_lfc<true, 4>), lg, dim3(256), 0, st, A, list, 2 * count, (const float *)h->y3, h->y3t);
-        hipLaunchKernelGGL(k_lout, dim3(count), dim3(256), (size_t)512 * h->cfg.n_actions * sizeof(float), st, A, list, (const float *)h->y3t, h->action, logits);
+        hipLaunchKernelGGL(k_lout, dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->action, logits);
         return;
     }
     if (count <= h->fc_tail_max) {   // latency-bound regime: 4 workgroups per group + a separate output-layer kernel
@@ -1433,7 +1419,7 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
     do {                                                                                                                     \
         if (count <= h->fc_quad_max) hipLaunchKernelGGL((k_fc_quad<NV, BN>), dim3(count * 64), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
         else hipLaunchKernelGGL((k_fc_cols<NV, BN>), dim3(count * 4), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
-        if (!out_fused) hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), (size_t)NV * 256 * h->cfg.n_actions * sizeof(float), st, A, list, (const float *)h->y3t, h->y3, h->action, logits); \
+        if (!out_fused) hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->y3, h->action, logits); \
     } while (0)
         if (gsize == 2) { if (es) FCT(2, true); else FCT(2, false); }
         else { if (es) FCT(1, true); else FCT(1, false); }
@@ -1443,7 +1429,7 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
     if (h->duo_now && !logits && order && (gsize == 2 ? es : !es)) {   // table-ordered units: adjacent (group, k-slice) units share their noise rows
         const bool solo = h->duo_solo_now;
         const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 3) / 4, blocks = std::min(items, h->fc_grid);
-        const size_t out_lds = std::max((size_t)gsize * 256 * h->cfg.n_actions * sizeof(float), (size_t)h->out_lds_kb * 1024);
+        const size_t out_lds = (size_t)h->out_lds_kb * 1024;   // an LDS reservation nobody uses: it only bounds k_out's workgroups per CU next to the streaming fc
         if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0));
         else hipLaunchKernelGGL((k_fc_duo<1, false>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0));
         if (after_stream_kernel) hipEventRecord(after_stream_kernel, st);

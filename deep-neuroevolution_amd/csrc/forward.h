@@ -704,12 +704,74 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// ------------------------------------------------------------------ output layer (policies.py:329 / 457), the oracle's out_raw_k
+// logit[a] = tree over k of p[k] = a3[k] * w[k][a]:  every group of 64 consecutive k is one wavefront, lane = k, and the 64
+// products are summed by a lane butterfly with strides 1, 2, 4, 8, 16, 32 -- a balanced binary tree, neighbours first, both lanes
+// of a pair holding the same sum at every level (fp addition is commutative); the groups' sums meet in LDS and are combined
+// ((S0+S1)+(S2+S3)) (+ ((S4+S5)+(S6+S7)) for the LargeModel's 512 inputs) + bias.  No serial chain, no staging of the weights:
+// a thread loads the nact consecutive weights of its own k (base and noise) and that is the layer's whole memory traffic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_tree_sum(float v) {
+    v = v + dpp_get<0xB1>(v);      // quad_perm [1,0,3,2]: lane ^ 1
+    v = v + dpp_get<0x4E>(v);      // quad_perm [2,3,0,1]: lane ^ 2
+    v = v + dpp_get<0x141>(v);     // row_half_mirror: the other quad of the 8 (every lane of a quad holds the quad's sum by now)
+    v = v + dpp_get<0x140>(v);     // row_mirror: the other half of the row of 16
+    v = v + __shfl_xor(v, 16);
+    v = v + __shfl_xor(v, 32);
+    return v;
+}
+
+constexpr int OUT_NA = 32;         // the action loops are unrolled over the largest action set the engine accepts
+
+// p[s][a] = x[s] * fl(theta[a] + fl(sc[s] * eps[a])) for this thread's k; wb / we point at w[k][0] in the base vector / noise slice.
+// The NS members share one base vector and one noise slice (an antithetic pair: scales +sigma / -sigma).
+template <int NS>
+__device__ __forceinline__ void out_products(float (&p)[NS][OUT_NA], const float (&x)[NS], const float *__restrict__ wb,
+                                             const float *__restrict__ we, const float (&sc)[NS], int nact) {
+    float th[OUT_NA], ep[OUT_NA];
+#pragma unroll
+    for (int a = 0; a < OUT_NA; a++) {
+        th[a] = a < nact ? wb[a] : 0.0f;
+        ep[a] = a < nact ? we[a] : 0.0f;
+    }
+#pragma unroll
+    for (int a = 0; a < OUT_NA; a++)
+#pragma unroll
+        for (int s2 = 0; s2 < NS; s2++) {
+            float pv = sc[s2] * ep[a];
+            float w = th[a] + pv;
+            p[s2][a] = x[s2] * w;
+        }
+}
+
+// the wavefront's tree sums of p -> red[s][a] (this wave's slot in LDS)
+template <int NS>
+__device__ __forceinline__ void out_wave_sums(float (&p)[NS][OUT_NA], int nact, float (*red)[OUT_NA], int lane) {
+#pragma unroll
+    for (int a = 0; a < OUT_NA; a++)
+        if (a < nact) {
+#pragma unroll
+            for (int s2 = 0; s2 < NS; s2++) p[s2][a] = wave_tree_sum(p[s2][a]);
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < OUT_NA; a++)
+            if (a < nact) {
+#pragma unroll
+                for (int s2 = 0; s2 < NS; s2++) red[s2][a] = p[s2][a];
+            }
+    }
+}
+
 template <int NV, bool SHARED_W, bool HAS_BN, int RB>
 __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ list, int n_local, int F, int member0,
                                             const float *__restrict__ y2, float *__restrict__ y3,
                                             int32_t *__restrict__ actions, float *__restrict__ logits_out) {
     __shared__ float part[4][NV][256];
-    __shared__ float a3[SHARED_W ? 1 : NV][256];
+    __shared__ float red[4][SHARED_W ? 1 : NV][OUT_NA];
     __shared__ float lg[SHARED_W ? 1 : NV][32];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const Layout &L = A.L;
@@ -837,8 +899,10 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
 #pragma unroll
         for (int q = 0; q < 4; q++) part[wv][v][lane * 4 + q] = acc[v][q];
     __syncthreads();
-    for (int i = tid; i < NV * 256; i += 256) {
-        const int v = i >> 8, j = i & 255;
+    float x3[NV];   // relu(bn3(y3)) of column tid, per member: this thread's input k = tid of the output layer
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        const int j = tid;
         const float s01 = part[0][v][j] + part[1][v][j];
         const float s23 = part[2][v][j] + part[3][v][j];
         float s = s01 + s23;
@@ -846,32 +910,29 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
         const float bias = base[L.fcb + j] + pv;
         s = s + bias;
         y3[(size_t)row[v] * 256 + j] = s;
-        if (!SHARED_W) {
-            float t = s;
-            if (HAS_BN) {
-                t = t * A.bn[(size_t)member[v] * 608 + 96 + j];
-                t = t + A.bn[(size_t)member[v] * 608 + 352 + j];
-            }
-            a3[v][j] = t > 0.0f ? t : 0.0f;
+        float t = s;
+        if (!SHARED_W && HAS_BN) {
+            t = t * A.bn[(size_t)member[v] * 608 + 96 + j];
+            t = t + A.bn[(size_t)member[v] * 608 + 352 + j];
         }
+        x3[v] = t > 0.0f ? t : 0.0f;
     }
-    if (SHARED_W) return;
-    __syncthreads();
+    if constexpr (!SHARED_W) {
     const int nact = L.nact;
+    {
+        float p[NV][OUT_NA];
+        out_products<NV>(p, x3, base + L.ow + tid * nact, A.noise + off + L.ow + tid * nact, scale, nact);
+        out_wave_sums<NV>(p, nact, red[wv], lane);
+    }
+    __syncthreads();
     if (tid < NV * nact) {
         const int v = tid / nact, a = tid % nact;
-        const float *wb = base + L.ow + a;
-        const float *we = A.noise + off + L.ow + a;
-        float s = 0.0f;
-#pragma unroll 8
-        for (int k = 0; k < 256; k++) {
-            float pv = scale[v] * we[k * nact];
-            float w = wb[k * nact] + pv;
-            s = __builtin_fmaf(a3[v][k], w, s);
-        }
-        float pv = scale[v] * A.noise[off + L.ob + a];
+        const float s01 = red[0][v][a] + red[1][v][a];
+        const float s23 = red[2][v][a] + red[3][v][a];
+        const float t = s01 + s23;
+        float pv = A.m_scale[member[0] + v] * A.noise[off + L.ob + a];
         const float bias = base[L.ob + a] + pv;
-        lg[v][a] = s + bias;
+        lg[v][a] = t + bias;
     }
     __syncthreads();
     if (tid < NV) {
@@ -879,11 +940,12 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
         int best = 0;
         for (int a = 1; a < nact; a++)
             if (lg[v][a] > lg[v][best]) best = a;   // tf.argmax: first maximum
-        actions[member[v]] = best;
+        actions[member[0] + v] = best;
         if (logits_out)
-            for (int a = 0; a < nact; a++) logits_out[(size_t)member[v] * nact + a] = lg[v][a];
+            for (int a = 0; a < nact; a++) logits_out[(size_t)(member[0] + v) * nact + a] = lg[v][a];
     }
     __syncthreads();   // LDS is reused by the next group
+    }
     }
 }
 
@@ -898,7 +960,7 @@ __global__ __launch_bounds__(256) void k_fc2(FwdArgs A, const int *__restrict__ 
                                              int32_t *__restrict__ actions) {
     constexpr int NM = 4;   // members per item: pair p = members 2p, 2p+1
     __shared__ float part[4][NM][256];
-    __shared__ float a3[NM][256];
+    __shared__ float red[4][NM][OUT_NA];
     __shared__ float lg[NM][32];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const Layout &L = A.L;
@@ -1007,38 +1069,43 @@ __global__ __launch_bounds__(256) void k_fc2(FwdArgs A, const int *__restrict__ 
 #pragma unroll
         for (int q = 0; q < 4; q++) part[wv][v][lane * 4 + q] = acc[v][q];
     __syncthreads();
-    for (int i = tid; i < nm * 256; i += 256) {
-        const int v = i >> 8, j = i & 255;
-        const float s01 = part[0][v][j] + part[1][v][j];
-        const float s23 = part[2][v][j] + part[3][v][j];
-        float s = s01 + s23;
-        float pv = scale[v] * A.noise[off[v >> 1] + L.fcb + j];
-        const float bias = base[L.fcb + j] + pv;
-        s = s + bias;
-        y3[(size_t)member[v] * 256 + j] = s;
-        float t = s;
-        if (HAS_BN) {
-            t = t * A.bn[(size_t)member[v] * 608 + 96 + j];
-            t = t + A.bn[(size_t)member[v] * 608 + 352 + j];
+    const int nact = L.nact;
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {   // the item's two pairs: each shares one noise slice, all four members the base vector
+        if (2 * pr < nm) {
+            float x3[2], sc2[2] = {scale[2 * pr], scale[2 * pr + 1]};
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int v = 2 * pr + u, j = tid;
+                const float s01 = part[0][v][j] + part[1][v][j];
+                const float s23 = part[2][v][j] + part[3][v][j];
+                float s = s01 + s23;
+                float pv = scale[v] * A.noise[off[pr] + L.fcb + j];
+                const float bias = base[L.fcb + j] + pv;
+                s = s + bias;
+                y3[(size_t)member[v] * 256 + j] = s;
+                float t = s;
+                if (HAS_BN) {
+                    t = t * A.bn[(size_t)member[v] * 608 + 96 + j];
+                    t = t + A.bn[(size_t)member[v] * 608 + 352 + j];
+                }
+                x3[u] = t > 0.0f ? t : 0.0f;
+            }
+            float p[2][OUT_NA];
+            out_products<2>(p, x3, base + L.ow + tid * nact, A.noise + off[pr] + L.ow + tid * nact, sc2, nact);
+            out_wave_sums<2>(p, nact, red[wv] + 2 * pr, lane);
         }
-        a3[v][j] = t > 0.0f ? t : 0.0f;
     }
     __syncthreads();
-    const int nact = L.nact;
     if (tid < nm * nact) {
         const int v = tid / nact, a = tid % nact;
-        const float *wb = base + L.ow + a;
-        const float *we = A.noise + off[v >> 1] + L.ow + a;
-        float s = 0.0f;
-#pragma unroll 8
-        for (int k = 0; k < 256; k++) {
-            float pv = scale[v] * we[k * nact];
-            float w = wb[k * nact] + pv;
-            s = __builtin_fmaf(a3[v][k], w, s);
-        }
-        float pv = scale[v] * A.noise[off[v >> 1] + L.ob + a];
+        const float s01 = red[0][v][a] + red[1][v][a];
+        const float s23 = red[2][v][a] + red[3][v][a];
+        const float t = s01 + s23;
+        const int mv = (v >> 1 ? member[2] : member[0]) + (v & 1);
+        float pv = A.m_scale[mv] * A.noise[(v >> 1 ? off[1] : off[0]) + L.ob + a];
         const float bias = base[L.ob + a] + pv;
-        lg[v][a] = s + bias;
+        lg[v][a] = t + bias;
     }
     __syncthreads();
     if (tid < nm) {
@@ -1046,7 +1113,7 @@ __global__ __launch_bounds__(256) void k_fc2(FwdArgs A, const int *__restrict__ 
         int best = 0;
         for (int a = 1; a < nact; a++)
             if (lg[v][a] > lg[v][best]) best = a;   // tf.argmax: first maximum
-        actions[member[v]] = best;
+        actions[(v >> 1 ? member[2] : member[0]) + (v & 1)] = best;
     }
     __syncthreads();   // LDS is reused by the next item
     }
@@ -1235,14 +1302,28 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
         };
         auto row = [&](Side &Z, const f32x4 &e, const f32x4 &t, int li, const float (&scale)[NV]) {
             const f32x2 elo = {e[0], e[1]}, ehi = {e[2], e[3]}, tlo = {t[0], t[1]}, thi = {t[2], t[3]};
+            if constexpr (NV == 2) {
+                // an antithetic pair (dne_es_eval: scales +sigma / -sigma exactly): fl(-sigma * eps) = -fl(sigma * eps), so the
+                // second member's weight is base - p with the first member's p -- the same two roundings, two multiplies fewer per row
+                const f32x2 sc = {scale[0], scale[0]};
+                const f32x2 pl = sc * elo, ph = sc * ehi;
+                const float x0 = lane_bcast(Z.xv[0], li), x1 = lane_bcast(Z.xv[1], li);
+                const f32x2 xx0 = {x0, x0}, xx1 = {x1, x1};
+                const f32x2 wl0 = tlo + pl, wh0 = thi + ph, wl1 = tlo - pl, wh1 = thi - ph;
+                Z.acc[0][0] = __builtin_elementwise_fma(xx0, wl0, Z.acc[0][0]);
+                Z.acc[0][1] = __builtin_elementwise_fma(xx0, wh0, Z.acc[0][1]);
+                Z.acc[1][0] = __builtin_elementwise_fma(xx1, wl1, Z.acc[1][0]);
+                Z.acc[1][1] = __builtin_elementwise_fma(xx1, wh1, Z.acc[1][1]);
+            } else {
 #pragma unroll
-            for (int v = 0; v < NV; v++) {
-                const float x = lane_bcast(Z.xv[v], li);
-                const f32x2 xx = {x, x}, sc = {scale[v], scale[v]};
-                f32x2 pl = sc * elo, ph = sc * ehi;       // base + scale * noise, two roundings, then one fused multiply-add
-                f32x2 wl = tlo + pl, wh = thi + ph;
-                Z.acc[v][0] = __builtin_elementwise_fma(xx, wl, Z.acc[v][0]);
-                Z.acc[v][1] = __builtin_elementwise_fma(xx, wh, Z.acc[v][1]);
+                for (int v = 0; v < NV; v++) {
+                    const float x = lane_bcast(Z.xv[v], li);
+                    const f32x2 xx = {x, x}, sc = {scale[v], scale[v]};
+                    f32x2 pl = sc * elo, ph = sc * ehi;       // base + scale * noise, two roundings, then one fused multiply-add
+                    f32x2 wl = tlo + pl, wh = thi + ph;
+                    Z.acc[v][0] = __builtin_elementwise_fma(xx, wl, Z.acc[v][0]);
+                    Z.acc[v][1] = __builtin_elementwise_fma(xx, wh, Z.acc[v][1]);
+                }
             }
         };
         auto end_block = [&](Side &Z) {
@@ -1732,14 +1813,15 @@ __global__ __launch_bounds__(256) void k_fc_cols(FwdArgs A, const int *__restric
     for (int v = 0; v < NV; v++) y3t[((size_t)member[v] * 4 + wv) * 256 + col] = acc[v];
 }
 
-// bn3 + relu + out layer (256 x nact, k-ordered chain) + first-max argmax from y3, one workgroup per group
+// fc slice combine + bias, bn3 + relu, output layer (out_products / out_wave_sums: thread = input k) + first-max argmax from the
+// fc partial sums, one workgroup per group.  The members of a group share base vector and noise slice (antithetic pair).
 template <int NV, bool HAS_BN>
 __global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y3t,
                                             float *__restrict__ y3, int32_t *__restrict__ actions,
                                             float *__restrict__ logits_out) {
-    __shared__ float a3[NV][256];
+    __shared__ float red[4][NV][OUT_NA];
     __shared__ float lg[NV][32];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const Layout &L = A.L;
     const int g = list ? list[blockIdx.x] : blockIdx.x;
     const int nact = L.nact;
@@ -1749,59 +1831,49 @@ __global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ 
         for (int v = 0; v < NV; v++) all_done = all_done && A.done[g * NV + v] != 0;
         if (all_done) return;
     }
+    const int m0 = g * NV;
+    const int64_t off = A.m_off[m0];
+    const float *base = A.bases + (size_t)A.m_slot[m0] * A.base_stride;
+    const float *eps = A.noise + off;
+    float sc[NV], x3[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) sc[v] = A.m_scale[m0 + v];
+    const float fb_t = base[L.fcb + tid], fb_e = eps[L.fcb + tid];
 #pragma unroll
     for (int v = 0; v < NV; v++) {
-        const int m = g * NV + v;
-        for (int j = tid; j < 256; j += 256) {
-            const float *p = y3t + (size_t)m * 4 * 256 + j;
-            const float s01 = p[0] + p[256];
-            const float s23 = p[512] + p[768];
-            float t = s01 + s23;
-            float pvb = A.m_scale[m] * A.noise[A.m_off[m] + L.fcb + j];
-            const float fb = (A.bases + (size_t)A.m_slot[m] * A.base_stride)[L.fcb + j] + pvb;
-            t = t + fb;
-            y3[(size_t)m * 256 + j] = t;
-            if (HAS_BN) {
-                t = t * A.bn[(size_t)m * 608 + 96 + j];
-                t = t + A.bn[(size_t)m * 608 + 352 + j];
-            }
-            a3[v][j] = t > 0.0f ? t : 0.0f;
+        const int m = m0 + v;
+        const float *p = y3t + (size_t)m * 4 * 256 + tid;
+        const float s01 = p[0] + p[256];
+        const float s23 = p[512] + p[768];
+        float t = s01 + s23;
+        float pvb = sc[v] * fb_e;
+        const float fb = fb_t + pvb;
+        t = t + fb;
+        y3[(size_t)m * 256 + tid] = t;
+        if (HAS_BN) {
+            t = t * A.bn[(size_t)m * 608 + 96 + tid];
+            t = t + A.bn[(size_t)m * 608 + 352 + tid];
         }
+        x3[v] = t > 0.0f ? t : 0.0f;
     }
-    // the (256 x nact) output weights of every member are staged by the whole wave in a few load batches (the
-    // chain below is latency-bound: 256 dependent fmaf per logit)
-    extern __shared__ float wo_dyn[];   // [NV][256 * nact]: sized by the launch (36 KB for 18 actions, so that the kernel fits next to the convolutions' LDS)
-    float *wo[NV];
-#pragma unroll
-    for (int v = 0; v < NV; v++) wo[v] = wo_dyn + (size_t)v * 256 * nact;
-#pragma unroll
-    for (int v = 0; v < NV; v++) {
-        const int m = g * NV + v;
-        const float sc = A.m_scale[m];
-        const float *wb = A.bases + (size_t)A.m_slot[m] * A.base_stride + L.ow;
-        const float *we = A.noise + A.m_off[m] + L.ow;
-#pragma unroll 8
-        for (int i = tid; i < 256 * nact; i += 256) {
-            float pv = sc * we[i];
-            wo[v][i] = wb[i] + pv;
-        }
+    {
+        float p[NV][OUT_NA];
+        out_products<NV>(p, x3, base + L.ow + tid * nact, eps + L.ow + tid * nact, sc, nact);
+        out_wave_sums<NV>(p, nact, red[wv], lane);
     }
     __syncthreads();
     if (tid < NV * nact) {
-        const int v = tid / nact, a = tid % nact, m = g * NV + v;
-        const float sc = A.m_scale[m];
-        const int64_t off = A.m_off[m];
-        const float *base = A.bases + (size_t)A.m_slot[m] * A.base_stride;
-        float s = 0.0f;
-#pragma unroll 16
-        for (int k = 0; k < 256; k++) s = __builtin_fmaf(a3[v][k], wo[v][k * nact + a], s);
-        float pv = sc * A.noise[off + L.ob + a];
+        const int v = tid / nact, a = tid % nact;
+        const float s01 = red[0][v][a] + red[1][v][a];
+        const float s23 = red[2][v][a] + red[3][v][a];
+        const float t = s01 + s23;
+        float pv = A.m_scale[m0 + v] * eps[L.ob + a];
         const float bias = base[L.ob + a] + pv;
-        lg[v][a] = s + bias;
+        lg[v][a] = t + bias;
     }
     __syncthreads();
     if (tid < NV) {
-        const int v = tid, m = g * NV + v;
+        const int v = tid, m = m0 + v;
         int best = 0;
         for (int a = 1; a < nact; a++)
             if (lg[v][a] > lg[v][best]) best = a;

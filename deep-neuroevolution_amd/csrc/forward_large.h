@@ -264,37 +264,38 @@ __global__ __launch_bounds__(256) void k_lfc_cols(FwdArgs A, const int *__restri
     }
 }
 
-// relu + out layer (512 x nact, k-ordered chain) + first-max argmax, one workgroup per member
+// relu + out layer (512 x nact: thread = inputs k = tid and 256 + tid, forward.h's out_products / out_wave_sums; the eight groups
+// of 64 combined ((S0+S1)+(S2+S3)) + ((S4+S5)+(S6+S7))) + first-max argmax, one workgroup per member
 __global__ __launch_bounds__(256) void k_lout(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y4,
                                               int32_t *__restrict__ actions, float *__restrict__ logits_out) {
-    __shared__ float a4[512];
+    __shared__ float red[4][2][OUT_NA];   // [wave][half of k][action]
     __shared__ float lg[32];
-    extern __shared__ float wo_l[];   // [512 * nact]
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const Layout &L = A.L;
     const int nact = L.nact;
     const int m = list ? list[blockIdx.x] : blockIdx.x;
     if (A.done && A.done[m]) return;
-    const float sc = A.m_scale[m];
+    const float sc[1] = {A.m_scale[m]};
     const int64_t off = A.m_off[m];
     const float *base = A.bases + (size_t)A.m_slot[m] * A.base_stride;
-    for (int j = tid; j < 512; j += 256) {
-        const float t = y4[(size_t)m * 512 + j];
-        a4[j] = t > 0.0f ? t : 0.0f;
-    }
-#pragma unroll 8
-    for (int i = tid; i < 512 * nact; i += 256) {
-        float pv = sc * A.noise[off + L.ow + i];
-        wo_l[i] = base[L.ow + i] + pv;
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++) {
+        const int k = hf * 256 + tid;
+        const float t = y4[(size_t)m * 512 + k];
+        const float x[1] = {t > 0.0f ? t : 0.0f};
+        float p[1][OUT_NA];
+        out_products<1>(p, x, base + L.ow + k * nact, A.noise + off + L.ow + k * nact, sc, nact);
+        out_wave_sums<1>(p, nact, red[wv] + hf, lane);
     }
     __syncthreads();
     if (tid < nact) {
-        float s = 0.0f;
-#pragma unroll 16
-        for (int k = 0; k < 512; k++) s = __builtin_fmaf(a4[k], wo_l[k * nact + tid], s);
-        float pv = sc * A.noise[off + L.ob + tid];
+        const float s01 = red[0][0][tid] + red[1][0][tid], s23 = red[2][0][tid] + red[3][0][tid];
+        const float s45 = red[0][1][tid] + red[1][1][tid], s67 = red[2][1][tid] + red[3][1][tid];
+        const float lo = s01 + s23, hi = s45 + s67;
+        const float t = lo + hi;
+        float pv = sc[0] * A.noise[off + L.ob + tid];
         const float bias = base[L.ob + tid] + pv;
-        lg[tid] = s + bias;
+        lg[tid] = t + bias;
     }
     __syncthreads();
     if (tid == 0) {

@@ -3,8 +3,9 @@
  * See dne_oracle.h for scope, pinning status and the rule on who may use it.
  *
  * Numerics contract (what "bit-exact" means for the HIP engine):
- *   - every dot product is an fp32 fmaf chain in the stated k order, starting at 0
+ *   - every dot product of the convolutions and the fc is an fp32 fmaf chain in the stated k order, starting at 0
  *   - fc uses 4 k-slices of 968 rows combined as ((s0+s1)+(s2+s3)) + bias
+ *   - the output layer sums its K products by a fixed binary tree (out_raw_k)
  *   - everything else is one IEEE fp32 operation per written operator
  *   built with -ffp-contract=off so the compiler never fuses or splits
  */
@@ -177,14 +178,37 @@ static void fc_raw(const float *w, const float *b, const float *a2, float *y3) {
     }
 }
 
-/* out 256 -> nact (policies.py:329 / 457) */
-static void out_raw(const float *w, const float *b, const float *a3, int nact, float *logits) {
+/* Sum of 64 values by a balanced binary tree: neighbours first, (x0+x1), (x2+x3), ..., then pairs of pairs, ... -- what 64
+ * lanes of a wavefront produce with a butterfly of strides 1, 2, 4, 8, 16, 32 (fp addition is commutative, so both lanes of a
+ * pair hold the same sum at every level). */
+static float tree64(const float *x) {
+    float t[64];
+    for (int i = 0; i < 64; i++) t[i] = x[i];
+    for (int n = 64; n > 1; n /= 2)
+        for (int i = 0; i < n / 2; i++) t[i] = t[2 * i] + t[2 * i + 1];
+    return t[0];
+}
+
+/* out K -> nact (policies.py:329 / 457; K = 256, LargeModel 512).  TensorFlow's summation order is unknowable;
+ * the order defined here (round 3) is the one a GPU forms without a serial chain: the K products p[k] = a3[k] * w[k][a] (one
+ * rounding each), every group of 64 consecutive k summed by tree64, the groups combined pairwise in order
+ * ((S0+S1)+(S2+S3)) [+ ((S4+S5)+(S6+S7)) for K = 512], + bias.  (Rounds 1-2: one fmaf chain over k.) */
+static void out_raw_k(const float *w, const float *b, const float *a3, int K, int nact, float *logits) {
     for (int a = 0; a < nact; a++) {
-        float acc = 0.0f;
-        for (int k = 0; k < 256; k++) acc = fmaf(a3[k], w[k * nact + a], acc);
-        logits[a] = acc + b[a];
+        float p[512], S[8];
+        for (int k = 0; k < K; k++) p[k] = a3[k] * w[k * nact + a];
+        for (int g = 0; g < K / 64; g++) S[g] = tree64(p + 64 * g);
+        float s01 = S[0] + S[1], s23 = S[2] + S[3];
+        float t = s01 + s23;
+        if (K == 512) {
+            float s45 = S[4] + S[5], s67 = S[6] + S[7];
+            float u = s45 + s67;
+            t = t + u;
+        }
+        logits[a] = t + b[a];
     }
 }
+static void out_raw(const float *w, const float *b, const float *a3, int nact, float *logits) { out_raw_k(w, b, a3, 256, nact, logits); }
 
 /* tf.argmax: index of the first maximum */
 static int argmax_first(const float *x, int n) {
@@ -267,11 +291,7 @@ void orc_forward_large_debug(const orc_layout *L, const float *th, const uint8_t
         y4[j] = t + th[L->fcb + j];
         a4[j] = y4[j] > 0.0f ? y4[j] : 0.0f;
     }
-    for (int a = 0; a < L->nact; a++) {
-        float acc = 0.0f;
-        for (int kk = 0; kk < 512; kk++) acc = fmaf(a4[kk], th[L->ow + kk * L->nact + a], acc);
-        logits[a] = acc + th[L->ob + a];
-    }
+    out_raw_k(th + L->ow, th + L->ob, a4, 512, L->nact, logits);
 }
 
 int orc_act(const orc_layout *L, const float *th, const float *bn, const uint8_t *ob, float *logits) {
