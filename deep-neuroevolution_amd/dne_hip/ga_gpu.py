@@ -22,95 +22,91 @@ from . import _lib
 from .policies import flat_layout
 
 
-# ---------------------------------------------------------------------------------------------- helper.py:46-88
-class ConstantSchedule(object):
-    def __init__(self, value):
-        self._value = value
+# ---------------------------------------------------------------------------------------------- mutation-power schedules
+class Schedule(object):
+    """The three schedules of neuroevolution/helper.py:46-88 as one value object.  The experiment JSON names them by the
+    reference's class names ('ConstantSchedule', 'LinearSchedule', 'ExponentialSchedule') with that class's keyword arguments;
+    progress is looked up by `field` among the keywords of value() ('iteration', 'timesteps_so_far': ga.py:73-74).
+    linear:       start + min(progress / span, 1) * (stop - start)
+    exponential:  the same interpolation between log(start) and log(stop), exponentiated.  (The reference's
+                  ExponentialSchedule.value calls `self.linear(**kwargs)` on an object without __call__ and raises; the
+                  interpolation in log space is what its constructor sets up.)"""
+    KINDS = {'ConstantSchedule': 'constant', 'LinearSchedule': 'linear', 'ExponentialSchedule': 'exponential'}
 
-    def value(self, **kwargs):
-        return self._value
+    def __init__(self, kind, start, stop=None, span=None, field=None):
+        if kind not in ('constant', 'linear', 'exponential'):
+            raise ValueError('unknown schedule kind {!r}'.format(kind))
+        self.kind, self.start, self.stop, self.span, self.field = kind, start, stop, span, field
+
+    @classmethod
+    def from_config(cls, spec):
+        """helper.py:84-88: a bare number is a constant; otherwise {'type': <reference class name>, ...its keyword arguments}"""
+        if isinstance(spec, numbers.Number):
+            return cls('constant', spec)
+        kw = dict(spec)
+        kind = cls.KINDS[kw.pop('type')]
+        if kind == 'constant':
+            return cls(kind, kw['value'])
+        return cls(kind, kw['initial_p'], kw['final_p'], kw['schedule'], kw['field'])
+
+    def value(self, **progress):
+        if self.kind == 'constant':
+            return self.start
+        # the reference asserts here (helper.py:61); callers that catch its AssertionError keep working
+        assert self.field in progress, 'schedule needs {!r}; value() was given {}'.format(self.field, sorted(progress))
+        reached = min(float(progress[self.field]) / self.span, 1.0)
+        if self.kind == 'linear':
+            return self.start + reached * (self.stop - self.start)
+        lo, hi = math.log(self.start), math.log(self.stop)
+        return math.exp(lo + reached * (hi - lo))
 
 
-class LinearSchedule(object):
-    def __init__(self, schedule, final_p, initial_p, field):
-        self.schedule, self.field, self.final_p, self.initial_p = schedule, field, final_p, initial_p
-
-    def value(self, **kwargs):
-        assert self.field in kwargs, "Argument {} not provided to scheduler Available: {}".format(self.field, kwargs)
-        fraction = min(float(kwargs[self.field]) / self.schedule, 1.0)
-        return self.initial_p + fraction * (self.final_p - self.initial_p)
+make_schedule = Schedule.from_config
 
 
-class ExponentialSchedule(object):
-    """helper.py:69-82 interpolates linearly in log space.  (The reference's `value` calls `self.linear(**kwargs)` on an object
-    that has no __call__ and would raise; `.value(**kwargs)` is what it means.)"""
+# ---------------------------------------------------------------------------------------------- run state (what snapshot.pkl holds)
+class Offspring(object):
+    """One evaluated genome (ga.py:88-106): seeds = (idx0, (idx1, power1), ...), the rewards / lengths of its training
+    episodes and -- once validated -- of its validation episodes."""
 
-    def __init__(self, initial_p, final_p, schedule, field):
-        self.initial_p, self.final_p, self.schedule, self.field = initial_p, final_p, schedule, field
-        self.linear = LinearSchedule(initial_p=math.log(initial_p), final_p=math.log(final_p), schedule=schedule, field=field)
+    def __init__(self, seeds, rewards, ep_len, validation_rewards=(), validation_ep_len=()):
+        self.seeds = seeds
+        self.rewards, self.ep_len = rewards, ep_len
+        self.validation_rewards, self.validation_ep_len = list(validation_rewards), list(validation_ep_len)
 
-    def value(self, **kwargs):
-        return math.exp(self.linear.value(**kwargs))
-
-
-def make_schedule(args):
-    """helper.py:84-88: a number -> ConstantSchedule, else {'type': <class name>, ...kwargs}"""
-    if isinstance(args, numbers.Number):
-        return ConstantSchedule(args)
-    return {'ConstantSchedule': ConstantSchedule, 'LinearSchedule': LinearSchedule,
-            'ExponentialSchedule': ExponentialSchedule}[args['type']](**{k: v for k, v in args.items() if k != 'type'})
+    fitness = property(lambda self: np.mean(self.rewards))
+    training_steps = property(lambda self: np.sum(self.ep_len))
 
 
-# ---------------------------------------------------------------------------------------------- ga.py:40-112
 class TrainingState(object):
+    """Everything a run needs to continue after a restart (ga.py:40-76): counters, the sorted population, the elite, the best
+    validated solution, the mutation-power schedule and the episode cutoff with its adaptive growth rule."""
+    COUNTERS = ('num_frames', 'timesteps_so_far', 'time_elapsed', 'validation_timesteps_so_far', 'it')
+
     def __init__(self, exp):
-        self.num_frames = 0
-        self.population = []
-        self.timesteps_so_far = 0
-        self.time_elapsed = 0
-        self.validation_timesteps_so_far = 0
-        self.elite = None
-        self.it = 0
-        self.mutation_power = make_schedule(exp['mutation_power'])
-        self.curr_solution = None
-        self.curr_solution_val = float('-inf')
-        self.curr_solution_test = float('-inf')
-        mode = exp['episode_cutoff_mode']
-        if isinstance(mode, int):
-            self.tslimit, self.incr_tslimit_threshold, self.tslimit_incr_ratio, self.adaptive_tslimit = mode, None, None, False
-        elif mode.startswith('adaptive:'):
-            a0, a1, a2, a3 = mode.split(':')[1].split(',')
-            self.tslimit, self.incr_tslimit_threshold, self.tslimit_incr_ratio, self.tslimit_max = int(a0), float(a1), float(a2), float(a3)
-            self.adaptive_tslimit = True
-        elif mode == 'env_default':
-            self.tslimit, self.incr_tslimit_threshold, self.tslimit_incr_ratio, self.adaptive_tslimit = None, None, None, False
-        else:
-            raise NotImplementedError(mode)
+        from .es import parse_cutoff
+        for name in self.COUNTERS:
+            setattr(self, name, 0)
+        self.population, self.elite = [], None
+        self.curr_solution, self.curr_solution_val, self.curr_solution_test = None, float('-inf'), float('-inf')
+        self.mutation_power = Schedule.from_config(exp['mutation_power'])
+        limit, grow_at, grow_by, limit_max, adaptive = parse_cutoff(exp['episode_cutoff_mode'])
+        self.tslimit, self.adaptive_tslimit = limit, adaptive
+        self.incr_tslimit_threshold, self.tslimit_incr_ratio = grow_at, grow_by
+        if adaptive:
+            self.tslimit_max = limit_max
 
     def sample(self, schedule):
         return schedule.value(iteration=self.it, timesteps_so_far=self.timesteps_so_far)
 
     def copy_population(self, filename):
-        """ga.py:78-86 incl. the back-compatibility rule: bare seeds get the mutation power 0.005"""
-        with open(filename, 'rb+') as file:
-            state = pickle.load(file)
-            self.population = state.population
-            for offspring in self.population:
-                offspring.seeds = (offspring.seeds[0], ) + tuple(s if isinstance(s, tuple) else (s, 0.005) for s in offspring.seeds[1:])
-
-
-class Offspring(object):
-    def __init__(self, seeds, rewards, ep_len, validation_rewards=[], validation_ep_len=[]):
-        self.seeds, self.rewards, self.ep_len = seeds, rewards, ep_len
-        self.validation_rewards, self.validation_ep_len = validation_rewards, validation_ep_len
-
-    @property
-    def fitness(self):
-        return np.mean(self.rewards)
-
-    @property
-    def training_steps(self):
-        return np.sum(self.ep_len)
+        """Start from another run's population (exp['load_population'], ga.py:78-86).  Snapshots written before mutation powers
+        were stored per seed hold bare indices: those mutations were made at power 0.005."""
+        with open(filename, 'rb') as f:
+            self.population = pickle.load(f).population
+        for o in self.population:
+            root, rest = o.seeds[0], o.seeds[1:]
+            o.seeds = (root, ) + tuple(m if isinstance(m, tuple) else (m, 0.005) for m in rest)
 
 
 # ---------------------------------------------------------------------------------------------- models/dqn.py:24-37, base.py:190-201
