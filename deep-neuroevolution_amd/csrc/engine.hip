@@ -53,7 +53,16 @@ struct EnvArgs {
     int32_t *spec_rw;                // [SPEC_CAP * 32][2]: reward, game over
     uint8_t *spec_stacks;            // [SPEC_CAP * 32][84][84][4]
     float *spec_y1;                  // [SPEC_CAP * 32][441][16]: conv1 of every candidate stack (the next step starts at conv2)
+    // tail table (forward.h TailTable): position in the window -> member, in the kernel arguments; tt_n = 0: read the list
+    int tt_n;
+    int tt_member[TT_MAX];
 };
+
+__device__ __forceinline__ int env_member(const EnvArgs &E, const int *__restrict__ list, int gsize, int b) {
+    if (E.tt_n > 0) return E.tt_member[b];
+    const int g = list ? list[b / gsize] : b / gsize;
+    return g * gsize + b % gsize;
+}
 
 // The emulator state is 40 live bytes per member (RAM bytes 40..127 stay zero).  The per-frame logic is branchy
 // scalar code: it runs one member per lane on a register-resident copy of the state (struct Emu); the pixel work
@@ -155,8 +164,7 @@ constexpr int SPEC_ACTIONS = 32;   // stride of the candidate arrays (>= n_actio
 __global__ __launch_bounds__(64) void k_env_logic(EnvArgs E, const int *__restrict__ list, int gsize, int n_items, int tslimit) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n_items) return;
-    const int g = list ? list[b / gsize] : b / gsize;
-    const int m = g * gsize + b % gsize;
+    const int m = env_member(E, list, gsize, b);
     if (E.done[m]) { E.stepped[m] = 0; return; }
     env_member_step(E, m, E.action[m], tslimit);
 }
@@ -175,8 +183,7 @@ __device__ __forceinline__ void render_body(EnvLds &s, const EnvArgs &E, int m, 
 __global__ __launch_bounds__(1024) void k_env_render(EnvArgs E, const int *__restrict__ list, int gsize, int fill, int nbands) {
     __shared__ __attribute__((aligned(16))) EnvLds s;
     const int b = blockIdx.x / nbands, band = blockIdx.x % nbands;
-    const int g = list ? list[b / gsize] : b / gsize;
-    const int m = g * gsize + b % gsize;
+    const int m = env_member(E, list, gsize, b);
     if (!E.stepped[m]) return;
     synth_load_tables(s, E.T);
     render_body(s, E, m, fill != 0, band, nbands);
@@ -202,15 +209,18 @@ struct HeadLds {
 template <bool HAS_BN, bool RENDER, typename WaitFn>
 __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, const EnvArgs &E, int m, int tslimit,
                                           const float *__restrict__ y3t, float *__restrict__ y3, int32_t *__restrict__ actions,
-                                          WaitFn wait, int spec_pos = -1 /* >= 0: adopt the speculated outcome at this list position */) {
+                                          WaitFn wait, int pos /* position in the window (tail table), or -1 */,
+                                          int spec_pos = -1 /* >= 0: adopt the speculated outcome at this list position */) {
     auto &s = H.s;
     float (&lg)[32] = H.lg;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const Layout &L = A.L;
     const int nact = L.nact;
-    const float sc = A.m_scale[m];
-    const int64_t off = A.m_off[m];
-    const float *base = A.bases + (size_t)A.m_slot[m] * A.base_stride;
+    Item who;
+    who.member = m; who.pos = A.tt.n > 0 ? pos : -1;
+    const float sc = item_scale(A, who);
+    const float *base = item_base(A, who);
+    const float *noise_slice = item_eps(A, who);
     // speculative tail: thread a reads candidate a's outcome (and the member's bookkeeping) now, long before the choice is known
     uint32_t cwp[RAM_LIVE / 4] = {}, cwc[RAM_LIVE / 4] = {};
     int c_r = 0, c_over = 0;
@@ -233,13 +243,13 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
     float wth[OUT_NA], wep[OUT_NA];
     float fbt = 0.0f, fbe = 0.0f, s3 = 1.0f, h3 = 0.0f;
     if (tid < 256) {
-        const float *wb = base + L.ow + tid * nact, *we = A.noise + off + L.ow + tid * nact;
+        const float *wb = base + L.ow + tid * nact, *we = noise_slice + L.ow + tid * nact;
 #pragma unroll
         for (int a = 0; a < OUT_NA; a++) {
             wth[a] = a < nact ? wb[a] : 0.0f;
             wep[a] = a < nact ? we[a] : 0.0f;
         }
-        fbt = base[L.fcb + tid]; fbe = A.noise[off + L.fcb + tid];
+        fbt = base[L.fcb + tid]; fbe = noise_slice[L.fcb + tid];
         if (HAS_BN) { s3 = A.bn[(size_t)m * 608 + 96 + tid]; h3 = A.bn[(size_t)m * 608 + 352 + tid]; }
     }
     if constexpr (RENDER) synth_load_tables(s, E.T);
@@ -272,7 +282,7 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
         const float s01 = H.red[0][0][tid] + H.red[1][0][tid];
         const float s23 = H.red[2][0][tid] + H.red[3][0][tid];
         const float t = s01 + s23;
-        float pv = sc * A.noise[off + L.ob + tid];
+        float pv = sc * noise_slice[L.ob + tid];
         const float bias = base[L.ob + tid] + pv;
         lg[tid] = t + bias;
     }
@@ -315,10 +325,9 @@ __global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const 
                                                      int32_t *__restrict__ actions) {
     __shared__ HeadLds<RENDER> H;
     const int b = blockIdx.x;
-    const int g = list ? list[b / gsize] : b / gsize;
-    const int m = g * gsize + b % gsize;
+    const int m = env_member(E, list, gsize, b);
     if (E.done[m]) { if (threadIdx.x == 0) E.stepped[m] = 0; return; }
-    head_body<HAS_BN, RENDER>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{});
+    head_body<HAS_BN, RENDER>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b);
 }
 
 // The two speculative kernels ride in launches of the forward pass (same stream, no event traffic -- a cross-stream event
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(256) void k_conv1_spec(FwdArgs A, EnvArgs E, const 
                                                     float *__restrict__ y1, int nsplit, int n_conv_blocks, int n_items, int nact) {
     __shared__ Conv1Lds S;
     if ((int)blockIdx.x < n_conv_blocks) {
-        const Item it = decode_item(blockIdx.x / nsplit, list, gsize, 1, 0, E.stacks, nullptr, A.done);
+        const Item it = decode_item(A, blockIdx.x / nsplit, list, gsize, 1, 0, E.stacks, nullptr, A.done);
         if (it.skip) return;
         conv1_body(S, A, it, y1, blockIdx.x % nsplit, nsplit);
         return;
@@ -336,8 +345,7 @@ __global__ __launch_bounds__(256) void k_conv1_spec(FwdArgs A, EnvArgs E, const 
     const int i = ((int)blockIdx.x - n_conv_blocks) * 256 + threadIdx.x;
     if (i >= n_items * nact) return;
     const int b = i / nact, a = i % nact;
-    const int g = list ? list[b / gsize] : b / gsize;
-    const int m = g * gsize + b % gsize;
+    const int m = env_member(E, list, gsize, b);
     if (E.done[m]) return;
     Emu cur = ram_load(E.ram_cur + (size_t)m * 128), prev = cur;
     int over;
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(256) void k_conv2_spec(FwdArgs A, EnvArgs E, const 
     __shared__ Conv2Lds S;
     if ((int)blockIdx.x < n_conv_blocks) {
         const int b = blockIdx.x / nsplit;
-        const Item it = decode_item(b, list, gsize, 1, 0, nullptr, nullptr, A.done);
+        const Item it = decode_item(A, b, list, gsize, 1, 0, nullptr, nullptr, A.done);
         if (it.skip) return;
         const float *row = E.spec_y1 + ((size_t)b * SPEC_ACTIONS + last_action[it.member]) * 7056;
         conv2_body<HAS_BN>(S, A, it, y1, y2, blockIdx.x % nsplit, nsplit, nullptr, row);
@@ -367,8 +375,7 @@ __global__ __launch_bounds__(256) void k_conv2_spec(FwdArgs A, EnvArgs E, const 
     const int i = ((int)blockIdx.x - n_conv_blocks) * 256 + threadIdx.x;
     if (i >= n_items * nact) return;
     const int b = i / nact, a = i % nact;
-    const int g = list ? list[b / gsize] : b / gsize;
-    const int m = g * gsize + b % gsize;
+    const int m = env_member(E, list, gsize, b);
     if (E.done[m]) return;
     Emu cur = ram_load(E.ram_cur + (size_t)m * 128), prev = cur;
     int over;
@@ -389,14 +396,13 @@ __global__ __launch_bounds__(256) void k_fc_quad_spec(FwdArgs A, EnvArgs E, cons
     if ((int)blockIdx.x < n_fc_blocks) {
         QuadLds<NV> &S = *reinterpret_cast<QuadLds<NV> *>(lds);
         const int item = blockIdx.x >> 6, cg = (blockIdx.x >> 2) & 15, sl = blockIdx.x & 3;
-        fc_quad_body<NV, HAS_BN, false>(S, A, list ? list[item] : item, cg, sl, y2, y3t, NoWait{});
+        fc_quad_body<NV, HAS_BN, false>(S, A, list, item, cg, sl, y2, y3t, NoWait{});
         return;
     }
     EnvLds &s = *reinterpret_cast<EnvLds *>(lds);
     const int rb = (int)blockIdx.x - n_fc_blocks;
     const int band = rb % nbands, ba = rb / nbands, b = ba / nact, a = ba % nact;
-    const int g = list ? list[b / gsize] : b / gsize;
-    const int m = g * gsize + b % gsize;
+    const int m = env_member(E, list, gsize, b);
     if (E.done[m]) return;
     synth_load_tables(s, E.T);
     const size_t c = (size_t)b * SPEC_ACTIONS + a;
@@ -415,10 +421,9 @@ __global__ __launch_bounds__(1024) void k_tail_select(FwdArgs A, EnvArgs E, cons
                                                        int32_t *__restrict__ actions) {
     __shared__ HeadLds<false> H;
     const int b = blockIdx.x;
-    const int g = list ? list[b / gsize] : b / gsize;
-    const int m = g * gsize + b % gsize;
+    const int m = env_member(E, list, gsize, b);
     if (E.done[m]) { if (threadIdx.x == 0) E.stepped[m] = 0; return; }
-    head_body<HAS_BN, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b);
+    head_body<HAS_BN, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b, b);
 }
 
 // k_tail_select + conv1 of every candidate frame stack (workgroups past the first n_items): whichever action the policy picks in
@@ -432,17 +437,16 @@ __global__ __launch_bounds__(256) void k_tail_select_conv1(FwdArgs A, EnvArgs E,
     if ((int)blockIdx.x < n_items) {
         HeadLds<false> &H = *reinterpret_cast<HeadLds<false> *>(lds);
         const int b = blockIdx.x;
-        const int g = list ? list[b / gsize] : b / gsize;
-        const int m = g * gsize + b % gsize;
+        const int m = env_member(E, list, gsize, b);
         if (E.done[m]) { if (threadIdx.x == 0) E.stepped[m] = 0; return; }
-        head_body<HAS_BN, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b);
+        head_body<HAS_BN, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b, b);
         return;
     }
     Conv1Lds &S = *reinterpret_cast<Conv1Lds *>(lds);
     const int cb = (int)blockIdx.x - n_items, part = cb % nsplit, ba = cb / nsplit, b = ba / nact, a = ba % nact;
-    const int g = list ? list[b / gsize] : b / gsize;
     Item it;
-    it.member = g * gsize + b % gsize;
+    it.member = env_member(E, list, gsize, b);
+    it.pos = A.tt.n > 0 ? b : -1;
     if (E.done[it.member]) return;
     it.row = b * SPEC_ACTIONS + a;
     it.ob = E.spec_stacks + (size_t)it.row * OB_BYTES;
@@ -469,7 +473,11 @@ __global__ __launch_bounds__(1024) void k_compact(const int32_t *__restrict__ do
         __syncthreads();
         int before = 0, total = 0;
         for (int k = 0; k < 16; k++) { before += k < wv ? wave_tot[k] : 0; total += wave_tot[k]; }
-        if (alive) list_out[running + before + __popcll(bal & ((1ull << lane) - 1ull))] = g;
+        if (alive) {
+            const int pos = running + before + __popcll(bal & ((1ull << lane) - 1ull));
+            list_out[pos] = g;
+            if (pos < TT_MAX) count_out[8 + pos] = g;   // the head of the list travels to the host with the count (tail table)
+        }
         running += total;
         __syncthreads();
     }
@@ -529,6 +537,9 @@ struct dne_handle {
     float *ref_f32 = nullptr;        // the reference frames as padded planar floats (k_conv1_ref_shared)
     int conv1_shared = 1;            // DNE_CONV1_SHARED: reference-pass conv1 with eight members sharing a frame in LDS
     int32_t *m_slot = nullptr; int64_t *m_off = nullptr; float *m_scale = nullptr;
+    std::vector<int32_t> host_slot; std::vector<int64_t> host_off; std::vector<float> host_scale;   // what dne_set_members uploaded
+    TailTable tt{}; bool tt_on = false;   // the current burst's window as kernel arguments (at most TT_MAX members left)
+    int tt_enable = 1;               // DNE_TAIL_TABLE
     float *bn = nullptr, *bn_mom = nullptr;
     uint8_t *ram_prev = nullptr, *ram_cur = nullptr, *stacks = nullptr;
     ResizeLds *tables = nullptr;
@@ -637,6 +648,7 @@ struct dne_handle {
         A.noise = noise; A.bases = bases; A.base_stride = base_stride;
         A.m_slot = m_slot; A.m_off = m_off; A.m_scale = m_scale; A.bn = bn; A.bn_mom = bn_mom;
         A.done = use_done ? done : nullptr; A.L = L;
+        if (tt_on) A.tt = tt; else A.tt.n = 0;
         return A;
     }
     EnvArgs env(int bc_mode) const {
@@ -645,6 +657,8 @@ struct dne_handle {
         E.ret = ret; E.sign = sign; E.step_reward = step_reward; E.len = len; E.done = done; E.stepped = stepped; E.action = action; E.step_counter = nullptr;
         E.bc = bc; E.bc_mode = bc ? bc_mode : 0; E.bc_max_steps = cfg.bc_max_steps; E.immortal = dbg_immortal;
         E.spec_prev = spec_prev; E.spec_cur = spec_cur; E.spec_rw = spec_rw; E.spec_stacks = spec_stacks; E.spec_y1 = spec_y1;
+        E.tt_n = tt_on ? tt.n : 0;
+        if (tt_on) memcpy(E.tt_member, tt.member, sizeof(E.tt_member));
         return E;
     }
     hipEvent_t event(size_t i) {
@@ -860,6 +874,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
     env_int("DNE_DEBUG_SKIP", 0, 7, &h->dbg_skip);
     env_int("DNE_DEBUG_IMMORTAL", 0, 1, &h->dbg_immortal);
+    env_int("DNE_TAIL_TABLE", 0, 1, &h->tt_enable);
     env_int("DNE_RENDER_THREADS", 256, 1024, &h->render_threads); h->render_threads = wg_size(h->render_threads);
     env_int("DNE_BAND_THREADS", 256, 1024, &h->band_threads); h->band_threads = wg_size(h->band_threads);
     env_int("DNE_TAIL_FUSED_MAX", 0, 1 << 20, &h->tail_fused_max);
@@ -942,8 +957,8 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
             CH(hipEventCreateWithFlags(&h->ev_ref[w], hipEventDisableTiming));
         }
     }
-    CH(h->alloc(&h->list_a, M, "list_a")); CH(h->alloc(&h->list_b, M, "list_b")); CH(h->alloc(&h->count_dev, 8, "count_dev"));
-    CH(hipHostMalloc((void **)&h->count_host, 64, hipHostMallocDefault));
+    CH(h->alloc(&h->list_a, M, "list_a")); CH(h->alloc(&h->list_b, M, "list_b")); CH(h->alloc(&h->count_dev, 8 + TT_MAX, "count_dev"));
+    CH(hipHostMalloc((void **)&h->count_host, (8 + TT_MAX) * sizeof(int), hipHostMallocDefault));
     if (cfg->record_bc) {
         h->bc_bytes = cfg->policy_kind == DNE_KIND_ES && !cfg->bc_final_only ? M * (size_t)std::max(cfg->bc_max_steps, 1) * 128 : M * 128;
         CH(h->alloc(&h->bc, h->bc_bytes, "bc"));
@@ -1271,6 +1286,7 @@ extern "C" int dne_set_members(dne_handle *h, int n, const int32_t *slot, const 
     h->uniform_base = true;
     for (int i = 0; i < n; i++) h->uniform_base = h->uniform_base && slot[i] == slot[0];
     h->members_materialized = false;
+    h->host_slot.assign(slot, slot + n); h->host_off.assign(off, off + n); h->host_scale.assign(scale, scale + n);
     return 0;
 }
 
@@ -1497,6 +1513,7 @@ extern "C" int dne_debug_activations_large(dne_handle *h, int member, float *y1,
 // and its emulator frames, so the memory system and the matrix/vector pipes are busy at the same time.
 static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_t *env_seed, float *returns,
                      float *signreturns, int32_t *lengths, uint8_t *bc_out) {
+    h->tt_on = false;
     if (n % gsize) return h->fail("member count %d not a multiple of the group size %d", n, gsize);
     if (tslimit <= 0) return h->fail("timestep limit must be positive");
     if (bc_out && !h->bc) return h->fail("behaviour characterisations requested but the engine was created with record_bc = 0");
@@ -1537,6 +1554,19 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     };
     int *cur = h->list_a, *nxt = h->list_b;
     int total = groups;
+    // tail table: with at most TT_MAX members left the window's member descriptors ride in the kernel arguments
+    auto set_tail_table = [&](const int *host_list /* the active groups in list order, null = 0, 1, 2, ... */) {
+        h->tt_on = false;
+        if (!h->tt_enable || h->large || total * gsize > TT_MAX || (int)h->host_off.size() < n || pick_nsub(total) != 1) return;
+        h->tt.n = total * gsize;
+        for (int i = 0; i < total; i++)
+            for (int v = 0; v < gsize; v++) {
+                const int m = (host_list ? host_list[i] : i) * gsize + v, k = i * gsize + v;
+                h->tt.member[k] = m; h->tt.slot[k] = h->host_slot[m]; h->tt.scale[k] = h->host_scale[m]; h->tt.off[k] = h->host_off[m];
+            }
+        h->tt_on = true;
+    };
+    set_tail_table(nullptr);
     EnvArgs E = h->env(bc_mode);
     int t = 0;
     long long group_steps = 0, launch_sets = 0;
@@ -1665,12 +1695,16 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
         for (int s = 1; s < nsub; s++) HCHECK(h, hipStreamSynchronize(h->sub_streams[s]));
         hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, (const int32_t *)h->done, gsize, (const int *)cur,
                            total, nxt, h->count_dev);
-        HCHECK(h, hipMemcpyAsync(h->count_host, h->count_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HCHECK(h, hipMemcpyAsync(h->count_host, h->count_dev, (8 + TT_MAX) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HCHECK(h, hipStreamSynchronize(h->stream));
         total = *h->count_host;
         std::swap(cur, nxt);
+        set_tail_table(h->count_host + 8);
+        E.tt_n = h->tt_on ? h->tt.n : 0;
+        if (h->tt_on) memcpy(E.tt_member, h->tt.member, sizeof(E.tt_member));
         h->trace("eval: lock-step %d, %d active groups", t, total);
     }
+    h->tt_on = false;
     HCHECK(h, hipGetLastError());
     HCHECK(h, hipEventRecord(h->ev_b, h->stream));
     HCHECK(h, hipMemcpyAsync(returns, h->ret, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));

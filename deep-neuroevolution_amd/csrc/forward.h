@@ -26,6 +26,20 @@ struct Layout {
     int c3w, c3b;   // LargeModel only
 };
 
+// Tail of a generation (at most TT_MAX members left): a lock-step is a chain of short dependent launches, and what each of them
+// does first -- list -> member -> (noise offset, base slot, scale) -> first weight address -- is two dependent memory round trips
+// before the first useful load can be issued.  The host knows all of it (the active list comes back with the active count at
+// every compaction), so it rides in the kernel arguments: position in the window -> member and descriptors, read with scalar
+// loads from the argument segment.  n = 0: the table is not in use and the kernels read list / m_off / m_slot / m_scale.
+constexpr int TT_MAX = 48;
+struct TailTable {
+    int n;
+    int member[TT_MAX];
+    int slot[TT_MAX];
+    float scale[TT_MAX];
+    long long off[TT_MAX];
+};
+
 struct FwdArgs {
     const float *noise;
     const float *bases;      // [slots][base_stride]
@@ -37,6 +51,7 @@ struct FwdArgs {
     float *bn_mom;           // [members][608]: the batch moments behind them, mean / variance in the same layout (snapshots)
     const int32_t *done;     // per member, step mode only
     Layout L;
+    TailTable tt;
 };
 
 constexpr int OB_BYTES = 84 * 84 * 4;
@@ -45,17 +60,38 @@ typedef float f4a __attribute__((ext_vector_type(4)));
 
 struct Item {
     int member, row;
+    int pos;                 // index into the tail table, -1 when the descriptors come from memory
     const uint8_t *ob;
     bool skip;
 };
 
-__device__ __forceinline__ Item decode_item(int b, const int *__restrict__ list, int gsize, int F, int member0,
+// a member's base vector / noise slice / scale: from the tail table (scalar loads from the kernel arguments) or from memory
+__device__ __forceinline__ const float *item_base(const FwdArgs &A, const Item &it) {
+    const int slot = it.pos >= 0 ? A.tt.slot[it.pos] : A.m_slot[it.member];
+    return A.bases + (size_t)slot * A.base_stride;
+}
+__device__ __forceinline__ const float *item_eps(const FwdArgs &A, const Item &it) {
+    const long long off = it.pos >= 0 ? A.tt.off[it.pos] : (long long)A.m_off[it.member];
+    return A.noise + off;
+}
+__device__ __forceinline__ float item_scale(const FwdArgs &A, const Item &it) {
+    return it.pos >= 0 ? A.tt.scale[it.pos] : A.m_scale[it.member];
+}
+// member at position b of the window (b = group index * gsize + member within the group)
+__device__ __forceinline__ int window_member(const FwdArgs &A, const int *__restrict__ list, int gsize, int b) {
+    if (A.tt.n > 0) return A.tt.member[b];
+    const int g = list ? list[b / gsize] : b / gsize;
+    return g * gsize + b % gsize;
+}
+
+__device__ __forceinline__ Item decode_item(const FwdArgs &A, int b, const int *__restrict__ list, int gsize, int F, int member0,
                                             const uint8_t *__restrict__ stacks, const uint8_t *__restrict__ ref,
                                             const int32_t *__restrict__ done) {
     Item it;
+    it.pos = -1;
     if (F == 1) {
-        int g = list ? list[b / gsize] : b / gsize;
-        it.member = g * gsize + b % gsize;
+        it.member = window_member(A, list, gsize, b);
+        if (A.tt.n > 0) it.pos = b;
         it.row = it.member;
         it.ob = stacks + (size_t)it.member * OB_BYTES;
         it.skip = done && done[it.member];
@@ -93,9 +129,9 @@ __device__ __forceinline__ void conv1_body(Conv1Lds &S, const FwdArgs &A, const 
     float (&lut)[256] = S.lut;
     uint32_t (&img)[88 * 88] = S.img;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, ci = lane >> 4;
-    const float *base = A.bases + (size_t)A.m_slot[it.member] * A.base_stride + A.L.c1w;
-    const float *eps = A.noise + A.m_off[it.member] + A.L.c1w;
-    const float sc = A.m_scale[it.member];
+    const float *base = item_base(A, it) + A.L.c1w;
+    const float *eps = item_eps(A, it) + A.L.c1w;
+    const float sc = item_scale(A, it);
     const int wl = CO == 16 ? lane : ci * CO + half * 16 + lp;   // this lane's weight within a tap's [ci][CO] block
     float b[64];
 #pragma unroll
@@ -169,7 +205,7 @@ __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict_
                                                const uint8_t *__restrict__ stacks, const uint8_t *__restrict__ ref,
                                                float *__restrict__ y1, int nsplit) {
     __shared__ Conv1Lds S;
-    const Item it = decode_item(blockIdx.x / nsplit, list, gsize, F, member0, stacks, ref, A.done);
+    const Item it = decode_item(A, blockIdx.x / nsplit, list, gsize, F, member0, stacks, ref, A.done);
     if (it.skip) return;
     conv1_body(S, A, it, y1, blockIdx.x % nsplit, nsplit);
 }
@@ -432,9 +468,9 @@ __device__ __forceinline__ void conv2_body(Conv2Lds &S, const FwdArgs &A, const 
     float (&wsum)[4][2][16] = S.wsum;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
     const int nt = wv & 1, mt0 = 4 * (wv >> 1);
-    const float *base = A.bases + (size_t)A.m_slot[it.member] * A.base_stride + A.L.c2w;
-    const float *eps = A.noise + A.m_off[it.member] + A.L.c2w;
-    const float sc = A.m_scale[it.member];
+    const float *base = item_base(A, it) + A.L.c2w;
+    const float *eps = item_eps(A, it) + A.L.c2w;
+    const float sc = item_scale(A, it);
     const float *bn = A.bn + (size_t)it.member * 608;
     const float *src = y1_row ? y1_row : y1 + (size_t)it.row * 7056;
     float yv[28];   // all of this thread's activation loads in flight at once (its channel is tid & 15 throughout)
@@ -530,7 +566,7 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
                                                const float *__restrict__ y1, float *__restrict__ y2, int nsplit,
                                                float *__restrict__ fr /*reference pass: [rows][2][32] per-frame moments, else null*/) {
     __shared__ Conv2Lds S;
-    const Item it = decode_item(blockIdx.x / nsplit, list, gsize, F, member0, nullptr, nullptr, A.done);
+    const Item it = decode_item(A, blockIdx.x / nsplit, list, gsize, F, member0, nullptr, nullptr, A.done);
     if (it.skip) return;
     conv2_body<HAS_BN>(S, A, it, y1, y2, blockIdx.x % nsplit, nsplit, fr);
 }
@@ -553,13 +589,13 @@ __global__ __launch_bounds__(256, 2) void k_conv12(FwdArgs A, const int *__restr
                                                 float *__restrict__ y2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char conv12_raw[];
     Conv12Lds &S = *reinterpret_cast<Conv12Lds *>(conv12_raw);
-    const Item it = decode_item(blockIdx.x, list, gsize, 1, 0, stacks, nullptr, A.done);
+    const Item it = decode_item(A, blockIdx.x, list, gsize, 1, 0, stacks, nullptr, A.done);
     if (it.skip) return;
     constexpr int PS = C2_PS, RW = C2_RW;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, ci = lane >> 4;
-    const float *base = A.bases + (size_t)A.m_slot[it.member] * A.base_stride;
-    const float *eps = A.noise + A.m_off[it.member];
-    const float sc = A.m_scale[it.member];
+    const float *base = item_base(A, it);
+    const float *eps = item_eps(A, it);
+    const float sc = item_scale(A, it);
     const float *bn = A.bn + (size_t)it.member * 608;
     // ---- everything both convolutions need from memory, issued up front
     uint32_t px[28];
@@ -1571,7 +1607,8 @@ struct NoWait {
 };
 
 template <int NV, bool HAS_BN, bool WEIGHTS_FIRST, typename WaitFn>
-__device__ __forceinline__ void fc_quad_body(QuadLds<NV> &S, const FwdArgs &A, int g, int cg, int sl, const float *__restrict__ y2,
+__device__ __forceinline__ void fc_quad_body(QuadLds<NV> &S, const FwdArgs &A, const int *__restrict__ list, int item /* position of the group in the window */,
+                                             int cg, int sl, const float *__restrict__ y2,
                                              float *__restrict__ y3t /*[member][4 slices][256]*/, WaitFn wait) {
     // One workgroup per (group, 16-column block, k-slice).  Its four waves split the slice's 242 four-row groups
     // 61/61/60/60: every wave has ALL of its rows in flight at once (4x the bytes in flight of a one-wave block --
@@ -1585,21 +1622,27 @@ __device__ __forceinline__ void fc_quad_body(QuadLds<NV> &S, const FwdArgs &A, i
     const Layout &L = A.L;
     int member[NV];
     float scale[NV];
+    Item first;                                              // the group's first member: the group shares its base vector and noise slice
+    first.pos = A.tt.n > 0 ? item * NV : -1;
+    first.member = window_member(A, list, NV, item * NV);
 #pragma unroll
-    for (int v = 0; v < NV; v++) { member[v] = g * NV + v; scale[v] = A.m_scale[member[v]]; }
+    for (int v = 0; v < NV; v++) {
+        member[v] = first.member + v;
+        scale[v] = first.pos >= 0 ? A.tt.scale[first.pos + v] : A.m_scale[member[v]];
+    }
     if (A.done) {   // finished group still in the list: nothing to compute
         bool all_done = true;
 #pragma unroll
         for (int v = 0; v < NV; v++) all_done = all_done && A.done[member[v]] != 0;
         if (all_done) return;
     }
-    const int64_t off = A.m_off[member[0]];
-    const float *base = A.bases + (size_t)A.m_slot[member[0]] * A.base_stride;
+    const float *base = item_base(A, first);
+    const float *noise_slice = item_eps(A, first);
     const int col = cg * 16 + cl;
     const int kbeg = 968 * sl;
     constexpr int GW = 61;                                   // groups per wave (the last two waves use 60)
     const int g0 = wv * 60 + (wv < 2 ? wv : 2), ng = wv < 2 ? 61 : 60;
-    const float *eps = A.noise + off + L.fcw + (size_t)(kbeg + 4 * g0 + rg) * 256 + col;
+    const float *eps = noise_slice + L.fcw + (size_t)(kbeg + 4 * g0 + rg) * 256 + col;
     const float *th = base + L.fcw + (size_t)(kbeg + 4 * g0 + rg) * 256 + col;
     // The activation loads are issued first and consumed after the weight loads are in flight: loads return in order, so the
     // barrier below waits for (at most) the first weight rows, not for all of them.  WEIGHTS_FIRST (the single-launch lock-step
@@ -1723,7 +1766,7 @@ __global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restric
                                                  float *__restrict__ y3t /*[member][4 slices][256]*/) {
     __shared__ QuadLds<NV> S;
     const int item = blockIdx.x >> 6, cg = (blockIdx.x >> 2) & 15, sl = blockIdx.x & 3;
-    fc_quad_body<NV, HAS_BN, false>(S, A, list ? list[item] : item, cg, sl, y2, y3t, NoWait{});
+    fc_quad_body<NV, HAS_BN, false>(S, A, list, item, cg, sl, y2, y3t, NoWait{});
 }
 
 // Middle of the tail (a few dozen active groups): 4 workgroups per group (one per 64-column quarter), wave = k-slice,

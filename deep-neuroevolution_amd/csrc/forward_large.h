@@ -17,7 +17,7 @@ namespace dne {
 __global__ __launch_bounds__(256) void k_lconv1(FwdArgs A, const int *__restrict__ list, const uint8_t *__restrict__ stacks,
                                                 float *__restrict__ y1) {
     __shared__ Conv1Lds S;
-    const Item it = decode_item(blockIdx.x >> 1, list, 1, 1, 0, stacks, nullptr, A.done);
+    const Item it = decode_item(A, blockIdx.x >> 1, list, 1, 1, 0, stacks, nullptr, A.done);
     if (it.skip) return;
     conv1_body<32>(S, A, it, y1, 0, 1, blockIdx.x & 1);
 }

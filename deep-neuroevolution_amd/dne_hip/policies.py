@@ -347,44 +347,45 @@ class GAAtariPolicy(Policy):
         return self._flat
 
 
+class _GymBox(object):
+    """stand-in whose pickle is renamed to gym.spaces.box.Box (state: low, high)"""
+
+
+class _GymDiscrete(object):
+    """stand-in whose pickle is renamed to gym.spaces.discrete.Discrete (state: n)"""
+
+
 def _dumps_spaces(ob_shape, nact, kwargs):
     """policies.py:56: `pickle.dumps((self.args, self.kwargs))` where args are the gym spaces the policy was built with.  A stock
     checkout's Policy.Load does `cls(*args, **kwargs)` and reads ob_space.shape / ac_space.n (policies.py:306-309, 434-438), so
-    the pickle must name gym's classes.  Stand-ins registered under gym's module paths for the duration of the dump give the
-    pickle gym 0.9.4 (requirements.txt:3) produces -- Box state {low, high}, Discrete state {n} -- whether or not gym is here.
+    the pickle must name gym's classes -- whether or not gym is installed here, and without touching sys.modules (another thread
+    may be importing or unpickling gym objects at this moment).  The two stand-in classes above are pickled under their own
+    names and the GLOBAL opcodes are then renamed in the byte stream: protocol 2 writes a class reference as the text
+    `c<module>\n<name>\n`, with no length field in front of it, so the replacement is exact.  The result is the pickle gym 0.9.4
+    (requirements.txt:3) produces: Box state {low, high}, Discrete state {n}.
     The two bound arrays are written as `numpy.zeros(shape)` / `numpy.ones(shape)` calls rather than as 2 x 226 KB of buffer:
     smaller, and free of the numpy-version-specific module path (`numpy._core` vs `numpy.core`) of a pickled ndarray."""
     import io
-    import sys
-    import types
-    saved, names = {}, ('gym', 'gym.spaces', 'gym.spaces.box', 'gym.spaces.discrete')
-    try:
-        for m in names:
-            saved[m] = sys.modules.get(m)
-            sys.modules[m] = types.ModuleType(m)
-        Box = type('Box', (), {'__module__': 'gym.spaces.box'})
-        Discrete = type('Discrete', (), {'__module__': 'gym.spaces.discrete'})
-        sys.modules['gym.spaces.box'].Box, sys.modules['gym.spaces.discrete'].Discrete = Box, Discrete
-        ob, ac = Box(), Discrete()
-        ob.low, ob.high = np.zeros(ob_shape), np.ones(ob_shape)      # float64, as box.py builds them from scalar bounds
-        ac.n = int(nact)
+    ob, ac = _GymBox(), _GymDiscrete()
+    ob.low, ob.high = np.zeros(ob_shape), np.ones(ob_shape)      # float64, as box.py builds them from scalar bounds
+    ac.n = int(nact)
 
-        class _Pickler(pickle.Pickler):
-            def reducer_override(self, obj):
-                if obj is ob.low:
-                    return np.zeros, (tuple(ob_shape),)
-                if obj is ob.high:
-                    return np.ones, (tuple(ob_shape),)
-                return NotImplemented
-        out = io.BytesIO()
-        _Pickler(out, protocol=2).dump(((ob, ac), kwargs))
-        return out.getvalue()
-    finally:
-        for m in names:
-            if saved[m] is None:
-                sys.modules.pop(m, None)
-            else:
-                sys.modules[m] = saved[m]
+    class _Pickler(pickle.Pickler):
+        def reducer_override(self, obj):
+            if obj is ob.low:
+                return np.zeros, (tuple(ob_shape),)
+            if obj is ob.high:
+                return np.ones, (tuple(ob_shape),)
+            return NotImplemented
+    out = io.BytesIO()
+    _Pickler(out, protocol=2).dump(((ob, ac), kwargs))
+    blob = out.getvalue()
+    here = __name__.encode()
+    for mine, (mod, name) in ((b'_GymBox', (b'gym.spaces.box', b'Box')), (b'_GymDiscrete', (b'gym.spaces.discrete', b'Discrete'))):
+        ref = b'c' + here + b'\n' + mine + b'\n'
+        assert blob.count(ref) == 1, 'unexpected pickle layout'
+        blob = blob.replace(ref, b'c' + mod + b'\n' + name + b'\n')
+    return blob
 
 
 def _loads_spaces(blob):
