@@ -239,6 +239,17 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
         s.ram_prev[tid] = E.ram_prev[(size_t)m * 128 + tid];
         s.ram_cur[tid] = E.ram_cur[(size_t)m * 128 + tid];
     }
+    // a workgroup with more than the output layer's four waves steps the emulator for EVERY action on the lanes of its fifth wave
+    // while the others wait for their weights: the emulator does not need the forward pass, only its 1-of-nact answer (the
+    // speculative tail's idea inside one launch).  The lane of the chosen action commits; nothing is predicted or rolled back.
+    const bool own_candidates = spec_pos < 0 && blockDim.x > 256;
+    if (own_candidates && tid >= 256 && tid < 256 + nact) {
+        Emu cur = ram_load(E.ram_cur + (size_t)m * 128), prev = cur;   // skip4 overwrites prev before its first use
+        c_r = skip4(prev, cur, tid - 256, &c_over);
+        emu_pack(prev, cwp);
+        emu_pack(cur, cwc);
+        book.t = E.len[m]; book.ret = E.ret[m]; book.sign = E.sign[m];
+    }
     // this thread's row of the output layer (k = tid): nact consecutive weights of the base vector and of the noise slice
     float wth[OUT_NA], wep[OUT_NA];
     float fbt = 0.0f, fbe = 0.0f, s3 = 1.0f, h3 = 0.0f;
@@ -306,7 +317,15 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
         }
         return;
     }
-    if (tid == 0) {
+    if (own_candidates) {
+        int best = 0;
+        for (int a = 1; a < nact; a++)
+            if (lg[a] > lg[best]) best = a;   // tf.argmax: first maximum
+        if (tid == 256 + best) {
+            actions[m] = best;
+            env_commit(E, m, cwp, cwc, c_r, c_over, tslimit, RENDER ? s.ram_prev : nullptr, RENDER ? s.ram_cur : nullptr, &book);
+        }
+    } else if (tid == 0) {
         int best = 0;
         for (int a = 1; a < nact; a++)
             if (lg[a] > lg[best]) best = a;   // tf.argmax: first maximum
@@ -388,15 +407,15 @@ __global__ __launch_bounds__(256) void k_conv2_spec(FwdArgs A, EnvArgs E, const 
 }
 
 template <int NV, bool HAS_BN>
-__global__ __launch_bounds__(256) void k_fc_quad_spec(FwdArgs A, EnvArgs E, const int *__restrict__ list, int gsize,
+__global__ __launch_bounds__(512) void k_fc_tail_spec(FwdArgs A, EnvArgs E, const int *__restrict__ list, int gsize,
                                                       const float *__restrict__ y2, float *__restrict__ y3t, int n_fc_blocks,
                                                       int nact, int nbands) {
-    constexpr size_t LDS_BYTES = sizeof(EnvLds) > sizeof(QuadLds<NV>) ? sizeof(EnvLds) : sizeof(QuadLds<NV>);
+    constexpr size_t LDS_BYTES = sizeof(EnvLds) > sizeof(TailFcLds<NV>) ? sizeof(EnvLds) : sizeof(TailFcLds<NV>);
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     if ((int)blockIdx.x < n_fc_blocks) {
-        QuadLds<NV> &S = *reinterpret_cast<QuadLds<NV> *>(lds);
-        const int item = blockIdx.x >> 6, cg = (blockIdx.x >> 2) & 15, sl = blockIdx.x & 3;
-        fc_quad_body<NV, HAS_BN, false>(S, A, list, item, cg, sl, y2, y3t, NoWait{});
+        TailFcLds<NV> &S = *reinterpret_cast<TailFcLds<NV> *>(lds);
+        const int item = blockIdx.x >> 4, sl = (blockIdx.x >> 2) & 3, cb = blockIdx.x & 3;
+        fc_tail_body<NV, HAS_BN>(S, A, list, item, sl, cb, y2, y3t);
         return;
     }
     EnvLds &s = *reinterpret_cast<EnvLds *>(lds);
@@ -525,7 +544,7 @@ struct dne_handle {
     bool uniform_base = false;       // every member perturbs base slot 0 (set by dne_es_eval, cleared by dne_set_members)
     int render_bands = 4, band_threads = 512;   // tail: workgroups per frame (DNE_RENDER_BANDS, 1 = render inside k_tail_step) and their size
     int tail_fused_max = 200;        // up to this many active groups (all windows) k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
-    int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_quad_max = 24, fc_rb = 4, fc_chain_min = 1 << 30;
+    int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_rb = 4, fc_chain_min = 1 << 30;
     int M = 0, F = 0, ref_chunk = 0;
     size_t base_stride = 0;
     // device memory
@@ -540,6 +559,7 @@ struct dne_handle {
     std::vector<int32_t> host_slot; std::vector<int64_t> host_off; std::vector<float> host_scale;   // what dne_set_members uploaded
     TailTable tt{}; bool tt_on = false;   // the current burst's window as kernel arguments (at most TT_MAX members left)
     int tt_enable = 1;               // DNE_TAIL_TABLE
+    int head_threads = 320;          // DNE_HEAD_THREADS: 320 = the policy head's four waves + a fifth that steps the emulator for every action meanwhile; 256 = one lane steps it afterwards
     float *bn = nullptr, *bn_mom = nullptr;
     uint8_t *ram_prev = nullptr, *ram_cur = nullptr, *stacks = nullptr;
     ResizeLds *tables = nullptr;
@@ -871,10 +891,10 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipFuncSetAttribute((const void *)k_out<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
     env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
-    env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
     env_int("DNE_DEBUG_SKIP", 0, 7, &h->dbg_skip);
     env_int("DNE_DEBUG_IMMORTAL", 0, 1, &h->dbg_immortal);
     env_int("DNE_TAIL_TABLE", 0, 1, &h->tt_enable);
+    env_int("DNE_HEAD_THREADS", 256, 320, &h->head_threads); h->head_threads = h->head_threads >= 320 ? 320 : 256;
     env_int("DNE_RENDER_THREADS", 256, 1024, &h->render_threads); h->render_threads = wg_size(h->render_threads);
     env_int("DNE_BAND_THREADS", 256, 1024, &h->band_threads); h->band_threads = wg_size(h->band_threads);
     env_int("DNE_TAIL_FUSED_MAX", 0, 1 << 20, &h->tail_fused_max);
@@ -1326,7 +1346,7 @@ static int ref_pass(dne_handle *h, int n) {
                            h->L.c2b, h->L.bn2b, h->L.bn2g);
         if (F == 16 || F == 32 || F == 64 || F == 128) {   // matrix-core path
             const int grid = (nc + 7) / 8 * 8 * 4;   // (member, k-slice) workgroups, the four of a member on one XCD
-#define FCREF(MT) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid), dim3(256), 0, st, A, nc, m0, (const float *)y2, y3p)
+#define FCREF(MT) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid), dim3(MT == 8 ? 512 : 256), 0, st, A, nc, m0, (const float *)y2, y3p)
             if (F == 16) FCREF(1); else if (F == 32) FCREF(2); else if (F == 64) FCREF(4); else FCREF(8);
 #undef FCREF
             hipLaunchKernelGGL(k_bn3_partials, dim3(nc), dim3(256), 0, st, A, m0, F, (const float *)y3p);
@@ -1433,8 +1453,7 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
     if (count <= h->fc_tail_max) {   // latency-bound regime: 4 workgroups per group + a separate output-layer kernel
 #define FCT(NV, BN)                                                                                                          \
     do {                                                                                                                     \
-        if (count <= h->fc_quad_max) hipLaunchKernelGGL((k_fc_quad<NV, BN>), dim3(count * 64), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
-        else hipLaunchKernelGGL((k_fc_cols<NV, BN>), dim3(count * 4), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
+        hipLaunchKernelGGL((k_fc_tail<NV, BN>), dim3(count * 16), dim3(512), 0, st, A, list, (const float *)h->y2, h->y3t); \
         if (!out_fused) hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->y3, h->action, logits); \
     } while (0)
         if (gsize == 2) { if (es) FCT(2, true); else FCT(2, false); }
@@ -1616,7 +1635,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 // fused policy head + emulator (+ render): while all windows together still fit the chip one workgroup per member
                 const bool tail = !h->large && cnt <= h->fc_tail_max && total <= h->tail_fused_max;   // (the fused tail kernels are the small networks')
                 // speculative tail: the emulator + renderer outcome of every action, inside the launches of this step's forward pass
-                const bool spec = tail && nsub == 1 && h->spec_max > 0 && cnt * gsize <= h->spec_max && cnt <= h->fc_quad_max &&
+                const bool spec = tail && nsub == 1 && h->spec_max > 0 && cnt * gsize <= h->spec_max &&
                                   cnt * gsize <= h->conv_split_max && !h->dbg_skip;
                 if (spec) {
                     const int items = cnt * gsize, nact = h->cfg.n_actions, nb = h->spec_bands;
@@ -1632,7 +1651,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                     } else {
                         hipLaunchKernelGGL((k_conv2_spec<false>), dim3(items * 4 + emu_blocks), dim3(256), 0, sst, A, E, lst, gsize, (const float *)h->y1, h->y2, 4, items * 4, items, nact, (const int32_t *)h->action);
                     }
-#define FQS(NV, BN) hipLaunchKernelGGL((k_fc_quad_spec<NV, BN>), dim3(cnt * 64 + items * nact * nb), dim3(256), 0, sst, A, E, lst, gsize, (const float *)h->y2, h->y3t, cnt * 64, nact, nb)
+#define FQS(NV, BN) hipLaunchKernelGGL((k_fc_tail_spec<NV, BN>), dim3(cnt * 16 + items * nact * nb), dim3(512), 0, sst, A, E, lst, gsize, (const float *)h->y2, h->y3t, cnt * 16, nact, nb)
                     if (gsize == 2) { if (es) FQS(2, true); else FQS(2, false); }
                     else { if (es) FQS(1, true); else FQS(1, false); }
 #undef FQS
@@ -1668,15 +1687,15 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
 #define TS(BN, R, THR) hipLaunchKernelGGL((k_tail_step<BN, R>), dim3(items), dim3(THR), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action)
                     const bool es = h->L.kind == DNE_KIND_ES;
                     if (nb > 1 && items * nb <= 512) {   // few members left: policy head + emulator, then each frame over nb workgroups
-                        if (es) TS(true, false, 256); else TS(false, false, 256);
+                        if (es) TS(true, false, h->head_threads); else TS(false, false, h->head_threads);
                         hipLaunchKernelGGL(k_env_render, dim3(items * nb), dim3(h->band_threads), 0, sst, E, lst, gsize, 0, nb);
                     } else if (es) TS(true, true, 1024); else TS(false, true, 1024);
 #undef TS
                 } else if (duo_head) {
                     const FwdArgs A = h->fwd(false);
                     const int items = cnt * gsize;
-                    if (h->L.kind == DNE_KIND_ES) hipLaunchKernelGGL((k_tail_step<true, false>), dim3(items), dim3(256), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
-                    else hipLaunchKernelGGL((k_tail_step<false, false>), dim3(items), dim3(256), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
+                    if (h->L.kind == DNE_KIND_ES) hipLaunchKernelGGL((k_tail_step<true, false>), dim3(items), dim3(h->head_threads), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
+                    else hipLaunchKernelGGL((k_tail_step<false, false>), dim3(items), dim3(h->head_threads), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
                     if (!(h->dbg_skip & 4))
                         hipLaunchKernelGGL(k_env_render, dim3(items), dim3(items <= 192 ? 1024 : h->render_threads), 0, sst, E, lst, gsize, 0, 1);
                 } else launch_env_step(h, E, lst, cnt, gsize, tslimit, sst);

@@ -6,9 +6,10 @@
 // (two fp32 roundings, exactly params + noise_stdev*noise.get(...)) while it streams from the
 // SharedNoiseTable device buffer, so an antithetic pair reads its 4 MB noise slice ONCE per env-step.
 //
-// Numerics contract (identical to the CPU oracle): each dot product is an fp32 fmaf chain in
-// (kh, kw, ci) / k order starting at 0; fc = 4 k-slices of 968 rows combined ((s0+s1)+(s2+s3)) + bias;
-// batch-norm is x*scale + shift with two roundings.  Built with -ffp-contract=off.
+// Numerics contract (identical to the CPU oracle): each dot product of the convolutions is an fp32 fmaf chain in
+// (kh, kw, ci) order starting at 0; fc (oracle fc_raw) = 4 quarters of 968 rows, a quarter = the left fold of the 8 sub-slice
+// chains of 128, 120 x 7 rows, quarters combined ((q0+q1)+(q2+q3)) + bias; the output layer is a fixed binary tree
+// (out_raw_k); batch-norm is x*scale + shift with two roundings.  Built with -ffp-contract=off.
 //
 // Work decode shared by all kernels: step mode (F == 1) walks a list of active groups (ES: antithetic
 // pairs, GA: single members) and reads each member's own frame stack; reference mode (F > 1) runs F
@@ -55,6 +56,9 @@ struct FwdArgs {
 };
 
 constexpr int OB_BYTES = 84 * 84 * 4;
+// fc sub-slices within a quarter of 968 rows (oracle ORC_FC_SUB): the first has 128 rows, the other seven 120 -- every boundary is
+// a multiple of 8 rows.  A kernel that walks a quarter row by row keeps the running left fold T: at a boundary T (+)= chain, chain = 0.
+constexpr int FC_SUB0 = 128, FC_SUBN = 120;
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment
 typedef float f4a __attribute__((ext_vector_type(4)));
 
@@ -887,6 +891,12 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
         t_cur[i] = *(const f4a *)(th + ro);
     }
     constexpr int NB = 968 / RB, BPC = 64 / RB;   // batches per slice, batches per 64-row activation chunk
+    float fold[NV][4];                            // the quarter's running left fold over its sub-slices
+#pragma unroll
+    for (int v = 0; v < NV; v++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) fold[v][q] = 0.0f;
+    int next_sub = FC_SUB0;
     for (int bt = 0; bt < NB; bt++) {
         if (bt + 1 < NB) {
 #pragma unroll
@@ -929,11 +939,21 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
             for (int v = 0; v < NV; v++) xv[v] = xn[v];
             load_x(bt / BPC + 2, xn);
         }
+        if ((bt + 1) * RB == next_sub) {   // end of a sub-slice: the chain joins the quarter's running fold and starts again from 0
+#pragma unroll
+            for (int v = 0; v < NV; v++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    fold[v][q] = next_sub == FC_SUB0 ? acc[v][q] : fold[v][q] + acc[v][q];
+                    acc[v][q] = 0.0f;
+                }
+            next_sub += FC_SUBN;
+        }
     }
 #pragma unroll
     for (int v = 0; v < NV; v++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) part[wv][v][lane * 4 + q] = acc[v][q];
+        for (int q = 0; q < 4; q++) part[wv][v][lane * 4 + q] = fold[v][q];
     __syncthreads();
     float x3[NV];   // relu(bn3(y3)) of column tid, per member: this thread's input k = tid of the output layer
 #pragma unroll
@@ -1068,6 +1088,12 @@ __global__ __launch_bounds__(256) void k_fc2(FwdArgs A, const int *__restrict__ 
         t_cur[i] = *(const f4a *)(th + ro);
     }
     constexpr int NB = 968 / RB, BPC = 64 / RB;
+    float fold[NM][4];                            // the quarter's running left fold over its sub-slices
+#pragma unroll
+    for (int v = 0; v < NM; v++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) fold[v][q] = 0.0f;
+    int next_sub = FC_SUB0;
     for (int bt = 0; bt < NB; bt++) {
         if (bt + 1 < NB) {
 #pragma unroll
@@ -1099,11 +1125,21 @@ __global__ __launch_bounds__(256) void k_fc2(FwdArgs A, const int *__restrict__ 
             for (int v = 0; v < NM; v++) xv[v] = xn[v];
             load_x(bt / BPC + 2, xn);
         }
+        if ((bt + 1) * RB == next_sub) {   // end of a sub-slice (k_fc)
+#pragma unroll
+            for (int v = 0; v < NM; v++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    fold[v][q] = next_sub == FC_SUB0 ? acc[v][q] : fold[v][q] + acc[v][q];
+                    acc[v][q] = 0.0f;
+                }
+            next_sub += FC_SUBN;
+        }
     }
 #pragma unroll
     for (int v = 0; v < NM; v++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) part[wv][v][lane * 4 + q] = acc[v][q];
+        for (int q = 0; q < 4; q++) part[wv][v][lane * 4 + q] = fold[v][q];
     __syncthreads();
     const int nact = L.nact;
 #pragma unroll
@@ -1194,7 +1230,9 @@ struct DuoSide {
     const float *enext, *tnext;   // wave-uniform: the unit's next row block in the noise table / in the base vector
     const float *xs[NV];
     float scale[NV], s2[NV], h2[NV];
-    f32x2 acc[NV][2];             // this lane's 4 columns as two register pairs (v_pk_fma_f32)
+    f32x2 acc[NV][2];             // this lane's 4 columns as two register pairs (v_pk_fma_f32): the chain of the current sub-slice
+    f32x2 fold[NV][2];            // the quarter's running left fold over its finished sub-slices
+    int nb;                       // row block at which the current sub-slice ends (wave-uniform)
     float xv[NV], xn[NV];         // relu(bn2(y2)) of the current / next 64-row chunk, one row per lane
     int lb;                       // index of the row block computed next (wave-uniform)
     int sl, mem[NV];              // k-slice and members of the unit
@@ -1282,9 +1320,11 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
                 Z.h2[v] = HAS_BN ? A.bn[(size_t)Z.mem[v] * 608 + 64 + ch] : 0.0f;
                 Z.xs[v] = y2 + (size_t)Z.mem[v] * 3872 + 968 * Z.sl;
                 Z.acc[v][0] = Z.acc[v][1] = f32x2{0.0f, 0.0f};
+                Z.fold[v][0] = Z.fold[v][1] = f32x2{0.0f, 0.0f};
                 Z.xv[v] = Z.xn[v] = 0.0f;
             }
             Z.lb = 0;
+            Z.nb = FC_SUB0 / W;
         };
         init(SA, uA);
         init(SB, uB);
@@ -1369,6 +1409,17 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
                 request_x(Z, Z.lb / BPC + 2);
             }
             Z.lb++;
+            if (Z.lb == Z.nb) {   // end of a sub-slice (oracle fc_raw): the chain joins the quarter's fold and starts again from 0
+                const bool first = Z.nb == FC_SUB0 / W;
+#pragma unroll
+                for (int v = 0; v < NV; v++)
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++) {
+                        Z.fold[v][hf] = first ? Z.acc[v][hf] : Z.fold[v][hf] + Z.acc[v][hf];
+                        Z.acc[v][hf] = f32x2{0.0f, 0.0f};
+                    }
+                Z.nb += FC_SUBN / W;
+            }
         };
         auto fill = [&](auto sa, auto sb) {   // the first block of the selected sides; everything in flight has landed afterwards
             constexpr bool DA = decltype(sa)::value, DB = decltype(sb)::value;
@@ -1429,7 +1480,7 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
         auto store = [&](Side &Z) {
 #pragma unroll
             for (int v = 0; v < NV; v++) {
-                f4a o = {Z.acc[v][0][0], Z.acc[v][0][1], Z.acc[v][1][0], Z.acc[v][1][1]};
+                f4a o = {Z.fold[v][0][0], Z.fold[v][0][1], Z.fold[v][1][0], Z.fold[v][1][1]};
                 *(f4a *)(y3t + ((size_t)Z.mem[v] * 4 + Z.sl) * 256 + lane * 4) = o;
             }
         };
@@ -1446,23 +1497,28 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
 // 44 k-values, weights are formed per lane as theta + sigma*eps straight into the B operand.  The MFMA's
 // k-ordered fmaf chain per slice + the ((s0+s1)+(s2+s3)) + bias combine (k_bn3_partials) are the oracle's order.
 template <int MT>
-__global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int member0, const float *__restrict__ y2,
-                                                float *__restrict__ y3p /*[n_local][4][F][256]*/) {
-    // One workgroup per (member, k-slice); wave w owns columns 64w .. 64w+63 as four interleaved 16-column MFMA tiles
-    // (tile c = columns 64w + 4*lane + c), so a lane's four B operands of a k-row are one 16-byte load and the member's
+__global__ __launch_bounds__(MT == 8 ? 512 : 256) void k_fc_ref(FwdArgs A, int n_local, int member0, const float *__restrict__ y2,
+                                                                float *__restrict__ y3p /*[n_local][4][F][256]*/) {
+    // One workgroup per (member, quarter); a wave owns columns 64c .. 64c+63 (c = wave & 3) as four interleaved 16-column MFMA
+    // tiles (tile j = columns 64c + 4*lane + j), so a lane's four B operands of a k-row are one 16-byte load and the member's
     // activations and weights each cross the memory system once.  8-row stages through a double-buffered LDS tile.
+    // With 128 frames the 32 accumulator tiles of a column block are split over two waves (frames 0-63 / 64-127: 512 threads),
+    // so that the running fold over the sub-slices (oracle fc_raw; one more register set the size of the accumulators) still
+    // leaves two waves per SIMD.
     constexpr int F = MT * 16, KC = 8, XS = KC + 2, NST = 968 / KC, KK = KC / 4;   // XS = 10: lanes (frame, k) of a half-wave hit 32 distinct banks
-    constexpr int LD = (F * KC + 255) / 256;
+    constexpr int FH = MT == 8 ? 2 : 1, NT = 256 * FH, MW = MT / FH;               // frame halves, threads, frame tiles per wave
+    constexpr int LD = (F * KC + NT - 1) / NT;
     __shared__ float xs[2][F * XS];
     __shared__ float bn2[64];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
+    const int cb = wv & 3, m0 = (wv >> 2) * MW;                 // column block, first frame tile of this wave
     const Layout &L = A.L;
-    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;          // the four slices of a member stay on one XCD (block b -> XCD b % 8)
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;          // the four quarters of a member stay on one XCD (block b -> XCD b % 8)
     const int mloc = (q >> 2) * 8 + x, sl = q & 3;
     if (mloc >= n_local) return;
     const int member = member0 + mloc;
     const float sc = A.m_scale[member];
-    const int kbeg = 968 * sl, col0 = 64 * wv + 4 * lp;
+    const int kbeg = 968 * sl, col0 = 64 * cb + 4 * lp;
     const float *eps = A.noise + A.m_off[member] + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
     const float *th = A.bases + (size_t)A.m_slot[member] * A.base_stride + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
     const float *ysrc = y2 + (size_t)mloc * F * 3872 + kbeg;
@@ -1473,7 +1529,7 @@ __global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int memb
     auto load_stage = [&](int st) {
 #pragma unroll
         for (int j = 0; j < LD; j++) {
-            const int e = tid + 256 * j;
+            const int e = tid + NT * j;
             yr[j] = e < F * KC ? ysrc[(size_t)(e / KC) * 3872 + st * KC + e % KC] : 0.0f;
         }
 #pragma unroll
@@ -1486,7 +1542,7 @@ __global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int memb
     auto store_stage = [&](int st, int buf) {
 #pragma unroll
         for (int j = 0; j < LD; j++) {
-            const int e = tid + 256 * j;
+            const int e = tid + NT * j;
             if (e < F * KC) {
                 const int ch = (kbeg + st * KC + e % KC) & 31;
                 float t = yr[j] * bn2[ch];
@@ -1495,11 +1551,11 @@ __global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int memb
             }
         }
     };
-    f32x4 acc[MT][4];
+    f32x4 acc[MW][4], fold[MW][4];
 #pragma unroll
-    for (int m = 0; m < MT; m++)
+    for (int m = 0; m < MW; m++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) acc[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < 4; c++) acc[m][c] = fold[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     float w[KK][4];
     auto form_w = [&]() {
 #pragma unroll
@@ -1512,17 +1568,29 @@ __global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int memb
     store_stage(0, 0);
     form_w();
     __syncthreads();
+    int next_sub = FC_SUB0 / KC;
     for (int st = 0; st < NST; st++) {
         const int buf = st & 1;
         if (st + 1 < NST) load_stage(st + 1);
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
 #pragma unroll
-            for (int m = 0; m < MT; m++) {
-                const float a = xs[buf][(m * 16 + lp) * XS + 4 * kk + lk];
+            for (int m = 0; m < MW; m++) {
+                const float a = xs[buf][((m0 + m) * 16 + lp) * XS + 4 * kk + lk];
 #pragma unroll
                 for (int c = 0; c < 4; c++) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[kk][c], acc[m][c], 0, 0, 0);
             }
+        }
+        if (st + 1 == next_sub) {   // end of a sub-slice: the chains join the quarter's running fold and start again from 0
+            const bool first = next_sub == FC_SUB0 / KC;
+#pragma unroll
+            for (int m = 0; m < MW; m++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    fold[m][c] = first ? acc[m][c] : fold[m][c] + acc[m][c];
+                    acc[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            next_sub += FC_SUBN / KC;
         }
         if (st + 1 < NST) {
             store_stage(st + 1, buf ^ 1);
@@ -1532,10 +1600,10 @@ __global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int memb
     }
     float *out = y3p + ((size_t)(mloc * 4 + sl) * F) * 256 + col0;
 #pragma unroll
-    for (int m = 0; m < MT; m++)
+    for (int m = 0; m < MW; m++)
 #pragma unroll
         for (int r = 0; r < 4; r++)   // D[row = 4*(l>>4) + r][col = l&15] of tile c -> frame m*16 + 4*lk + r, column col0 + c
-            *(f32x4 *)(out + (size_t)(m * 16 + lk * 4 + r) * 256) = f32x4{acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
+            *(f32x4 *)(out + (size_t)((m0 + m) * 16 + lk * 4 + r) * 256) = f32x4{fold[m][0][r], fold[m][1][r], fold[m][2][r], fold[m][3][r]};
 }
 
 // bn3 statistics from the four k-slice partials: y3 = ((p0+p1)+(p2+p3)) + bias per frame, then the batch
@@ -1583,48 +1651,35 @@ __global__ __launch_bounds__(256) void k_bn3_partials(FwdArgs A, int member0, in
     A.bn_mom[(size_t)member * 608 + 352 + j] = var;
 }
 
-// ------------------------------------------------------------ fc for small active counts (the tail)
-// When only a few episodes are still running a lock-step is latency-bound, and what limits one wave streaming its
-// k-slice is the issue rate of its load instructions (~40 cycles each), not bytes.  So a wave covers 4 ROWS x 16
-// columns per load: lanes 4c..4c+3 (a DPP quad) hold four consecutive rows of column c, and the fp32 chain of that
-// column runs around the quad -- step j: lane j = fma(x[4g+j], w[row 4g+j], value from lane j-1) -- one
-// v_mov_dpp quad_perm + one v_fma per row.  Same 4 k-slices, same row order, same bits; 4x fewer load
-// instructions per slice.  One single-wave workgroup per (group, 16-column group, k-slice): 64 CUs per pair.
-// The ((s0+s1)+(s2+s3)) + bias combine, bn3, the 256 x nact output layer and the argmax run in k_out.
-template <int J>
-__device__ __forceinline__ float quad_bcast(float v) {   // every lane of a quad receives lane J's value (folds into v_fmac_f32_dpp)
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), J * 0x55, 0xf, 0xf, true));
-}
-
-template <int NV>
-struct QuadLds {
-    __attribute__((aligned(16))) float xs[NV][968];
-    float hand[NV][64];
-};
-
 struct NoWait {
     __device__ __forceinline__ bool operator()() const { return true; }
 };
 
-template <int NV, bool HAS_BN, bool WEIGHTS_FIRST, typename WaitFn>
-__device__ __forceinline__ void fc_quad_body(QuadLds<NV> &S, const FwdArgs &A, const int *__restrict__ list, int item /* position of the group in the window */,
-                                             int cg, int sl, const float *__restrict__ y2,
-                                             float *__restrict__ y3t /*[member][4 slices][256]*/, WaitFn wait) {
-    // One workgroup per (group, 16-column block, k-slice).  Its four waves split the slice's 242 four-row groups
-    // 61/61/60/60: every wave has ALL of its rows in flight at once (4x the bytes in flight of a one-wave block --
-    // this regime is pure load latency), perturbs them in registers, and then the waves run their parts of the
-    // ordered chain one after the other, handing the chain value over through LDS.  Lane (rg, cl) loads row 4g + rg of
-    // column cl; the chain takes row j's weight from lane j of the quad with a DPP operand, so all four lanes of a quad
-    // carry the same value.
-    float (&xs)[NV][968] = S.xs;
-    float (&hand)[NV][64] = S.hand;
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, rg = lane & 3, cl = lane >> 2;
+// ------------------------------------------------------------ fc for the tail of a generation (at most ~100 active groups), round 3
+// One workgroup of 8 waves per (group, quarter, 64-column block): wave i owns sub-slice i of the quarter (oracle fc_raw: 128 or
+// 120 rows, its own chain from 0 -- the 32 chains of an output run concurrently, nothing is handed from wave to wave), and the
+// eight sums meet in LDS for the quarter's left fold.  Lane (c4, r) loads 16 bytes = columns 4 c4 .. 4 c4 + 3 of row 4 g + r
+// (one instruction = four rows of the block, 1 KiB), sixteen row groups in flight per wave as a rolling window; the chain of a
+// column visits the four lanes of a quad in row order with the weight as a DPP operand (v_fmac_f32_dpp quad_perm:[j,j,j,j]), the
+// 4 columns x NV members of a lane being 8 independent chains that keep the pipeline full.  Per (group, quarter) the four column
+// blocks repeat the activation staging; the noise and base rows are read exactly once.
+template <int NV>
+struct TailFcLds {
+    __attribute__((aligned(16))) float xs[NV][968];
+    float comb[8][NV][64];
+};
+
+template <int NV, bool HAS_BN>
+__device__ __forceinline__ void fc_tail_body(TailFcLds<NV> &S, const FwdArgs &A, const int *__restrict__ list, int item, int sl, int cb,
+                                             const float *__restrict__ y2, float *__restrict__ y3t /*[member][4 quarters][256]*/) {
+    constexpr int D = 16;                                    // row groups in flight per wave
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 3, c4 = lane >> 2;
     const Layout &L = A.L;
-    int member[NV];
-    float scale[NV];
     Item first;                                              // the group's first member: the group shares its base vector and noise slice
     first.pos = A.tt.n > 0 ? item * NV : -1;
     first.member = window_member(A, list, NV, item * NV);
+    int member[NV];
+    float scale[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) {
         member[v] = first.member + v;
@@ -1636,224 +1691,155 @@ __device__ __forceinline__ void fc_quad_body(QuadLds<NV> &S, const FwdArgs &A, c
         for (int v = 0; v < NV; v++) all_done = all_done && A.done[member[v]] != 0;
         if (all_done) return;
     }
-    const float *base = item_base(A, first);
-    const float *noise_slice = item_eps(A, first);
-    const int col = cg * 16 + cl;
     const int kbeg = 968 * sl;
-    constexpr int GW = 61;                                   // groups per wave (the last two waves use 60)
-    const int g0 = wv * 60 + (wv < 2 ? wv : 2), ng = wv < 2 ? 61 : 60;
-    const float *eps = noise_slice + L.fcw + (size_t)(kbeg + 4 * g0 + rg) * 256 + col;
-    const float *th = base + L.fcw + (size_t)(kbeg + 4 * g0 + rg) * 256 + col;
-    // The activation loads are issued first and consumed after the weight loads are in flight: loads return in order, so the
-    // barrier below waits for (at most) the first weight rows, not for all of them.  WEIGHTS_FIRST (the single-launch lock-step
-    // experiment, DESIGN.md "measured and not adopted"): the weight rows go out before the activations exist, wait() blocks
-    // until their producer has signalled, then the activations load.
-    float yv[NV][4], s2[NV][4], h2[NV][4];
-    auto load_y = [&]() {
-#pragma unroll
-        for (int v = 0; v < NV; v++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int i = tid + 256 * j, ch = (kbeg + i) & 31;
-                const bool in = i < 968;
-                yv[v][j] = in ? y2[(size_t)member[v] * 3872 + kbeg + i] : 0.0f;
-                s2[v][j] = HAS_BN && in ? A.bn[(size_t)member[v] * 608 + 32 + ch] : 1.0f;
-                h2[v][j] = HAS_BN && in ? A.bn[(size_t)member[v] * 608 + 64 + ch] : 0.0f;
-            }
-    };
-    if (!WEIGHTS_FIRST) load_y();
-    __builtin_amdgcn_sched_barrier(0);
-    float e[GW], t[GW];
-#pragma unroll
-    for (int i = 0; i < GW; i++) {
-        const int ii = i < ng ? i : ng - 1;                  // wave-uniform clamp: the 61st load of a 60-group wave is a repeat
-        e[i] = eps[(size_t)(4 * ii) * 256];
-        t[i] = th[(size_t)(4 * ii) * 256];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (WEIGHTS_FIRST) {
-        if (!wait()) return;
-        load_y();
-    }
+    const int beg = wv == 0 ? 0 : FC_SUB0 + FC_SUBN * (wv - 1);     // this wave's sub-slice within the quarter
+    const int ng = (wv == 0 ? FC_SUB0 : FC_SUBN) / 4;               // its 4-row groups: 32 or 30
+    const size_t o0 = (size_t)(kbeg + beg + r) * 256 + cb * 64 + c4 * 4;
+    const float *ep = item_eps(A, first) + L.fcw + o0, *tp = item_base(A, first) + L.fcw + o0;
+    // the quarter's activations (two per thread and member): requested first, consumed after the weight rows are in flight
+    float yv[NV][2], s2[NV][2], h2[NV][2];
 #pragma unroll
     for (int v = 0; v < NV; v++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int i = tid + 256 * j;
+        for (int j = 0; j < 2; j++) {
+            const int i = tid + 512 * j, ch = (kbeg + i) & 31;
+            const bool in = i < 968;
+            yv[v][j] = in ? y2[(size_t)member[v] * 3872 + kbeg + i] : 0.0f;
+            s2[v][j] = HAS_BN && in ? A.bn[(size_t)member[v] * 608 + 32 + ch] : 1.0f;
+            h2[v][j] = HAS_BN && in ? A.bn[(size_t)member[v] * 608 + 64 + ch] : 0.0f;
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    f4u e[D];
+    f4a t[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+        e[i] = *(const f4u *)(ep + (size_t)i * 1024);
+        t[i] = *(const f4a *)(tp + (size_t)i * 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 0; v < NV; v++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int i = tid + 512 * j;
             if (i < 968) {
                 float x = yv[v][j];
                 if (HAS_BN) {
                     x = x * s2[v][j];
                     x = x + h2[v][j];
                 }
-                xs[v][i] = x > 0.0f ? x : 0.0f;
+                S.xs[v][i] = x > 0.0f ? x : 0.0f;
             }
         }
     __syncthreads();
-    // perturbed weights in place: e[] <- the first member's weight, t[] <- the second's
+    float acc[NV][4];
 #pragma unroll
-    for (int i = 0; i < GW; i++) {
-        const float ee = e[i], tt = t[i];
-        float pv = scale[0] * ee;
-        e[i] = tt + pv;
-        if (NV == 2) {
-            float pw = scale[NV - 1] * ee;
-            t[i] = tt + pw;
-        }
-    }
-    float acc[NV];
+    for (int v = 0; v < NV; v++)
 #pragma unroll
-    for (int v = 0; v < NV; v++) acc[v] = 0.0f;
-    for (int p = 0; p < 4; p++) {
-        if (wv == p) {
-            if (p > 0) {
+        for (int q = 0; q < 4; q++) acc[v][q] = 0.0f;
 #pragma unroll
-                for (int v = 0; v < NV; v++) acc[v] = hand[v][lane];
-            }
-            f4a xn[NV];
+    for (int g = 0; g < FC_SUB0 / 4; g++) {
+        if (g < ng) {
+            const int slot = g % D;
+            f4a x4[NV];
+            float w[NV][4];
 #pragma unroll
-            for (int v = 0; v < NV; v++) xn[v] = *(const f4a *)&xs[v][4 * g0];   // rows 4g .. 4g+3 (broadcast), one group ahead
+            for (int v = 0; v < NV; v++) {
+                x4[v] = *(const f4a *)&S.xs[v][beg + 4 * g];        // rows 4g .. 4g+3 of the sub-slice (broadcast read)
 #pragma unroll
-            for (int i = 0; i < GW; i++) {
-                if (i < ng) {
-                    f4a x4[NV];
-#pragma unroll
-                    for (int v = 0; v < NV; v++) {
-                        x4[v] = xn[v];
-                        xn[v] = *(const f4a *)&xs[v][4 * (g0 + (i + 1 < GW ? i + 1 : i))];
-                    }
-                    // row 4g + j's weight sits in lane j of the quad and enters the fused multiply-add as a DPP operand
-                    // (v_fmac_f32 = the same single-rounding fma); all four lanes carry the same chain value.  s_nop:
-                    // the two wait states a DPP read needs after a VALU write of its source register.
-                    if constexpr (NV == 2) {   // the two members' chains interleaved: a dependent v_fmac issues every ~8 cycles
-                        asm("s_nop 1\n\t"
-                            "v_fmac_f32_dpp %0, %2, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-                            "v_fmac_f32_dpp %1, %3, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-                            "v_fmac_f32_dpp %0, %2, %5 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-                            "v_fmac_f32_dpp %1, %3, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-                            "v_fmac_f32_dpp %0, %2, %6 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
-                            "v_fmac_f32_dpp %1, %3, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
-                            "v_fmac_f32_dpp %0, %2, %7 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
-                            "v_fmac_f32_dpp %1, %3, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
-                            : "+v"(acc[0]), "+v"(acc[NV - 1])
-                            : "v"(e[i]), "v"(t[i]), "v"(x4[0][0]), "v"(x4[0][1]), "v"(x4[0][2]), "v"(x4[0][3]),
-                              "v"(x4[NV - 1][0]), "v"(x4[NV - 1][1]), "v"(x4[NV - 1][2]), "v"(x4[NV - 1][3]));
-                    } else {
-                        asm("s_nop 1\n\t"
-                            "v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
-                            "v_fmac_f32_dpp %0, %1, %3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
-                            "v_fmac_f32_dpp %0, %1, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
-                            "v_fmac_f32_dpp %0, %1, %5 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
-                            : "+v"(acc[0])
-                            : "v"(e[i]), "v"(x4[0][0]), "v"(x4[0][1]), "v"(x4[0][2]), "v"(x4[0][3]));
-                    }
+                for (int q = 0; q < 4; q++) {
+                    float pv = scale[v] * e[slot][q];
+                    w[v][q] = t[slot][q] + pv;
                 }
             }
-            if (p < 3) {
-#pragma unroll
-                for (int v = 0; v < NV; v++) hand[v][lane] = acc[v];
-            } else if (rg == 0) {
-#pragma unroll
-                for (int v = 0; v < NV; v++) y3t[((size_t)member[v] * 4 + sl) * 256 + col] = acc[v];
+            if (g + D < ng) {                                       // this slot's registers take the group sixteen ahead
+                e[slot] = *(const f4u *)(ep + (size_t)(g + D) * 1024);
+                t[slot] = *(const f4a *)(tp + (size_t)(g + D) * 1024);
+            }
+            // row 4g + j's weights sit in lane j of the quad and enter the fused multiply-add as a DPP operand (v_fmac_f32 = the same
+            // single-rounding fma); all four lanes of a quad carry the same chain values.  s_nop: the wait states a DPP read needs
+            // after a VALU write of its source register.
+            if constexpr (NV == 2) {
+                asm("s_nop 1\n\t"
+                        "v_fmac_f32_dpp %[a00], %[w00], %[x00] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a10], %[w10], %[x10] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a01], %[w01], %[x00] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a11], %[w11], %[x10] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a02], %[w02], %[x00] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a12], %[w12], %[x10] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a03], %[w03], %[x00] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a13], %[w13], %[x10] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a00], %[w00], %[x01] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a10], %[w10], %[x11] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a01], %[w01], %[x01] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a11], %[w11], %[x11] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a02], %[w02], %[x01] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a12], %[w12], %[x11] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a03], %[w03], %[x01] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a13], %[w13], %[x11] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a00], %[w00], %[x02] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a10], %[w10], %[x12] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a01], %[w01], %[x02] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a11], %[w11], %[x12] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a02], %[w02], %[x02] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a12], %[w12], %[x12] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a03], %[w03], %[x02] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a13], %[w13], %[x12] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a00], %[w00], %[x03] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a10], %[w10], %[x13] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a01], %[w01], %[x03] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a11], %[w11], %[x13] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a02], %[w02], %[x03] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a12], %[w12], %[x13] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a03], %[w03], %[x03] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a13], %[w13], %[x13] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                        : [a00] "+v"(acc[0][0]), [a01] "+v"(acc[0][1]), [a02] "+v"(acc[0][2]), [a03] "+v"(acc[0][3]), [a10] "+v"(acc[1][0]), [a11] "+v"(acc[1][1]), [a12] "+v"(acc[1][2]), [a13] "+v"(acc[1][3])
+                        : [w00] "v"(w[0][0]), [w01] "v"(w[0][1]), [w02] "v"(w[0][2]), [w03] "v"(w[0][3]), [w10] "v"(w[1][0]), [w11] "v"(w[1][1]), [w12] "v"(w[1][2]), [w13] "v"(w[1][3]), [x00] "v"(x4[0][0]), [x01] "v"(x4[0][1]), [x02] "v"(x4[0][2]), [x03] "v"(x4[0][3]), [x10] "v"(x4[1][0]), [x11] "v"(x4[1][1]), [x12] "v"(x4[1][2]), [x13] "v"(x4[1][3]));
+            } else {
+                asm("s_nop 1\n\t"
+                        "v_fmac_f32_dpp %[a00], %[w00], %[x00] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a01], %[w01], %[x00] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a02], %[w02], %[x00] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a03], %[w03], %[x00] quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a00], %[w00], %[x01] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a01], %[w01], %[x01] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a02], %[w02], %[x01] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a03], %[w03], %[x01] quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a00], %[w00], %[x02] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a01], %[w01], %[x02] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a02], %[w02], %[x02] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a03], %[w03], %[x02] quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a00], %[w00], %[x03] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a01], %[w01], %[x03] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a02], %[w02], %[x03] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                        "v_fmac_f32_dpp %[a03], %[w03], %[x03] quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                        : [a00] "+v"(acc[0][0]), [a01] "+v"(acc[0][1]), [a02] "+v"(acc[0][2]), [a03] "+v"(acc[0][3])
+                        : [w00] "v"(w[0][0]), [w01] "v"(w[0][1]), [w02] "v"(w[0][2]), [w03] "v"(w[0][3]), [x00] "v"(x4[0][0]), [x01] "v"(x4[0][1]), [x02] "v"(x4[0][2]), [x03] "v"(x4[0][3]));
             }
         }
-        if (p < 3) __syncthreads();
     }
-}
-
-template <int NV, bool HAS_BN>
-__global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
-                                                 float *__restrict__ y3t /*[member][4 slices][256]*/) {
-    __shared__ QuadLds<NV> S;
-    const int item = blockIdx.x >> 6, cg = (blockIdx.x >> 2) & 15, sl = blockIdx.x & 3;
-    fc_quad_body<NV, HAS_BN, false>(S, A, list, item, cg, sl, y2, y3t, NoWait{});
-}
-
-// Middle of the tail (a few dozen active groups): 4 workgroups per group (one per 64-column quarter), wave = k-slice,
-// lane = ONE output column with 2 x 44 rows in flight.  Fewer, fatter workgroups than k_fc_quad -- faster once the
-// quad kernel's 64 workgroups per group no longer fit the chip at once.  Same partial-sum output.
-template <int NV, bool HAS_BN>
-__global__ __launch_bounds__(256) void k_fc_cols(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
-                                                 float *__restrict__ y3t /*[member][4 slices][256]*/) {
-    __shared__ float xs[4][NV][968];
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const Layout &L = A.L;
-    const int item = blockIdx.x >> 2, cq = blockIdx.x & 3;
-    const int g = list ? list[item] : item;
-    int member[NV];
-    float scale[NV];
-#pragma unroll
-    for (int v = 0; v < NV; v++) { member[v] = g * NV + v; scale[v] = A.m_scale[member[v]]; }
-    if (A.done) {   // finished group still in the list: nothing to compute
-        bool all_done = true;
-#pragma unroll
-        for (int v = 0; v < NV; v++) all_done = all_done && A.done[member[v]] != 0;
-        if (all_done) return;
-    }
-    const int64_t off = A.m_off[member[0]];
-    const float *base = A.bases + (size_t)A.m_slot[member[0]] * A.base_stride;
-    const int col = cq * 64 + lane;
-    const int kbeg = 968 * wv;
-    const float *eps = A.noise + off + L.fcw + (size_t)kbeg * 256 + col;
-    const float *th = base + L.fcw + (size_t)kbeg * 256 + col;
-    constexpr int RB = 44;
-    float e_cur[RB], t_cur[RB], e_nxt[RB], t_nxt[RB];
-#pragma unroll
-    for (int i = 0; i < RB; i++) { e_cur[i] = eps[(size_t)i * 256]; t_cur[i] = th[(size_t)i * 256]; }
-    {
-        float yv[NV][16], s2[NV], h2[NV];
-        const int ch = (kbeg + lane) & 31;
-#pragma unroll
-        for (int v = 0; v < NV; v++) {
-            s2[v] = HAS_BN ? A.bn[(size_t)member[v] * 608 + 32 + ch] : 1.0f;
-            h2[v] = HAS_BN ? A.bn[(size_t)member[v] * 608 + 64 + ch] : 0.0f;
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int i = lane + 64 * j;
-                yv[v][j] = i < 968 ? y2[(size_t)member[v] * 3872 + kbeg + i] : 0.0f;
-            }
-        }
+    if (r == 0) {
 #pragma unroll
         for (int v = 0; v < NV; v++)
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int i = lane + 64 * j;
-                if (i < 968) {
-                    float t = yv[v][j];
-                    if (HAS_BN) {
-                        t = t * s2[v];
-                        t = t + h2[v];
-                    }
-                    xs[wv][v][i] = t > 0.0f ? t : 0.0f;
-                }
-            }
+            for (int q = 0; q < 4; q++) S.comb[wv][v][c4 * 4 + q] = acc[v][q];
     }
     __syncthreads();
-    float acc[NV];
+    if (tid < NV * 64) {   // the quarter's left fold over its eight sub-slices
+        const int v = tid >> 6, col = tid & 63;
+        float f = S.comb[0][v][col];
 #pragma unroll
-    for (int v = 0; v < NV; v++) acc[v] = 0.0f;
-    for (int bt = 0; bt < 968 / RB; bt++) {
-        if (bt + 1 < 968 / RB) {
-#pragma unroll
-            for (int i = 0; i < RB; i++) {
-                e_nxt[i] = eps[(size_t)((bt + 1) * RB + i) * 256];
-                t_nxt[i] = th[(size_t)((bt + 1) * RB + i) * 256];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < RB; i++) {
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                float pv = scale[v] * e_cur[i];
-                const float w = t_cur[i] + pv;
-                acc[v] = __builtin_fmaf(xs[wv][v][bt * RB + i], w, acc[v]);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < RB; i++) { e_cur[i] = e_nxt[i]; t_cur[i] = t_nxt[i]; }
+        for (int i = 1; i < 8; i++) f = f + S.comb[i][v][col];
+        y3t[((size_t)(first.member + v) * 4 + sl) * 256 + cb * 64 + col] = f;
     }
-#pragma unroll
-    for (int v = 0; v < NV; v++) y3t[((size_t)member[v] * 4 + wv) * 256 + col] = acc[v];
+}
+
+template <int NV, bool HAS_BN>
+__global__ __launch_bounds__(512) void k_fc_tail(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
+                                                 float *__restrict__ y3t /*[member][4 quarters][256]*/) {
+    __shared__ TailFcLds<NV> S;
+    const int item = blockIdx.x >> 4, sl = (blockIdx.x >> 2) & 3, cb = blockIdx.x & 3;
+    fc_tail_body<NV, HAS_BN>(S, A, list, item, sl, cb, y2, y3t);
 }
 
 // fc slice combine + bias, bn3 + relu, output layer (out_products / out_wave_sums: thread = input k) + first-max argmax from the

@@ -4,7 +4,7 @@
  *
  * Numerics contract (what "bit-exact" means for the HIP engine):
  *   - every dot product of the convolutions and the fc is an fp32 fmaf chain in the stated k order, starting at 0
- *   - fc uses 4 k-slices of 968 rows combined as ((s0+s1)+(s2+s3)) + bias
+ *   - fc: 4 quarters of 968 rows, each the left fold of 8 sub-slice chains (fc_raw), combined ((q0+q1)+(q2+q3)) + bias
  *   - the output layer sums its K products by a fixed binary tree (out_raw_k)
  *   - everything else is one IEEE fp32 operation per written operator
  *   built with -ffp-contract=off so the compiler never fuses or splits
@@ -158,21 +158,36 @@ static void conv2_raw_acc(const float *w, const float *b, const float *a1 /*[21]
 }
 static void conv2_raw(const float *w, const float *b, const float *a1, float *y2) { conv2_raw_acc(w, b, a1, y2, NULL); }
 
-/* fc 3872 -> 256 (policies.py:327 / 455): 4 k-slices of 968, ((s0+s1)+(s2+s3)) + bias */
+/* fc 3872 -> 256 (policies.py:327 / 455).  TensorFlow's summation order is unknowable; the order defined
+ * here (round 3) gives a GPU 32 independent chains per output instead of 4:
+ *   the 3872 inputs are 4 quarters of 968 rows; a quarter is 8 sub-slices of 128, 120, 120, 120, 120, 120, 120, 120 rows
+ *   (every boundary a multiple of 8 rows: whole 4-row matrix-core steps and whole 8-row streaming blocks);
+ *   sub-slice sum u_i = fmaf chain over its rows in order, from 0;
+ *   quarter q = ((((((u0 + u1) + u2) + u3) + u4) + u5) + u6) + u7   (left fold: a kernel that walks a quarter needs one running sum);
+ *   y = ((q0 + q1) + (q2 + q3)) + bias.
+ * (Rounds 1-2: each quarter was one chain of 968.) */
+const int ORC_FC_SUB[9] = {0, 128, 248, 368, 488, 608, 728, 848, 968};   /* sub-slice boundaries within a quarter */
 static void fc_raw(const float *w, const float *b, const float *a2, float *y3) {
-    static __thread float part[4][256];
-    for (int s = 0; s < 4; s++) {
-        float *acc = part[s];
-        for (int j = 0; j < 256; j++) acc[j] = 0.0f;
-        for (int k = s * 968; k < (s + 1) * 968; k++) {
-            float x = a2[k];
-            const float *wk = w + (size_t)k * 256;
-            for (int j = 0; j < 256; j++) acc[j] = fmaf(x, wk[j], acc[j]);
+    static __thread float quarter[4][256];
+    float u[256];
+    for (int q = 0; q < 4; q++) {
+        float *Q = quarter[q];
+        for (int i = 0; i < 8; i++) {
+            for (int j = 0; j < 256; j++) u[j] = 0.0f;
+            for (int k = q * 968 + ORC_FC_SUB[i]; k < q * 968 + ORC_FC_SUB[i + 1]; k++) {
+                float x = a2[k];
+                const float *wk = w + (size_t)k * 256;
+                for (int j = 0; j < 256; j++) u[j] = fmaf(x, wk[j], u[j]);
+            }
+            if (i == 0)
+                for (int j = 0; j < 256; j++) Q[j] = u[j];
+            else
+                for (int j = 0; j < 256; j++) Q[j] = Q[j] + u[j];
         }
     }
     for (int j = 0; j < 256; j++) {
-        float s01 = part[0][j] + part[1][j];
-        float s23 = part[2][j] + part[3][j];
+        float s01 = quarter[0][j] + quarter[1][j];
+        float s23 = quarter[2][j] + quarter[3][j];
         float t = s01 + s23;
         y3[j] = t + b[j];
     }

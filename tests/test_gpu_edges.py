@@ -152,13 +152,14 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
     {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1"},                      # k_fc<2> streaming kernel
     {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1", "DNE_FC_RB": "2"},    # ... with 2-row batches
     {"DNE_SPEC_MAX": "0"},                                              # no speculative tail: k_tail_step + banded render (the default below steps every action under the forward pass)
-    {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0"},                      # ... with k_fc_cols
+    {"DNE_SPEC_MAX": "0", "DNE_TAIL_TABLE": "0"},                       # ... member descriptors read from memory instead of the kernel arguments
+    {"DNE_SPEC_MAX": "0", "DNE_HEAD_THREADS": "256"},                   # ... the policy head without its fifth wave: one lane steps the emulator after the argmax
+    {"DNE_TAIL_TABLE": "0"},                                            # speculative tail without the kernel-argument table
     {"DNE_SPEC_CONV1": "0"},                                            # speculative tail without the candidate conv1 (every lock-step starts at conv1)
     {"DNE_SPEC_MAX": "4"},                                              # speculative only for the last two pairs (default: the last four)
     {"DNE_SPEC_MAX": "64", "DNE_SPEC_BANDS": "2"},                      # speculative from the first lock-step on, two render workgroups per candidate
-    {"DNE_FC_QUAD_MAX": "0", "DNE_TAIL_FUSED_MAX": "0"},                # k_fc_cols + k_out + separate emulator / render launches
-    {"DNE_FC_QUAD_MAX": "0"},                                           # k_fc_cols + fused tail step
-    {"DNE_RENDER_BANDS": "1"},                                          # quad fc + tail step rendering in place
+    {"DNE_SPEC_MAX": "0", "DNE_TAIL_FUSED_MAX": "0"},                   # k_fc_tail + k_out + separate emulator / render launches
+    {"DNE_RENDER_BANDS": "1"},                                          # k_fc_tail + tail step rendering in place
     {"DNE_CONV1_FPW": "1"},                                             # reference-pass conv1 with one frame per workgroup (default 8)
     {"DNE_CONV1_FPW": "4"},
     {"DNE_CONV1_SHARED": "0"},                                          # reference-pass conv1 per member (k_conv1_ref<8>) instead of the shared float image
