@@ -407,15 +407,15 @@ __global__ __launch_bounds__(256) void k_conv2_spec(FwdArgs A, EnvArgs E, const 
 }
 
 template <int NV, bool HAS_BN>
-__global__ __launch_bounds__(512) void k_fc_tail_spec(FwdArgs A, EnvArgs E, const int *__restrict__ list, int gsize,
+__global__ __launch_bounds__(256) void k_fc_quad_spec(FwdArgs A, EnvArgs E, const int *__restrict__ list, int gsize,
                                                       const float *__restrict__ y2, float *__restrict__ y3t, int n_fc_blocks,
                                                       int nact, int nbands) {
-    constexpr size_t LDS_BYTES = sizeof(EnvLds) > sizeof(TailFcLds<NV>) ? sizeof(EnvLds) : sizeof(TailFcLds<NV>);
+    constexpr size_t LDS_BYTES = sizeof(EnvLds) > sizeof(QuadLds<NV>) ? sizeof(EnvLds) : sizeof(QuadLds<NV>);
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
     if ((int)blockIdx.x < n_fc_blocks) {
-        TailFcLds<NV> &S = *reinterpret_cast<TailFcLds<NV> *>(lds);
-        const int item = blockIdx.x >> 4, sl = (blockIdx.x >> 2) & 3, cb = blockIdx.x & 3;
-        fc_tail_body<NV, HAS_BN>(S, A, list, item, sl, cb, y2, y3t);
+        QuadLds<NV> &S = *reinterpret_cast<QuadLds<NV> *>(lds);
+        const int item = blockIdx.x >> 6, cg = (blockIdx.x >> 2) & 15, sl = blockIdx.x & 3;
+        fc_quad_body<NV, HAS_BN>(S, A, list, item, cg, sl, y2, y3t);
         return;
     }
     EnvLds &s = *reinterpret_cast<EnvLds *>(lds);
@@ -545,6 +545,8 @@ struct dne_handle {
     int render_bands = 4, band_threads = 512;   // tail: workgroups per frame (DNE_RENDER_BANDS, 1 = render inside k_tail_step) and their size
     int tail_fused_max = 200;        // up to this many active groups (all windows) k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
     int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_rb = 4, fc_chain_min = 1 << 30;
+    int fc_quad_max = 4;             // DNE_FC_QUAD_MAX: up to this many groups per window the 64-workgroups-per-group fc (k_fc_quad); above it k_fc_tail
+    int fc_tail_d8_min = 25;         // DNE_FC_TAIL_D8_MIN: from this many groups per window k_fc_tail keeps 8 instead of 16 row groups in flight (two workgroups per CU)
     int M = 0, F = 0, ref_chunk = 0;
     size_t base_stride = 0;
     // device memory
@@ -891,6 +893,8 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipFuncSetAttribute((const void *)k_out<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
     env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
+    env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
+    env_int("DNE_FC_TAIL_D8_MIN", 0, 1 << 20, &h->fc_tail_d8_min);
     env_int("DNE_DEBUG_SKIP", 0, 7, &h->dbg_skip);
     env_int("DNE_DEBUG_IMMORTAL", 0, 1, &h->dbg_immortal);
     env_int("DNE_TAIL_TABLE", 0, 1, &h->tt_enable);
@@ -1453,7 +1457,9 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
     if (count <= h->fc_tail_max) {   // latency-bound regime: 4 workgroups per group + a separate output-layer kernel
 #define FCT(NV, BN)                                                                                                          \
     do {                                                                                                                     \
-        hipLaunchKernelGGL((k_fc_tail<NV, BN>), dim3(count * 16), dim3(512), 0, st, A, list, (const float *)h->y2, h->y3t); \
+        if (count <= h->fc_quad_max) hipLaunchKernelGGL((k_fc_quad<NV, BN>), dim3(count * 64), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
+        else if (count < h->fc_tail_d8_min) hipLaunchKernelGGL((k_fc_tail<NV, BN, 16>), dim3(count * 16), dim3(512), 0, st, A, list, (const float *)h->y2, h->y3t); \
+        else hipLaunchKernelGGL((k_fc_tail<NV, BN, 8>), dim3(count * 16), dim3(512), 0, st, A, list, (const float *)h->y2, h->y3t); \
         if (!out_fused) hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->y3, h->action, logits); \
     } while (0)
         if (gsize == 2) { if (es) FCT(2, true); else FCT(2, false); }
@@ -1651,7 +1657,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                     } else {
                         hipLaunchKernelGGL((k_conv2_spec<false>), dim3(items * 4 + emu_blocks), dim3(256), 0, sst, A, E, lst, gsize, (const float *)h->y1, h->y2, 4, items * 4, items, nact, (const int32_t *)h->action);
                     }
-#define FQS(NV, BN) hipLaunchKernelGGL((k_fc_tail_spec<NV, BN>), dim3(cnt * 16 + items * nact * nb), dim3(512), 0, sst, A, E, lst, gsize, (const float *)h->y2, h->y3t, cnt * 16, nact, nb)
+#define FQS(NV, BN) hipLaunchKernelGGL((k_fc_quad_spec<NV, BN>), dim3(cnt * 64 + items * nact * nb), dim3(256), 0, sst, A, E, lst, gsize, (const float *)h->y2, h->y3t, cnt * 64, nact, nb)
                     if (gsize == 2) { if (es) FQS(2, true); else FQS(2, false); }
                     else { if (es) FQS(1, true); else FQS(1, false); }
 #undef FQS

@@ -1499,33 +1499,34 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
 template <int MT>
 __global__ __launch_bounds__(MT == 8 ? 512 : 256) void k_fc_ref(FwdArgs A, int n_local, int member0, const float *__restrict__ y2,
                                                                 float *__restrict__ y3p /*[n_local][4][F][256]*/) {
-    // One workgroup per (member, quarter); a wave owns columns 64c .. 64c+63 (c = wave & 3) as four interleaved 16-column MFMA
-    // tiles (tile j = columns 64c + 4*lane + j), so a lane's four B operands of a k-row are one 16-byte load and the member's
-    // activations and weights each cross the memory system once.  8-row stages through a double-buffered LDS tile.
-    // With 128 frames the 32 accumulator tiles of a column block are split over two waves (frames 0-63 / 64-127: 512 threads),
-    // so that the running fold over the sub-slices (oracle fc_raw; one more register set the size of the accumulators) still
-    // leaves two waves per SIMD.
+    // One workgroup per (member, quarter); a wave owns a block of 16 CW columns as CW interleaved 16-column MFMA tiles (tile j =
+    // columns CW * (16 w + lane) + j), so a lane's CW B operands of a k-row are one load and the member's activations and weights
+    // each cross the memory system once.  8-row stages through a double-buffered LDS tile.
+    // Up to 64 frames: 4 waves x 64 columns.  With 128 frames a wave would hold 32 accumulator tiles AND as many for the running
+    // fold over the sub-slices (oracle fc_raw) -- more than half the register file; 8 waves x 32 columns (16 + 16 tiles each) keep
+    // two waves per SIMD, and no weight is loaded twice.
     constexpr int F = MT * 16, KC = 8, XS = KC + 2, NST = 968 / KC, KK = KC / 4;   // XS = 10: lanes (frame, k) of a half-wave hit 32 distinct banks
-    constexpr int FH = MT == 8 ? 2 : 1, NT = 256 * FH, MW = MT / FH;               // frame halves, threads, frame tiles per wave
+    constexpr int NW = MT == 8 ? 8 : 4, NT = 64 * NW, CW = 256 / (16 * NW);        // waves, threads, column tiles per wave (2 or 4)
     constexpr int LD = (F * KC + NT - 1) / NT;
+    typedef float fcw_u __attribute__((ext_vector_type(CW), aligned(4)));          // CW consecutive floats at 4-byte alignment
+    typedef float fcw_a __attribute__((ext_vector_type(CW)));
     __shared__ float xs[2][F * XS];
     __shared__ float bn2[64];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
-    const int cb = wv & 3, m0 = (wv >> 2) * MW;                 // column block, first frame tile of this wave
     const Layout &L = A.L;
     const int x = blockIdx.x & 7, q = blockIdx.x >> 3;          // the four quarters of a member stay on one XCD (block b -> XCD b % 8)
     const int mloc = (q >> 2) * 8 + x, sl = q & 3;
     if (mloc >= n_local) return;
     const int member = member0 + mloc;
     const float sc = A.m_scale[member];
-    const int kbeg = 968 * sl, col0 = 64 * cb + 4 * lp;
+    const int kbeg = 968 * sl, col0 = CW * (16 * wv + lp);
     const float *eps = A.noise + A.m_off[member] + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
     const float *th = A.bases + (size_t)A.m_slot[member] * A.base_stride + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
     const float *ysrc = y2 + (size_t)mloc * F * 3872 + kbeg;
     if (tid < 64) bn2[tid] = A.bn[(size_t)member * 608 + 32 + tid];   // scale[32] then shift[32]
     float yr[LD];
-    f4u er[KK];
-    f4a tr[KK];
+    fcw_u er[KK];
+    fcw_a tr[KK];
     auto load_stage = [&](int st) {
 #pragma unroll
         for (int j = 0; j < LD; j++) {
@@ -1535,8 +1536,8 @@ __global__ __launch_bounds__(MT == 8 ? 512 : 256) void k_fc_ref(FwdArgs A, int n
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
             const size_t ro = (size_t)(st * KC + 4 * kk) * 256;
-            er[kk] = *(const f4u *)(eps + ro);
-            tr[kk] = *(const f4a *)(th + ro);
+            er[kk] = *(const fcw_u *)(eps + ro);
+            tr[kk] = *(const fcw_a *)(th + ro);
         }
     };
     auto store_stage = [&](int st, int buf) {
@@ -1551,17 +1552,17 @@ __global__ __launch_bounds__(MT == 8 ? 512 : 256) void k_fc_ref(FwdArgs A, int n
             }
         }
     };
-    f32x4 acc[MW][4], fold[MW][4];
+    f32x4 acc[MT][CW], fold[MT][CW];
 #pragma unroll
-    for (int m = 0; m < MW; m++)
+    for (int m = 0; m < MT; m++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) acc[m][c] = fold[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float w[KK][4];
+        for (int c = 0; c < CW; c++) acc[m][c] = fold[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float w[KK][CW];
     auto form_w = [&]() {
 #pragma unroll
         for (int kk = 0; kk < KK; kk++)
 #pragma unroll
-            for (int c = 0; c < 4; c++) { float pv = sc * er[kk][c]; w[kk][c] = tr[kk][c] + pv; }
+            for (int c = 0; c < CW; c++) { float pv = sc * er[kk][c]; w[kk][c] = tr[kk][c] + pv; }
     };
     load_stage(0);
     __syncthreads();          // bn2 visible
@@ -1575,18 +1576,18 @@ __global__ __launch_bounds__(MT == 8 ? 512 : 256) void k_fc_ref(FwdArgs A, int n
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
 #pragma unroll
-            for (int m = 0; m < MW; m++) {
-                const float a = xs[buf][((m0 + m) * 16 + lp) * XS + 4 * kk + lk];
+            for (int m = 0; m < MT; m++) {
+                const float a = xs[buf][(m * 16 + lp) * XS + 4 * kk + lk];
 #pragma unroll
-                for (int c = 0; c < 4; c++) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[kk][c], acc[m][c], 0, 0, 0);
+                for (int c = 0; c < CW; c++) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[kk][c], acc[m][c], 0, 0, 0);
             }
         }
         if (st + 1 == next_sub) {   // end of a sub-slice: the chains join the quarter's running fold and start again from 0
             const bool first = next_sub == FC_SUB0 / KC;
 #pragma unroll
-            for (int m = 0; m < MW; m++)
+            for (int m = 0; m < MT; m++)
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
+                for (int c = 0; c < CW; c++) {
                     fold[m][c] = first ? acc[m][c] : fold[m][c] + acc[m][c];
                     acc[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
@@ -1600,10 +1601,14 @@ __global__ __launch_bounds__(MT == 8 ? 512 : 256) void k_fc_ref(FwdArgs A, int n
     }
     float *out = y3p + ((size_t)(mloc * 4 + sl) * F) * 256 + col0;
 #pragma unroll
-    for (int m = 0; m < MW; m++)
+    for (int m = 0; m < MT; m++)
 #pragma unroll
-        for (int r = 0; r < 4; r++)   // D[row = 4*(l>>4) + r][col = l&15] of tile c -> frame m*16 + 4*lk + r, column col0 + c
-            *(f32x4 *)(out + (size_t)((m0 + m) * 16 + lk * 4 + r) * 256) = f32x4{fold[m][0][r], fold[m][1][r], fold[m][2][r], fold[m][3][r]};
+        for (int r = 0; r < 4; r++) {   // D[row = 4*(l>>4) + r][col = l&15] of tile c -> frame m*16 + 4*lk + r, column col0 + c
+            fcw_a o;
+#pragma unroll
+            for (int c = 0; c < CW; c++) o[c] = fold[m][c][r];
+            *(fcw_a *)(out + (size_t)(m * 16 + lk * 4 + r) * 256) = o;
+        }
 }
 
 // bn3 statistics from the four k-slice partials: y3 = ((p0+p1)+(p2+p3)) + bias per frame, then the batch
@@ -1655,6 +1660,169 @@ struct NoWait {
     __device__ __forceinline__ bool operator()() const { return true; }
 };
 
+// ------------------------------------------------------------ fc for the last handful of groups (the speculative tail)
+// With one to four groups left the layer is pure latency, and the more CUs pull on it the sooner it is over: 64 workgroups per
+// group = (16-column block, quarter), 4 waves each.  A wave takes two sub-slices of the quarter (oracle fc_raw: wave 0 rows 0-247 =
+// sub-slices 0 and 1, wave w rows 248 + 240 (w - 1) ...) and holds ALL of its rows in flight at once: lane (rg, cl) loads row
+// 4 g + rg of column cl (4 rows x 16 columns per load instruction), perturbs in registers, and runs the two chains of its
+// sub-slices, each from 0, around the DPP quad (v_fmac_f32_dpp quad_perm:[j,j,j,j]: row 4 g + j's weight sits in lane j).  The
+// four waves work concurrently -- in rounds 1-2 a quarter was one chain that the waves ran in turn -- and the eight sub-slice sums
+// meet in LDS for the quarter's left fold.
+template <int NV>
+struct QuadLds {
+    __attribute__((aligned(16))) float xs[NV][968];
+    float comb[8][NV][16];
+};
+
+template <int NV, bool HAS_BN>
+__device__ __forceinline__ void fc_quad_body(QuadLds<NV> &S, const FwdArgs &A, const int *__restrict__ list, int item /* position of the group in the window */,
+                                             int cg, int sl, const float *__restrict__ y2,
+                                             float *__restrict__ y3t /*[member][4 quarters][256]*/) {
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, rg = lane & 3, cl = lane >> 2;
+    const Layout &L = A.L;
+    Item first;                                              // the group's first member: the group shares its base vector and noise slice
+    first.pos = A.tt.n > 0 ? item * NV : -1;
+    first.member = window_member(A, list, NV, item * NV);
+    int member[NV];
+    float scale[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+        member[v] = first.member + v;
+        scale[v] = first.pos >= 0 ? A.tt.scale[first.pos + v] : A.m_scale[member[v]];
+    }
+    if (A.done) {   // finished group still in the list: nothing to compute
+        bool all_done = true;
+#pragma unroll
+        for (int v = 0; v < NV; v++) all_done = all_done && A.done[member[v]] != 0;
+        if (all_done) return;
+    }
+    const int col = cg * 16 + cl;
+    const int kbeg = 968 * sl;
+    constexpr int GW = (FC_SUB0 + FC_SUBN) / 4;              // 62: groups of the first wave (sub-slices 0 and 1); the others have 60
+    const int na = (wv == 0 ? FC_SUB0 : FC_SUBN) / 4;        // groups of this wave's first sub-slice (32 or 30), 30 in its second
+    const int ng = na + FC_SUBN / 4;
+    const int g0 = wv == 0 ? 0 : GW + (wv - 1) * (2 * FC_SUBN / 4);   // the wave's first group within the quarter
+    const size_t o0 = (size_t)(kbeg + 4 * g0 + rg) * 256 + col;
+    const float *eps = item_eps(A, first) + L.fcw + o0;
+    const float *th = item_base(A, first) + L.fcw + o0;
+    // The activation loads are issued first and consumed after the weight loads are in flight: loads return in order, so the
+    // barrier below waits for (at most) the first weight rows, not for all of them.
+    float yv[NV][4], s2[NV][4], h2[NV][4];
+#pragma unroll
+    for (int v = 0; v < NV; v++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = tid + 256 * j, ch = (kbeg + i) & 31;
+            const bool in = i < 968;
+            yv[v][j] = in ? y2[(size_t)member[v] * 3872 + kbeg + i] : 0.0f;
+            s2[v][j] = HAS_BN && in ? A.bn[(size_t)member[v] * 608 + 32 + ch] : 1.0f;
+            h2[v][j] = HAS_BN && in ? A.bn[(size_t)member[v] * 608 + 64 + ch] : 0.0f;
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    float e[GW], t[GW];
+#pragma unroll
+    for (int i = 0; i < GW; i++) {
+        const int ii = i < ng ? i : ng - 1;                  // wave-uniform clamp: loads 61 and 62 of a 60-group wave are repeats
+        e[i] = eps[(size_t)(4 * ii) * 256];
+        t[i] = th[(size_t)(4 * ii) * 256];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 0; v < NV; v++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = tid + 256 * j;
+            if (i < 968) {
+                float x = yv[v][j];
+                if (HAS_BN) {
+                    x = x * s2[v][j];
+                    x = x + h2[v][j];
+                }
+                S.xs[v][i] = x > 0.0f ? x : 0.0f;
+            }
+        }
+    __syncthreads();
+    // perturbed weights in place: e[] <- the first member's weight, t[] <- the second's
+#pragma unroll
+    for (int i = 0; i < GW; i++) {
+        const float ee = e[i], tt = t[i];
+        float pv = scale[0] * ee;
+        e[i] = tt + pv;
+        if (NV == 2) {
+            float pw = scale[NV - 1] * ee;
+            t[i] = tt + pw;
+        }
+    }
+    float acc[NV], ua[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) acc[v] = ua[v] = 0.0f;
+    f4a xn[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) xn[v] = *(const f4a *)&S.xs[v][4 * g0];   // rows 4g .. 4g+3 (broadcast), one group ahead
+#pragma unroll
+    for (int i = 0; i < GW; i++) {
+        if (i == FC_SUBN / 4 || i == FC_SUB0 / 4) {          // 30 / 32: the wave's first sub-slice may end here
+            if (i == na) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) { ua[v] = acc[v]; acc[v] = 0.0f; }
+            }
+        }
+        if (i < ng) {
+            f4a x4[NV];
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                x4[v] = xn[v];
+                xn[v] = *(const f4a *)&S.xs[v][4 * (g0 + (i + 1 < GW ? i + 1 : i))];
+            }
+            // row 4g + j's weight sits in lane j of the quad and enters the fused multiply-add as a DPP operand
+            // (v_fmac_f32 = the same single-rounding fma); all four lanes carry the same chain value.  s_nop:
+            // the two wait states a DPP read needs after a VALU write of its source register.
+            if constexpr (NV == 2) {   // the two members' chains interleaved
+                asm("s_nop 1\n\t"
+                    "v_fmac_f32_dpp %0, %2, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %1, %3, %8 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %0, %2, %5 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %1, %3, %9 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %0, %2, %6 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %1, %3, %10 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %0, %2, %7 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %1, %3, %11 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+                    : "+v"(acc[0]), "+v"(acc[NV - 1])
+                    : "v"(e[i]), "v"(t[i]), "v"(x4[0][0]), "v"(x4[0][1]), "v"(x4[0][2]), "v"(x4[0][3]),
+                      "v"(x4[NV - 1][0]), "v"(x4[NV - 1][1]), "v"(x4[NV - 1][2]), "v"(x4[NV - 1][3]));
+            } else {
+                asm("s_nop 1\n\t"
+                    "v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %0, %1, %3 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %0, %1, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf\n\t"
+                    "v_fmac_f32_dpp %0, %1, %5 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf"
+                    : "+v"(acc[0])
+                    : "v"(e[i]), "v"(x4[0][0]), "v"(x4[0][1]), "v"(x4[0][2]), "v"(x4[0][3]));
+            }
+        }
+    }
+    if (rg == 0) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) { S.comb[2 * wv][v][cl] = ua[v]; S.comb[2 * wv + 1][v][cl] = acc[v]; }
+    }
+    __syncthreads();
+    if (tid < NV * 16) {   // the quarter's left fold over its eight sub-slices
+        const int v = tid >> 4, c = tid & 15;
+        float f = S.comb[0][v][c];
+#pragma unroll
+        for (int i = 1; i < 8; i++) f = f + S.comb[i][v][c];
+        y3t[((size_t)(first.member + v) * 4 + sl) * 256 + cg * 16 + c] = f;
+    }
+}
+
+template <int NV, bool HAS_BN>
+__global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
+                                                 float *__restrict__ y3t /*[member][4 quarters][256]*/) {
+    __shared__ QuadLds<NV> S;
+    const int item = blockIdx.x >> 6, cg = (blockIdx.x >> 2) & 15, sl = blockIdx.x & 3;
+    fc_quad_body<NV, HAS_BN>(S, A, list, item, cg, sl, y2, y3t);
+}
+
 // ------------------------------------------------------------ fc for the tail of a generation (at most ~100 active groups), round 3
 // One workgroup of 8 waves per (group, quarter, 64-column block): wave i owns sub-slice i of the quarter (oracle fc_raw: 128 or
 // 120 rows, its own chain from 0 -- the 32 chains of an output run concurrently, nothing is handed from wave to wave), and the
@@ -1669,10 +1837,9 @@ struct TailFcLds {
     float comb[8][NV][64];
 };
 
-template <int NV, bool HAS_BN>
+template <int NV, bool HAS_BN, int D /* row groups in flight per wave: 16 (203 VGPRs, one workgroup per CU) or 8 (123, two) */>
 __device__ __forceinline__ void fc_tail_body(TailFcLds<NV> &S, const FwdArgs &A, const int *__restrict__ list, int item, int sl, int cb,
                                              const float *__restrict__ y2, float *__restrict__ y3t /*[member][4 quarters][256]*/) {
-    constexpr int D = 16;                                    // row groups in flight per wave
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 3, c4 = lane >> 2;
     const Layout &L = A.L;
     Item first;                                              // the group's first member: the group shares its base vector and noise slice
@@ -1834,12 +2001,12 @@ __device__ __forceinline__ void fc_tail_body(TailFcLds<NV> &S, const FwdArgs &A,
     }
 }
 
-template <int NV, bool HAS_BN>
+template <int NV, bool HAS_BN, int D>
 __global__ __launch_bounds__(512) void k_fc_tail(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
                                                  float *__restrict__ y3t /*[member][4 quarters][256]*/) {
     __shared__ TailFcLds<NV> S;
     const int item = blockIdx.x >> 4, sl = (blockIdx.x >> 2) & 3, cb = blockIdx.x & 3;
-    fc_tail_body<NV, HAS_BN>(S, A, list, item, sl, cb, y2, y3t);
+    fc_tail_body<NV, HAS_BN, D>(S, A, list, item, sl, cb, y2, y3t);
 }
 
 // fc slice combine + bias, bn3 + relu, output layer (out_products / out_wave_sums: thread = input k) + first-max argmax from the
