@@ -206,7 +206,7 @@ struct HeadLds {
 // inputs: forward.h out_products / out_wave_sums).  Everything that does not depend on the fc partial sums (this thread's
 // output-layer weights, the RAM rows, the resize tables) is issued before wait() -- a hook a producer / consumer variant would
 // block in; the kernels in use pass NoWait.
-template <bool HAS_BN, bool RENDER, typename WaitFn>
+template <bool HAS_BN, bool RENDER, bool TT, typename WaitFn>
 __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, const EnvArgs &E, int m, int tslimit,
                                           const float *__restrict__ y3t, float *__restrict__ y3, int32_t *__restrict__ actions,
                                           WaitFn wait, int pos /* position in the window (tail table), or -1 */,
@@ -217,10 +217,10 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
     const Layout &L = A.L;
     const int nact = L.nact;
     Item who;
-    who.member = m; who.pos = A.tt.n > 0 ? pos : -1;
-    const float sc = item_scale(A, who);
-    const float *base = item_base(A, who);
-    const float *noise_slice = item_eps(A, who);
+    who.member = m; who.pos = TT ? pos : -1;
+    const float sc = item_scale<TT>(A, who);
+    const float *base = item_base<TT>(A, who);
+    const float *noise_slice = item_eps<TT>(A, who);
     // speculative tail: thread a reads candidate a's outcome (and the member's bookkeeping) now, long before the choice is known
     uint32_t cwp[RAM_LIVE / 4] = {}, cwc[RAM_LIVE / 4] = {};
     int c_r = 0, c_over = 0;
@@ -346,7 +346,8 @@ __global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const 
     const int b = blockIdx.x;
     const int m = env_member(E, list, gsize, b);
     if (E.done[m]) { if (threadIdx.x == 0) E.stepped[m] = 0; return; }
-    head_body<HAS_BN, RENDER>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b);
+    if (A.tt.n > 0) head_body<HAS_BN, RENDER, true>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b);
+    else head_body<HAS_BN, RENDER, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b);
 }
 
 // The two speculative kernels ride in launches of the forward pass (same stream, no event traffic -- a cross-stream event
@@ -356,9 +357,15 @@ __global__ __launch_bounds__(256) void k_conv1_spec(FwdArgs A, EnvArgs E, const 
                                                     float *__restrict__ y1, int nsplit, int n_conv_blocks, int n_items, int nact) {
     __shared__ Conv1Lds S;
     if ((int)blockIdx.x < n_conv_blocks) {
-        const Item it = decode_item(A, blockIdx.x / nsplit, list, gsize, 1, 0, E.stacks, nullptr, A.done);
-        if (it.skip) return;
-        conv1_body(S, A, it, y1, blockIdx.x % nsplit, nsplit);
+        if (A.tt.n > 0) {
+            const Item it = decode_item<true>(A, blockIdx.x / nsplit, list, gsize, 1, 0, E.stacks, nullptr, A.done);
+            if (it.skip) return;
+            conv1_body<16, true>(S, A, it, y1, blockIdx.x % nsplit, nsplit);
+        } else {
+            const Item it = decode_item(A, blockIdx.x / nsplit, list, gsize, 1, 0, E.stacks, nullptr, A.done);
+            if (it.skip) return;
+            conv1_body(S, A, it, y1, blockIdx.x % nsplit, nsplit);
+        }
         return;
     }
     const int i = ((int)blockIdx.x - n_conv_blocks) * 256 + threadIdx.x;
@@ -385,10 +392,17 @@ __global__ __launch_bounds__(256) void k_conv2_spec(FwdArgs A, EnvArgs E, const 
     __shared__ Conv2Lds S;
     if ((int)blockIdx.x < n_conv_blocks) {
         const int b = blockIdx.x / nsplit;
-        const Item it = decode_item(A, b, list, gsize, 1, 0, nullptr, nullptr, A.done);
-        if (it.skip) return;
-        const float *row = E.spec_y1 + ((size_t)b * SPEC_ACTIONS + last_action[it.member]) * 7056;
-        conv2_body<HAS_BN>(S, A, it, y1, y2, blockIdx.x % nsplit, nsplit, nullptr, row);
+        if (A.tt.n > 0) {
+            const Item it = decode_item<true>(A, b, list, gsize, 1, 0, nullptr, nullptr, A.done);
+            if (it.skip) return;
+            const float *row = E.spec_y1 + ((size_t)b * SPEC_ACTIONS + last_action[it.member]) * 7056;
+            conv2_body<HAS_BN, true>(S, A, it, y1, y2, blockIdx.x % nsplit, nsplit, nullptr, row);
+        } else {
+            const Item it = decode_item(A, b, list, gsize, 1, 0, nullptr, nullptr, A.done);
+            if (it.skip) return;
+            const float *row = E.spec_y1 + ((size_t)b * SPEC_ACTIONS + last_action[it.member]) * 7056;
+            conv2_body<HAS_BN>(S, A, it, y1, y2, blockIdx.x % nsplit, nsplit, nullptr, row);
+        }
         return;
     }
     const int i = ((int)blockIdx.x - n_conv_blocks) * 256 + threadIdx.x;
@@ -415,7 +429,8 @@ __global__ __launch_bounds__(256) void k_fc_quad_spec(FwdArgs A, EnvArgs E, cons
     if ((int)blockIdx.x < n_fc_blocks) {
         QuadLds<NV> &S = *reinterpret_cast<QuadLds<NV> *>(lds);
         const int item = blockIdx.x >> 6, cg = (blockIdx.x >> 2) & 15, sl = blockIdx.x & 3;
-        fc_quad_body<NV, HAS_BN>(S, A, list, item, cg, sl, y2, y3t);
+        if (A.tt.n > 0) fc_quad_body<NV, HAS_BN, true>(S, A, list, item, cg, sl, y2, y3t);
+        else fc_quad_body<NV, HAS_BN, false>(S, A, list, item, cg, sl, y2, y3t);
         return;
     }
     EnvLds &s = *reinterpret_cast<EnvLds *>(lds);
@@ -442,7 +457,8 @@ __global__ __launch_bounds__(1024) void k_tail_select(FwdArgs A, EnvArgs E, cons
     const int b = blockIdx.x;
     const int m = env_member(E, list, gsize, b);
     if (E.done[m]) { if (threadIdx.x == 0) E.stepped[m] = 0; return; }
-    head_body<HAS_BN, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b, b);
+    if (A.tt.n > 0) head_body<HAS_BN, false, true>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b, b);
+    else head_body<HAS_BN, false, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b, b);
 }
 
 // k_tail_select + conv1 of every candidate frame stack (workgroups past the first n_items): whichever action the policy picks in
@@ -458,7 +474,8 @@ __global__ __launch_bounds__(256) void k_tail_select_conv1(FwdArgs A, EnvArgs E,
         const int b = blockIdx.x;
         const int m = env_member(E, list, gsize, b);
         if (E.done[m]) { if (threadIdx.x == 0) E.stepped[m] = 0; return; }
-        head_body<HAS_BN, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b, b);
+        if (A.tt.n > 0) head_body<HAS_BN, false, true>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b, b);
+    else head_body<HAS_BN, false, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b, b);
         return;
     }
     Conv1Lds &S = *reinterpret_cast<Conv1Lds *>(lds);
@@ -470,7 +487,8 @@ __global__ __launch_bounds__(256) void k_tail_select_conv1(FwdArgs A, EnvArgs E,
     it.row = b * SPEC_ACTIONS + a;
     it.ob = E.spec_stacks + (size_t)it.row * OB_BYTES;
     it.skip = false;
-    conv1_body(S, A, it, E.spec_y1, part, nsplit);
+    if (A.tt.n > 0) conv1_body<16, true>(S, A, it, E.spec_y1, part, nsplit);
+    else conv1_body(S, A, it, E.spec_y1, part, nsplit);
 }
 
 // order-preserving compaction of the active-group list
@@ -521,6 +539,7 @@ struct dne_handle {
     int conv1_fpw = 8;               // reference pass: frames per conv1 workgroup (DNE_CONV1_FPW: 1, 2, 4, 8)
     int conv_fused = 1, conv_fused_min = 129;   // DNE_CONV_FUSED / DNE_CONV_FUSED_MIN: conv1 + conv2 in one kernel from this many members
     int conv_split_max = 32;         // members up to which the convolutions use their finest split (DNE_CONV_SPLIT_MAX)
+    int conv_split_mid = 64;         // ... their middle split: conv1 over 4 workgroups up to this many members, conv2 over 2 up to twice as many (DNE_CONV_SPLIT_MID)
     int fc_pairs = 2;                // ES full-width fc: antithetic pairs per work item (DNE_FC_PAIRS, 1 = k_fc<2>)
     int fc2_min_total = 800;         // k_fc2 from this many active groups upwards (DNE_FC2_MIN)
     bool fc2_now = false;            // decided per burst by eval_core
@@ -546,7 +565,6 @@ struct dne_handle {
     int tail_fused_max = 200;        // up to this many active groups (all windows) k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
     int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_rb = 4, fc_chain_min = 1 << 30;
     int fc_quad_max = 4;             // DNE_FC_QUAD_MAX: up to this many groups per window the 64-workgroups-per-group fc (k_fc_quad); above it k_fc_tail
-    int fc_tail_d8_min = 25;         // DNE_FC_TAIL_D8_MIN: from this many groups per window k_fc_tail keeps 8 instead of 16 row groups in flight (two workgroups per CU)
     int M = 0, F = 0, ref_chunk = 0;
     size_t base_stride = 0;
     // device memory
@@ -894,7 +912,6 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
     env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
     env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
-    env_int("DNE_FC_TAIL_D8_MIN", 0, 1 << 20, &h->fc_tail_d8_min);
     env_int("DNE_DEBUG_SKIP", 0, 7, &h->dbg_skip);
     env_int("DNE_DEBUG_IMMORTAL", 0, 1, &h->dbg_immortal);
     env_int("DNE_TAIL_TABLE", 0, 1, &h->tt_enable);
@@ -905,6 +922,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_PAIRS", 1, 2, &h->fc_pairs);
     env_int("DNE_CONV1_FPW", 1, 8, &h->conv1_fpw);
     env_int("DNE_CONV_SPLIT_MAX", 0, 1 << 20, &h->conv_split_max);
+    env_int("DNE_CONV_SPLIT_MID", 0, 1 << 20, &h->conv_split_mid);
     env_int("DNE_FC2_MIN", 2, 1 << 30, &h->fc2_min_total);
     env_int("DNE_SPEC_MAX", 0, 64, &h->spec_max);
     env_int("DNE_SPEC_BANDS", 1, 12, &h->spec_bands);
@@ -1349,8 +1367,8 @@ static int ref_pass(dne_handle *h, int n) {
         hipLaunchKernelGGL((k_bn_finalize<32>), dim3((nc * 32 + 255) / 256), dim3(256), 0, st, A, m0, nc, F, (const float *)fr2, 121, 32,
                            h->L.c2b, h->L.bn2b, h->L.bn2g);
         if (F == 16 || F == 32 || F == 64 || F == 128) {   // matrix-core path
-            const int grid = (nc + 7) / 8 * 8 * 4;   // (member, k-slice) workgroups, the four of a member on one XCD
-#define FCREF(MT) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid), dim3(MT == 8 ? 512 : 256), 0, st, A, nc, m0, (const float *)y2, y3p)
+            const int grid = (nc + 7) / 8 * 8 * 4;   // (member, quarter) workgroups, those of a member on one XCD; 128 frames: two column halves each
+#define FCREF(MT) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid * (MT == 8 ? 2 : 1)), dim3(256), 0, st, A, nc, m0, (const float *)y2, y3p)
             if (F == 16) FCREF(1); else if (F == 32) FCREF(2); else if (F == 64) FCREF(4); else FCREF(8);
 #undef FCREF
             hipLaunchKernelGGL(k_bn3_partials, dim3(nc), dim3(256), 0, st, A, m0, F, (const float *)y3p);
@@ -1418,7 +1436,7 @@ static void launch_forward(dne_handle *h, const int *list, int count, int gsize,
     const bool es = h->L.kind == DNE_KIND_ES;
     const int items = count * gsize;
     // few members left: several workgroups per member (conv1: 28 position tiles over 4 or 7 workgroups; conv2: 8 over 2 or 4)
-    const int s1 = items <= h->conv_split_max ? 7 : items <= 64 ? 4 : 1, s2 = items <= h->conv_split_max ? 4 : items <= 128 ? 2 : 1;
+    const int s1 = items <= h->conv_split_max ? 7 : items <= h->conv_split_mid ? 4 : 1, s2 = items <= h->conv_split_max ? 4 : items <= 2 * h->conv_split_mid ? 2 : 1;
     if (h->conv_fused && items >= h->conv_fused_min && !h->dbg_skip) {   // one workgroup per member through both convolutions, y1 stays in LDS
         float *y1 = use_done ? nullptr : h->y1;                           // dne_act / debug_activations want y1; evaluations do not
         if (es) hipLaunchKernelGGL((k_conv12<true>), dim3(items), dim3(256), sizeof(Conv12Lds), st, A, list, gsize, (const uint8_t *)h->stacks, y1, h->y2);
@@ -1458,8 +1476,7 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
 #define FCT(NV, BN)                                                                                                          \
     do {                                                                                                                     \
         if (count <= h->fc_quad_max) hipLaunchKernelGGL((k_fc_quad<NV, BN>), dim3(count * 64), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
-        else if (count < h->fc_tail_d8_min) hipLaunchKernelGGL((k_fc_tail<NV, BN, 16>), dim3(count * 16), dim3(512), 0, st, A, list, (const float *)h->y2, h->y3t); \
-        else hipLaunchKernelGGL((k_fc_tail<NV, BN, 8>), dim3(count * 16), dim3(512), 0, st, A, list, (const float *)h->y2, h->y3t); \
+        else hipLaunchKernelGGL((k_fc_tail<NV, BN>), dim3(count * 16), dim3(512), 0, st, A, list, (const float *)h->y2, h->y3t); \
         if (!out_fused) hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->y3, h->action, logits); \
     } while (0)
         if (gsize == 2) { if (es) FCT(2, true); else FCT(2, false); }

@@ -69,33 +69,40 @@ struct Item {
     bool skip;
 };
 
-// a member's base vector / noise slice / scale: from the tail table (scalar loads from the kernel arguments) or from memory
+// a member's base vector / noise slice / scale: from the tail table (TT: scalar loads from the kernel arguments) or from memory.
+// TT is a compile-time choice -- a kernel branches once, on A.tt.n, into the body it needs -- so that the table form keeps its
+// addresses in scalar registers and neither form pays for the other.
+template <bool TT>
 __device__ __forceinline__ const float *item_base(const FwdArgs &A, const Item &it) {
-    const int slot = it.pos >= 0 ? A.tt.slot[it.pos] : A.m_slot[it.member];
+    const int slot = TT ? A.tt.slot[it.pos] : A.m_slot[it.member];
     return A.bases + (size_t)slot * A.base_stride;
 }
+template <bool TT>
 __device__ __forceinline__ const float *item_eps(const FwdArgs &A, const Item &it) {
-    const long long off = it.pos >= 0 ? A.tt.off[it.pos] : (long long)A.m_off[it.member];
+    const long long off = TT ? A.tt.off[it.pos] : (long long)A.m_off[it.member];
     return A.noise + off;
 }
+template <bool TT>
 __device__ __forceinline__ float item_scale(const FwdArgs &A, const Item &it) {
-    return it.pos >= 0 ? A.tt.scale[it.pos] : A.m_scale[it.member];
+    return TT ? A.tt.scale[it.pos] : A.m_scale[it.member];
 }
 // member at position b of the window (b = group index * gsize + member within the group)
+template <bool TT>
 __device__ __forceinline__ int window_member(const FwdArgs &A, const int *__restrict__ list, int gsize, int b) {
-    if (A.tt.n > 0) return A.tt.member[b];
+    if (TT) return A.tt.member[b];
     const int g = list ? list[b / gsize] : b / gsize;
     return g * gsize + b % gsize;
 }
 
+template <bool TT = false>
 __device__ __forceinline__ Item decode_item(const FwdArgs &A, int b, const int *__restrict__ list, int gsize, int F, int member0,
                                             const uint8_t *__restrict__ stacks, const uint8_t *__restrict__ ref,
                                             const int32_t *__restrict__ done) {
     Item it;
     it.pos = -1;
     if (F == 1) {
-        it.member = window_member(A, list, gsize, b);
-        if (A.tt.n > 0) it.pos = b;
+        it.member = window_member<TT>(A, list, gsize, b);
+        if (TT) it.pos = b;
         it.row = it.member;
         it.ob = stacks + (size_t)it.member * OB_BYTES;
         it.skip = done && done[it.member];
@@ -127,15 +134,15 @@ struct Conv1Lds {
 // member's 28 tiles to cut the latency); called by all 256 threads of a workgroup
 // CO = output channels of the layer (16; 32 for the LargeModel, whose two 16-channel halves are two calls with half = 0 / 1):
 // the weights are [kh][kw][ci][CO], the output rows [441][CO].
-template <int CO = 16>
+template <int CO = 16, bool TT = false>
 __device__ __forceinline__ void conv1_body(Conv1Lds &S, const FwdArgs &A, const Item &it, float *__restrict__ y1, int part, int nsplit,
                                            int half = 0) {
     float (&lut)[256] = S.lut;
     uint32_t (&img)[88 * 88] = S.img;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, ci = lane >> 4;
-    const float *base = item_base(A, it) + A.L.c1w;
-    const float *eps = item_eps(A, it) + A.L.c1w;
-    const float sc = item_scale(A, it);
+    const float *base = item_base<TT>(A, it) + A.L.c1w;
+    const float *eps = item_eps<TT>(A, it) + A.L.c1w;
+    const float sc = item_scale<TT>(A, it);
     const int wl = CO == 16 ? lane : ci * CO + half * 16 + lp;   // this lane's weight within a tap's [ci][CO] block
     float b[64];
 #pragma unroll
@@ -209,9 +216,15 @@ __global__ __launch_bounds__(256) void k_conv1(FwdArgs A, const int *__restrict_
                                                const uint8_t *__restrict__ stacks, const uint8_t *__restrict__ ref,
                                                float *__restrict__ y1, int nsplit) {
     __shared__ Conv1Lds S;
-    const Item it = decode_item(A, blockIdx.x / nsplit, list, gsize, F, member0, stacks, ref, A.done);
-    if (it.skip) return;
-    conv1_body(S, A, it, y1, blockIdx.x % nsplit, nsplit);
+    if (A.tt.n > 0) {
+        const Item it = decode_item<true>(A, blockIdx.x / nsplit, list, gsize, F, member0, stacks, ref, A.done);
+        if (it.skip) return;
+        conv1_body<16, true>(S, A, it, y1, blockIdx.x % nsplit, nsplit);
+    } else {
+        const Item it = decode_item(A, blockIdx.x / nsplit, list, gsize, F, member0, stacks, ref, A.done);
+        if (it.skip) return;
+        conv1_body(S, A, it, y1, blockIdx.x % nsplit, nsplit);
+    }
 }
 
 // Batch-norm moments of the reference pass, formed in the convolution epilogue (the oracle's bn_finish_tiles order): one
@@ -463,7 +476,7 @@ struct Conv2Lds {
 };
 
 // nsplit = 2 / 4: two / four workgroups share one member's position tiles
-template <bool HAS_BN>
+template <bool HAS_BN, bool TT = false>
 __device__ __forceinline__ void conv2_body(Conv2Lds &S, const FwdArgs &A, const Item &it, const float *__restrict__ y1,
                                            float *__restrict__ y2, int part, int nsplit, float *__restrict__ fr,
                                            const float *__restrict__ y1_row = nullptr /* the member's conv1 output when it is not row it.row of y1 */) {
@@ -472,9 +485,9 @@ __device__ __forceinline__ void conv2_body(Conv2Lds &S, const FwdArgs &A, const 
     float (&wsum)[4][2][16] = S.wsum;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
     const int nt = wv & 1, mt0 = 4 * (wv >> 1);
-    const float *base = item_base(A, it) + A.L.c2w;
-    const float *eps = item_eps(A, it) + A.L.c2w;
-    const float sc = item_scale(A, it);
+    const float *base = item_base<TT>(A, it) + A.L.c2w;
+    const float *eps = item_eps<TT>(A, it) + A.L.c2w;
+    const float sc = item_scale<TT>(A, it);
     const float *bn = A.bn + (size_t)it.member * 608;
     const float *src = y1_row ? y1_row : y1 + (size_t)it.row * 7056;
     float yv[28];   // all of this thread's activation loads in flight at once (its channel is tid & 15 throughout)
@@ -570,9 +583,15 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
                                                const float *__restrict__ y1, float *__restrict__ y2, int nsplit,
                                                float *__restrict__ fr /*reference pass: [rows][2][32] per-frame moments, else null*/) {
     __shared__ Conv2Lds S;
-    const Item it = decode_item(A, blockIdx.x / nsplit, list, gsize, F, member0, nullptr, nullptr, A.done);
-    if (it.skip) return;
-    conv2_body<HAS_BN>(S, A, it, y1, y2, blockIdx.x % nsplit, nsplit, fr);
+    if (A.tt.n > 0) {
+        const Item it = decode_item<true>(A, blockIdx.x / nsplit, list, gsize, F, member0, nullptr, nullptr, A.done);
+        if (it.skip) return;
+        conv2_body<HAS_BN, true>(S, A, it, y1, y2, blockIdx.x % nsplit, nsplit, fr);
+    } else {
+        const Item it = decode_item(A, blockIdx.x / nsplit, list, gsize, F, member0, nullptr, nullptr, A.done);
+        if (it.skip) return;
+        conv2_body<HAS_BN>(S, A, it, y1, y2, blockIdx.x % nsplit, nsplit, fr);
+    }
 }
 
 // ------------------------------------------------------------------------------- conv1 -> conv2 in one kernel (lock-steps)
@@ -597,9 +616,9 @@ __global__ __launch_bounds__(256, 2) void k_conv12(FwdArgs A, const int *__restr
     if (it.skip) return;
     constexpr int PS = C2_PS, RW = C2_RW;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, ci = lane >> 4;
-    const float *base = item_base(A, it);
-    const float *eps = item_eps(A, it);
-    const float sc = item_scale(A, it);
+    const float *base = item_base<false>(A, it);     // more than 128 members per launch: the tail table is never in use here
+    const float *eps = item_eps<false>(A, it);
+    const float sc = item_scale<false>(A, it);
     const float *bn = A.bn + (size_t)it.member * 608;
     // ---- everything both convolutions need from memory, issued up front
     uint32_t px[28];
@@ -1497,16 +1516,19 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
 // 44 k-values, weights are formed per lane as theta + sigma*eps straight into the B operand.  The MFMA's
 // k-ordered fmaf chain per slice + the ((s0+s1)+(s2+s3)) + bias combine (k_bn3_partials) are the oracle's order.
 template <int MT>
-__global__ __launch_bounds__(MT == 8 ? 512 : 256) void k_fc_ref(FwdArgs A, int n_local, int member0, const float *__restrict__ y2,
-                                                                float *__restrict__ y3p /*[n_local][4][F][256]*/) {
-    // One workgroup per (member, quarter); a wave owns a block of 16 CW columns as CW interleaved 16-column MFMA tiles (tile j =
-    // columns CW * (16 w + lane) + j), so a lane's CW B operands of a k-row are one load and the member's activations and weights
-    // each cross the memory system once.  8-row stages through a double-buffered LDS tile.
-    // Up to 64 frames: 4 waves x 64 columns.  With 128 frames a wave would hold 32 accumulator tiles AND as many for the running
-    // fold over the sub-slices (oracle fc_raw) -- more than half the register file; 8 waves x 32 columns (16 + 16 tiles each) keep
-    // two waves per SIMD, and no weight is loaded twice.
+__global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int member0, const float *__restrict__ y2,
+                                                float *__restrict__ y3p /*[n_local][4][F][256]*/) {
+    // One workgroup of 4 waves per (member, quarter[, column half]); a wave owns a block of 16 CW columns as CW interleaved
+    // 16-column MFMA tiles (tile j = columns col0 + j), so a lane's CW B operands of a k-row are one load.  8-row stages through a
+    // double-buffered LDS tile.
+    // Up to 64 frames: CW = 4, the workgroup covers all 256 columns, the member's activations and weights each cross the memory
+    // system once.  With 128 frames a wave would hold 32 accumulator tiles AND as many for the running fold over the sub-slices
+    // (oracle fc_raw) -- more than half the register file, i.e. one wave per SIMD; instead CW = 2 and two workgroups per quarter
+    // (columns 0-127 / 128-255: the activations are staged twice, no weight is loaded twice), 16 + 16 tiles per wave, and two
+    // independent workgroups per CU as before.  (8 waves x 32 columns in ONE workgroup were measured 58 % slower: all eight then
+    // stall at the same barrier.)
     constexpr int F = MT * 16, KC = 8, XS = KC + 2, NST = 968 / KC, KK = KC / 4;   // XS = 10: lanes (frame, k) of a half-wave hit 32 distinct banks
-    constexpr int NW = MT == 8 ? 8 : 4, NT = 64 * NW, CW = 256 / (16 * NW);        // waves, threads, column tiles per wave (2 or 4)
+    constexpr int NH = MT == 8 ? 2 : 1, NT = 256, CW = 4 / NH;                     // column halves, threads, column tiles per wave (2 or 4)
     constexpr int LD = (F * KC + NT - 1) / NT;
     typedef float fcw_u __attribute__((ext_vector_type(CW), aligned(4)));          // CW consecutive floats at 4-byte alignment
     typedef float fcw_a __attribute__((ext_vector_type(CW)));
@@ -1514,12 +1536,12 @@ __global__ __launch_bounds__(MT == 8 ? 512 : 256) void k_fc_ref(FwdArgs A, int n
     __shared__ float bn2[64];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
     const Layout &L = A.L;
-    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;          // the four quarters of a member stay on one XCD (block b -> XCD b % 8)
-    const int mloc = (q >> 2) * 8 + x, sl = q & 3;
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;          // the workgroups of a member stay on one XCD (block b -> XCD b % 8)
+    const int mloc = (q / (4 * NH)) * 8 + x, sl = q & 3, half = (q / 4) % NH;
     if (mloc >= n_local) return;
     const int member = member0 + mloc;
     const float sc = A.m_scale[member];
-    const int kbeg = 968 * sl, col0 = CW * (16 * wv + lp);
+    const int kbeg = 968 * sl, col0 = 128 * half * (NH - 1) + CW * (16 * wv + lp);
     const float *eps = A.noise + A.m_off[member] + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
     const float *th = A.bases + (size_t)A.m_slot[member] * A.base_stride + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
     const float *ysrc = y2 + (size_t)mloc * F * 3872 + kbeg;
@@ -1674,21 +1696,21 @@ struct QuadLds {
     float comb[8][NV][16];
 };
 
-template <int NV, bool HAS_BN>
+template <int NV, bool HAS_BN, bool TT>
 __device__ __forceinline__ void fc_quad_body(QuadLds<NV> &S, const FwdArgs &A, const int *__restrict__ list, int item /* position of the group in the window */,
                                              int cg, int sl, const float *__restrict__ y2,
                                              float *__restrict__ y3t /*[member][4 quarters][256]*/) {
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, rg = lane & 3, cl = lane >> 2;
     const Layout &L = A.L;
     Item first;                                              // the group's first member: the group shares its base vector and noise slice
-    first.pos = A.tt.n > 0 ? item * NV : -1;
-    first.member = window_member(A, list, NV, item * NV);
+    first.pos = TT ? item * NV : -1;
+    first.member = window_member<TT>(A, list, NV, item * NV);
     int member[NV];
     float scale[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) {
         member[v] = first.member + v;
-        scale[v] = first.pos >= 0 ? A.tt.scale[first.pos + v] : A.m_scale[member[v]];
+        scale[v] = TT ? A.tt.scale[first.pos + v] : A.m_scale[member[v]];
     }
     if (A.done) {   // finished group still in the list: nothing to compute
         bool all_done = true;
@@ -1703,8 +1725,8 @@ __device__ __forceinline__ void fc_quad_body(QuadLds<NV> &S, const FwdArgs &A, c
     const int ng = na + FC_SUBN / 4;
     const int g0 = wv == 0 ? 0 : GW + (wv - 1) * (2 * FC_SUBN / 4);   // the wave's first group within the quarter
     const size_t o0 = (size_t)(kbeg + 4 * g0 + rg) * 256 + col;
-    const float *eps = item_eps(A, first) + L.fcw + o0;
-    const float *th = item_base(A, first) + L.fcw + o0;
+    const float *eps = item_eps<TT>(A, first) + L.fcw + o0;
+    const float *th = item_base<TT>(A, first) + L.fcw + o0;
     // The activation loads are issued first and consumed after the weight loads are in flight: loads return in order, so the
     // barrier below waits for (at most) the first weight rows, not for all of them.
     float yv[NV][4], s2[NV][4], h2[NV][4];
@@ -1820,7 +1842,8 @@ __global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restric
                                                  float *__restrict__ y3t /*[member][4 quarters][256]*/) {
     __shared__ QuadLds<NV> S;
     const int item = blockIdx.x >> 6, cg = (blockIdx.x >> 2) & 15, sl = blockIdx.x & 3;
-    fc_quad_body<NV, HAS_BN>(S, A, list, item, cg, sl, y2, y3t);
+    if (A.tt.n > 0) fc_quad_body<NV, HAS_BN, true>(S, A, list, item, cg, sl, y2, y3t);
+    else fc_quad_body<NV, HAS_BN, false>(S, A, list, item, cg, sl, y2, y3t);
 }
 
 // ------------------------------------------------------------ fc for the tail of a generation (at most ~100 active groups), round 3
@@ -1837,20 +1860,21 @@ struct TailFcLds {
     float comb[8][NV][64];
 };
 
-template <int NV, bool HAS_BN, int D /* row groups in flight per wave: 16 (203 VGPRs, one workgroup per CU) or 8 (123, two) */>
+template <int NV, bool HAS_BN, bool TT>
 __device__ __forceinline__ void fc_tail_body(TailFcLds<NV> &S, const FwdArgs &A, const int *__restrict__ list, int item, int sl, int cb,
                                              const float *__restrict__ y2, float *__restrict__ y3t /*[member][4 quarters][256]*/) {
+    constexpr int D = 8;                                     // row groups in flight per wave (16: 203 VGPRs instead of 123, one workgroup per CU instead of two -- measured slower at every count)
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, r = lane & 3, c4 = lane >> 2;
     const Layout &L = A.L;
     Item first;                                              // the group's first member: the group shares its base vector and noise slice
-    first.pos = A.tt.n > 0 ? item * NV : -1;
-    first.member = window_member(A, list, NV, item * NV);
+    first.pos = TT ? item * NV : -1;
+    first.member = window_member<TT>(A, list, NV, item * NV);
     int member[NV];
     float scale[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) {
         member[v] = first.member + v;
-        scale[v] = first.pos >= 0 ? A.tt.scale[first.pos + v] : A.m_scale[member[v]];
+        scale[v] = TT ? A.tt.scale[first.pos + v] : A.m_scale[member[v]];
     }
     if (A.done) {   // finished group still in the list: nothing to compute
         bool all_done = true;
@@ -1862,7 +1886,7 @@ __device__ __forceinline__ void fc_tail_body(TailFcLds<NV> &S, const FwdArgs &A,
     const int beg = wv == 0 ? 0 : FC_SUB0 + FC_SUBN * (wv - 1);     // this wave's sub-slice within the quarter
     const int ng = (wv == 0 ? FC_SUB0 : FC_SUBN) / 4;               // its 4-row groups: 32 or 30
     const size_t o0 = (size_t)(kbeg + beg + r) * 256 + cb * 64 + c4 * 4;
-    const float *ep = item_eps(A, first) + L.fcw + o0, *tp = item_base(A, first) + L.fcw + o0;
+    const float *ep = item_eps<TT>(A, first) + L.fcw + o0, *tp = item_base<TT>(A, first) + L.fcw + o0;
     // the quarter's activations (two per thread and member): requested first, consumed after the weight rows are in flight
     float yv[NV][2], s2[NV][2], h2[NV][2];
 #pragma unroll
@@ -2001,12 +2025,13 @@ __device__ __forceinline__ void fc_tail_body(TailFcLds<NV> &S, const FwdArgs &A,
     }
 }
 
-template <int NV, bool HAS_BN, int D>
+template <int NV, bool HAS_BN>
 __global__ __launch_bounds__(512) void k_fc_tail(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
                                                  float *__restrict__ y3t /*[member][4 quarters][256]*/) {
     __shared__ TailFcLds<NV> S;
     const int item = blockIdx.x >> 4, sl = (blockIdx.x >> 2) & 3, cb = blockIdx.x & 3;
-    fc_tail_body<NV, HAS_BN, D>(S, A, list, item, sl, cb, y2, y3t);
+    if (A.tt.n > 0) fc_tail_body<NV, HAS_BN, true>(S, A, list, item, sl, cb, y2, y3t);
+    else fc_tail_body<NV, HAS_BN, false>(S, A, list, item, sl, cb, y2, y3t);
 }
 
 // fc slice combine + bias, bn3 + relu, output layer (out_products / out_wave_sums: thread = input k) + first-max argmax from the

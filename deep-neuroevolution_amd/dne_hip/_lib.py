@@ -19,7 +19,12 @@ OB_SHAPE = (84, 84, 4)
 OB_BYTES = 84 * 84 * 4
 RAM_BYTES = 128
 BN_FLOATS = 608
-ENV_MAX_EPISODE_STEPS = 400000  # gym NoFrameskip-v4 TimeLimit (raw frames); policies.py:383-385 takes the min
+# gym registers *NoFrameskip-v4 with max_episode_steps = 400000, counted by its TimeLimit wrapper in steps of the RAW environment
+# (frames).  policies.py:383-385 reads that number through env.spec and applies it as a bound on AGENT steps (one per 4 frames),
+# while the real TimeLimit sits inside the wrappers and would end the episode after 100000 agent steps.  The mirror keeps the
+# reference's arithmetic as written (min(task limit, 400000) agent steps): 4x looser than gym's own limit, never reached by the
+# BASELINE configurations (tslimit 5000) -- DESIGN.md section 5.
+ENV_MAX_EPISODE_STEPS = 400000
 
 
 class DneError(RuntimeError):

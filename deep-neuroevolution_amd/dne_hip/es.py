@@ -336,7 +336,12 @@ def run_worker(master_redis_cfg, relay_redis_cfg, noise, *, min_task_runtime=.2,
                seed=None, rank=0, world=1, reeval_after=1.0):
     """es.py:366-439 for one GPU: per task, evaluate this worker's whole shard of antithetic pairs in one
     device call and push one Result with n pairs (exactly episodes_per_batch/2 pairs per
-    generation across the `world` GPU workers).  min_task_runtime is accepted for signature parity."""
+    generation across the `world` GPU workers).  min_task_runtime is accepted for signature parity.
+    Deviation, on purpose: a reference worker's loop iteration is EITHER an evaluation episode (probability eval_prob,
+    es.py:388-405) OR a batch of pairs; a CPU fleet of hundreds of workers delivers both kinds all the time.  One GPU worker
+    delivers the whole generation in a single Result, so an iteration that only evaluated would leave the master without its
+    batch until the pacer re-evaluates: here the coin adds the evaluation episode (pushed first, as its own Result, never part
+    of the update) and the shard is evaluated in the same iteration."""
     logger.info('run_worker: {}'.format(locals()))
     assert isinstance(noise, SharedNoiseTable)
     worker = WorkerClient(relay_redis_cfg, master_redis_cfg)

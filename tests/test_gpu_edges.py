@@ -159,8 +159,8 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
     {"DNE_SPEC_MAX": "4"},                                              # speculative only for the last two pairs (default: the last four)
     {"DNE_SPEC_MAX": "64", "DNE_SPEC_BANDS": "2"},                      # speculative from the first lock-step on, two render workgroups per candidate
     {"DNE_SPEC_MAX": "0", "DNE_TAIL_FUSED_MAX": "0"},                   # k_fc_tail + k_out + separate emulator / render launches
-    {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0"},                      # k_fc_tail (16 row groups in flight) down to the last pair
-    {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0", "DNE_FC_TAIL_D8_MIN": "1"},   # ... with 8 row groups in flight (the form for > 24 groups per window)
+    {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0"},                      # k_fc_tail down to the last pair
+    {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0", "DNE_TAIL_TABLE": "0"},   # ... reading the member descriptors from memory
     {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "64"},                     # k_fc_quad (64 workgroups per pair) at every count
     {"DNE_RENDER_BANDS": "1"},                                          # k_fc_tail + tail step rendering in place
     {"DNE_CONV1_FPW": "1"},                                             # reference-pass conv1 with one frame per workgroup (default 8)
