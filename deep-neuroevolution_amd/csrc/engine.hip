@@ -588,7 +588,7 @@ struct dne_handle {
     int32_t *launch_units = nullptr; size_t launch_units_cap = 0;
     uint32_t *seeds = nullptr;
     float *y1 = nullptr, *y2 = nullptr, *y3 = nullptr, *y3t = nullptr;   // step mode: one row per member (y3t: 4 k-slice partials)
-    int ga_materialize = 0;          // DNE_GA_MATERIALIZE: GA children written out once per generation (default: on for the LargeModel)
+    int ga_materialize = 0;          // DNE_GA_MATERIALIZE: GA children written out once per generation, the streaming fc then reads plain rows (default: on for GA engines)
     bool members_materialized = false;   // the current members are plain vectors (scale 0 everywhere): kernels that have one skip the noise stream
     std::vector<int> child_slots;    // base slots set aside for materialised children
     int lfc_cols_max = 96;           // DNE_LFC_COLS_MAX: LargeModel windows of up to this many members use the column-split fc
@@ -974,12 +974,12 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(h->alloc(&h->len, M, "len")); CH(h->alloc(&h->done, M, "done")); CH(h->alloc(&h->action, M, "action")); CH(h->alloc(&h->seeds, M, "seeds")); CH(h->alloc(&h->stepped, M, "stepped"));
     CH(hipMemset(h->done, 0, M * sizeof(int32_t))); CH(hipMemset(h->len, 0, M * sizeof(int32_t)));
     h->large = cfg->policy_kind == DNE_KIND_GA_LARGE;
-    h->ga_materialize = h->large ? 1 : 0;
+    h->ga_materialize = cfg->policy_kind == DNE_KIND_ES ? 0 : 1;
     env_int("DNE_GA_MATERIALIZE", 0, 1, &h->ga_materialize);
     env_int("DNE_LFC_COLS_MAX", 0, 1 << 20, &h->lfc_cols_max);
     if (h->large) h->fc_rb = 8;      // the streamed LargeModel fc: 8-row batches measured 8 % faster than 4
     env_int("DNE_FC_RB", 2, 8, &h->fc_rb);
-    if (!h->large) h->ga_materialize = 0;   // only the LargeModel's fc has a noise-free variant
+    if (cfg->policy_kind == DNE_KIND_ES) h->ga_materialize = 0;   // ES members are antithetic pairs over one theta: nothing to write out
     if (h->large) { CH(h->alloc(&h->y1, M * 14112, "y1")); CH(h->alloc(&h->y2, M * 7744, "y2")); CH(h->alloc(&h->y3, M * 7744, "y3")); CH(h->alloc(&h->y3t, M * 512, "y3t")); }
     else { CH(h->alloc(&h->y1, M * 7056, "y1")); CH(h->alloc(&h->y2, M * 3872, "y2")); CH(h->alloc(&h->y3, M * 256, "y3")); CH(h->alloc(&h->y3t, M * 4 * 256, "y3t")); }
     CH(h->alloc(&h->unit_order, M * 4, "unit_order"));
@@ -1367,8 +1367,8 @@ static int ref_pass(dne_handle *h, int n) {
         hipLaunchKernelGGL((k_bn_finalize<32>), dim3((nc * 32 + 255) / 256), dim3(256), 0, st, A, m0, nc, F, (const float *)fr2, 121, 32,
                            h->L.c2b, h->L.bn2b, h->L.bn2g);
         if (F == 16 || F == 32 || F == 64 || F == 128) {   // matrix-core path
-            const int grid = (nc + 7) / 8 * 8 * 4;   // (member, quarter) workgroups, those of a member on one XCD; 128 frames: two column halves each
-#define FCREF(MT) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid * (MT == 8 ? 2 : 1)), dim3(256), 0, st, A, nc, m0, (const float *)y2, y3p)
+            const int grid = (nc + 7) / 8 * 8 * 4;   // (member, quarter) workgroups, the four of a member on one XCD
+#define FCREF(MT) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid), dim3(MT == 8 ? 512 : 256), 0, st, A, nc, m0, (const float *)y2, y3p)
             if (F == 16) FCREF(1); else if (F == 32) FCREF(2); else if (F == 64) FCREF(4); else FCREF(8);
 #undef FCREF
             hipLaunchKernelGGL(k_bn3_partials, dim3(nc), dim3(256), 0, st, A, m0, F, (const float *)y3p);
@@ -1505,7 +1505,10 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
     const int fc_blocks = std::min(count, h->fc_grid);   // persistent grid (an even groups-per-block split measured slower)
 #define FC(NV, BN, RB) hipLaunchKernelGGL((k_fc<NV, false, BN, RB>), dim3(fc_blocks), dim3(256), 0, st, A, list, count, 1, 0, (const float *)h->y2, h->y3, h->action, logits)
 #define FCR(NV, BN) do { if (h->fc_rb == 2) FC(NV, BN, 2); else if (h->fc_rb == 8) FC(NV, BN, 8); else FC(NV, BN, 4); } while (0)
-    if (gsize == 2) { if (es) FCR(2, true); else FCR(2, false); }
+    if (gsize == 1 && !es && h->members_materialized) {   // GA children written out once per generation: plain rows, no noise stream
+        if (h->fc_rb == 8) hipLaunchKernelGGL((k_fc<1, false, false, 8, false>), dim3(fc_blocks), dim3(256), 0, st, A, list, count, 1, 0, (const float *)h->y2, h->y3, h->action, logits);
+        else hipLaunchKernelGGL((k_fc<1, false, false, 4, false>), dim3(fc_blocks), dim3(256), 0, st, A, list, count, 1, 0, (const float *)h->y2, h->y3, h->action, logits);
+    } else if (gsize == 2) { if (es) FCR(2, true); else FCR(2, false); }
     else { if (es) FCR(1, true); else FCR(1, false); }
 #undef FCR
 #undef FC

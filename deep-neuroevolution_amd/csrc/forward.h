@@ -825,7 +825,9 @@ __device__ __forceinline__ void out_wave_sums(float (&p)[NS][OUT_NA], int nact, 
     }
 }
 
-template <int NV, bool SHARED_W, bool HAS_BN, int RB>
+// NOISE = false: the members are plain vectors (GA children written out once per generation, scale 0): the noise rows are not
+// streamed at all -- fl(base + fl(0 * eps)) = base -- which halves the bytes of a member-step.
+template <int NV, bool SHARED_W, bool HAS_BN, int RB, bool NOISE = true>
 __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ list, int n_local, int F, int member0,
                                             const float *__restrict__ y2, float *__restrict__ y3,
                                             int32_t *__restrict__ actions, float *__restrict__ logits_out) {
@@ -906,7 +908,7 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
 #pragma unroll
     for (int i = 0; i < RB; i++) {
         const size_t ro = (size_t)(kbeg + i) * 256;
-        e_cur[i] = *(const f4u *)(eps + ro);
+        if (NOISE) e_cur[i] = *(const f4u *)(eps + ro);
         t_cur[i] = *(const f4a *)(th + ro);
     }
     constexpr int NB = 968 / RB, BPC = 64 / RB;   // batches per slice, batches per 64-row activation chunk
@@ -921,7 +923,7 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
 #pragma unroll
             for (int i = 0; i < RB; i++) {
                 const size_t ro = (size_t)(kbeg + (bt + 1) * RB + i) * 256;
-                e_nxt[i] = *(const f4u *)(eps + ro);
+                if (NOISE) e_nxt[i] = *(const f4u *)(eps + ro);
                 t_nxt[i] = *(const f4a *)(th + ro);
             }
         }
@@ -931,7 +933,7 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
             if (SHARED_W) {
                 f4a w;
 #pragma unroll
-                for (int q = 0; q < 4; q++) { float pv = scale[0] * e_cur[i][q]; w[q] = t_cur[i][q] + pv; }
+                for (int q = 0; q < 4; q++) { float pv = NOISE ? scale[0] * e_cur[i][q] : 0.0f; w[q] = NOISE ? t_cur[i][q] + pv : t_cur[i][q]; }
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
                     const float x = lane_bcast(xv[v], li + i);
@@ -944,15 +946,15 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
                     const float x = lane_bcast(xv[v], li + i);
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        float pv = scale[v] * e_cur[i][q];
-                        float w = t_cur[i][q] + pv;
+                        float pv = NOISE ? scale[v] * e_cur[i][q] : 0.0f;
+                        float w = NOISE ? t_cur[i][q] + pv : t_cur[i][q];
                         acc[v][q] = __builtin_fmaf(x, w, acc[v][q]);
                     }
                 }
             }
         }
 #pragma unroll
-        for (int i = 0; i < RB; i++) { e_cur[i] = e_nxt[i]; t_cur[i] = t_nxt[i]; }
+        for (int i = 0; i < RB; i++) { if (NOISE) e_cur[i] = e_nxt[i]; t_cur[i] = t_nxt[i]; }
         if (bt % BPC == BPC - 1) {   // chunk boundary: rotate the activation registers, prefetch the chunk after next
 #pragma unroll
             for (int v = 0; v < NV; v++) xv[v] = xn[v];
@@ -1516,19 +1518,19 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
 // 44 k-values, weights are formed per lane as theta + sigma*eps straight into the B operand.  The MFMA's
 // k-ordered fmaf chain per slice + the ((s0+s1)+(s2+s3)) + bias combine (k_bn3_partials) are the oracle's order.
 template <int MT>
-__global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int member0, const float *__restrict__ y2,
-                                                float *__restrict__ y3p /*[n_local][4][F][256]*/) {
-    // One workgroup of 4 waves per (member, quarter[, column half]); a wave owns a block of 16 CW columns as CW interleaved
-    // 16-column MFMA tiles (tile j = columns col0 + j), so a lane's CW B operands of a k-row are one load.  8-row stages through a
-    // double-buffered LDS tile.
-    // Up to 64 frames: CW = 4, the workgroup covers all 256 columns, the member's activations and weights each cross the memory
-    // system once.  With 128 frames a wave would hold 32 accumulator tiles AND as many for the running fold over the sub-slices
-    // (oracle fc_raw) -- more than half the register file, i.e. one wave per SIMD; instead CW = 2 and two workgroups per quarter
-    // (columns 0-127 / 128-255: the activations are staged twice, no weight is loaded twice), 16 + 16 tiles per wave, and two
-    // independent workgroups per CU as before.  (8 waves x 32 columns in ONE workgroup were measured 58 % slower: all eight then
-    // stall at the same barrier.)
+__global__ __launch_bounds__(MT == 8 ? 512 : 256) void k_fc_ref(FwdArgs A, int n_local, int member0, const float *__restrict__ y2,
+                                                                float *__restrict__ y3p /*[n_local][4][F][256]*/) {
+    // One workgroup per (member, quarter); a wave owns a block of 16 CW columns as CW interleaved 16-column MFMA tiles (tile j =
+    // columns CW * (16 w + lane) + j), so a lane's CW B operands of a k-row are one load, and the member's activations and weights
+    // each cross the memory system once.  8-row stages through a double-buffered LDS tile.
+    // Up to 64 frames: 4 waves x 64 columns.  With 128 frames a wave of that shape would hold 32 accumulator tiles AND as many for
+    // the running fold over the sub-slices (oracle fc_raw) -- more than half the register file; 8 waves x 32 columns (16 + 16 tiles
+    // each) keep two waves per SIMD, and no weight is loaded twice.
+    // The stages of one sub-slice are the inner loop and the fold sits between two runs of it: with the fold as a conditional INSIDE
+    // the stage loop the compiler copied every accumulator around it on every stage (128 register moves per 32 MFMAs: 2.7 - 3.0 ms per
+    // chunk of 512 members instead of 1.7, rocprofv3 kernel stats of round 3).
     constexpr int F = MT * 16, KC = 8, XS = KC + 2, NST = 968 / KC, KK = KC / 4;   // XS = 10: lanes (frame, k) of a half-wave hit 32 distinct banks
-    constexpr int NH = MT == 8 ? 2 : 1, NT = 256, CW = 4 / NH;                     // column halves, threads, column tiles per wave (2 or 4)
+    constexpr int NW = MT == 8 ? 8 : 4, NT = 64 * NW, CW = 256 / (16 * NW);        // waves, threads, column tiles per wave (2 or 4)
     constexpr int LD = (F * KC + NT - 1) / NT;
     typedef float fcw_u __attribute__((ext_vector_type(CW), aligned(4)));          // CW consecutive floats at 4-byte alignment
     typedef float fcw_a __attribute__((ext_vector_type(CW)));
@@ -1536,12 +1538,12 @@ __global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int memb
     __shared__ float bn2[64];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
     const Layout &L = A.L;
-    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;          // the workgroups of a member stay on one XCD (block b -> XCD b % 8)
-    const int mloc = (q / (4 * NH)) * 8 + x, sl = q & 3, half = (q / 4) % NH;
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;          // the four quarters of a member stay on one XCD (block b -> XCD b % 8)
+    const int mloc = (q >> 2) * 8 + x, sl = q & 3;
     if (mloc >= n_local) return;
     const int member = member0 + mloc;
     const float sc = A.m_scale[member];
-    const int kbeg = 968 * sl, col0 = 128 * half * (NH - 1) + CW * (16 * wv + lp);
+    const int kbeg = 968 * sl, col0 = CW * (16 * wv + lp);
     const float *eps = A.noise + A.m_off[member] + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
     const float *th = A.bases + (size_t)A.m_slot[member] * A.base_stride + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
     const float *ysrc = y2 + (size_t)mloc * F * 3872 + kbeg;
@@ -1591,35 +1593,37 @@ __global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int memb
     store_stage(0, 0);
     form_w();
     __syncthreads();
-    int next_sub = FC_SUB0 / KC;
-    for (int st = 0; st < NST; st++) {
-        const int buf = st & 1;
-        if (st + 1 < NST) load_stage(st + 1);
+    int st = 0;
+#pragma unroll 1
+    for (int sub = 0; sub < 8; sub++) {
+        const int end_st = (FC_SUB0 + sub * FC_SUBN) / KC;      // stages 16, 31, 46, ..., 121: the ends of the sub-slices
+#pragma unroll 1
+        for (; st < end_st; st++) {
+            const int buf = st & 1;
+            if (st + 1 < NST) load_stage(st + 1);
 #pragma unroll
-        for (int kk = 0; kk < KK; kk++) {
+            for (int kk = 0; kk < KK; kk++) {
 #pragma unroll
-            for (int m = 0; m < MT; m++) {
-                const float a = xs[buf][(m * 16 + lp) * XS + 4 * kk + lk];
+                for (int m = 0; m < MT; m++) {
+                    const float a = xs[buf][(m * 16 + lp) * XS + 4 * kk + lk];
 #pragma unroll
-                for (int c = 0; c < CW; c++) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[kk][c], acc[m][c], 0, 0, 0);
-            }
-        }
-        if (st + 1 == next_sub) {   // end of a sub-slice: the chains join the quarter's running fold and start again from 0
-            const bool first = next_sub == FC_SUB0 / KC;
-#pragma unroll
-            for (int m = 0; m < MT; m++)
-#pragma unroll
-                for (int c = 0; c < CW; c++) {
-                    fold[m][c] = first ? acc[m][c] : fold[m][c] + acc[m][c];
-                    acc[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int c = 0; c < CW; c++) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[kk][c], acc[m][c], 0, 0, 0);
                 }
-            next_sub += FC_SUBN / KC;
+            }
+            if (st + 1 < NST) {
+                store_stage(st + 1, buf ^ 1);
+                form_w();
+            }
+            __syncthreads();
         }
-        if (st + 1 < NST) {
-            store_stage(st + 1, buf ^ 1);
-            form_w();
-        }
-        __syncthreads();
+        // end of a sub-slice: the chains join the quarter's running fold and start again from 0
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int c = 0; c < CW; c++) {
+                fold[m][c] = sub == 0 ? acc[m][c] : fold[m][c] + acc[m][c];
+                acc[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
     }
     float *out = y3p + ((size_t)(mloc * 4 + sl) * F) * 256 + col0;
 #pragma unroll

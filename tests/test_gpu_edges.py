@@ -317,6 +317,10 @@ def test_reference_batch_sizes(nref, members, oracle, small_noise):
     {"DNE_FC_DUO_GA": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0"},   # ... two units per wave
     {"DNE_SPEC_MAX": "0"},                                                                            # GA tail without speculation
     {"DNE_SPEC_MAX": "64"},                                                                           # ... speculative from the first lock-step
+    {"DNE_GA_MATERIALIZE": "0"},                                                                      # children NOT written out: parent row + noise row on the fly
+    {"DNE_GA_MATERIALIZE": "0", "DNE_FC_TAIL_MAX": "1"},                                              # ... through the streaming fc at every count
+    {"DNE_FC_TAIL_MAX": "1"},                                                                         # children written out (default), noise-free streaming fc at every count
+    {"DNE_FC_TAIL_MAX": "1", "DNE_FC_RB": "8"},                                                       # ... with 8-row batches
 ])
 def test_ga_step_kernel_variants_are_bit_exact(knobs, oracle, small_noise, monkeypatch):
     """the GA evaluation (single members, one base vector per parent, final-RAM behaviour characterisation) through the kernel
