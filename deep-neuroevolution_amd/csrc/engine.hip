@@ -539,7 +539,7 @@ struct dne_handle {
     int conv1_fpw = 8;               // reference pass: frames per conv1 workgroup (DNE_CONV1_FPW: 1, 2, 4, 8)
     int conv_fused = 1, conv_fused_min = 129;   // DNE_CONV_FUSED / DNE_CONV_FUSED_MIN: conv1 + conv2 in one kernel from this many members
     int conv_split_max = 32;         // members up to which the convolutions use their finest split (DNE_CONV_SPLIT_MAX)
-    int conv_split_mid = 64;         // ... their middle split: conv1 over 4 workgroups up to this many members, conv2 over 2 up to twice as many (DNE_CONV_SPLIT_MID)
+    int conv_split_mid = 256;        // ... their middle split: conv1 over 4 workgroups up to this many members, conv2 over 2 up to twice as many (DNE_CONV_SPLIT_MID)
     int fc_pairs = 2;                // ES full-width fc: antithetic pairs per work item (DNE_FC_PAIRS, 1 = k_fc<2>)
     int fc2_min_total = 800;         // k_fc2 from this many active groups upwards (DNE_FC2_MIN)
     bool fc2_now = false;            // decided per burst by eval_core
@@ -1367,9 +1367,9 @@ static int ref_pass(dne_handle *h, int n) {
         hipLaunchKernelGGL((k_bn_finalize<32>), dim3((nc * 32 + 255) / 256), dim3(256), 0, st, A, m0, nc, F, (const float *)fr2, 121, 32,
                            h->L.c2b, h->L.bn2b, h->L.bn2g);
         if (F == 16 || F == 32 || F == 64 || F == 128) {   // matrix-core path
-            const int grid = (nc + 7) / 8 * 8 * 4;   // (member, quarter) workgroups, the four of a member on one XCD
-#define FCREF(MT) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid), dim3(MT == 8 ? 512 : 256), 0, st, A, nc, m0, (const float *)y2, y3p)
-            if (F == 16) FCREF(1); else if (F == 32) FCREF(2); else if (F == 64) FCREF(4); else FCREF(8);
+            const int grid = (nc + 7) / 8 * 8 * 4;   // (member, quarter) workgroups, those of a member on one XCD
+#define FCREF(MT, NG) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid * NG), dim3(256), 0, st, A, nc, m0, F, (const float *)y2, y3p)
+            if (F == 16) FCREF(1, 1); else if (F == 32) FCREF(2, 1); else if (F == 64) FCREF(4, 1); else FCREF(4, 2);   // 128 frames: two groups of 64
 #undef FCREF
             hipLaunchKernelGGL(k_bn3_partials, dim3(nc), dim3(256), 0, st, A, m0, F, (const float *)y3p);
         } else {
@@ -1475,7 +1475,10 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
     if (count <= h->fc_tail_max) {   // latency-bound regime: 4 workgroups per group + a separate output-layer kernel
 #define FCT(NV, BN)                                                                                                          \
     do {                                                                                                                     \
-        if (count <= h->fc_quad_max) hipLaunchKernelGGL((k_fc_quad<NV, BN>), dim3(count * 64), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
+        if (NV == 1 && !BN && h->members_materialized) {   /* GA children written out: plain rows, no noise stream */        \
+            if (count <= h->fc_quad_max) hipLaunchKernelGGL((k_fc_quad<1, false, false>), dim3(count * 64), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
+            else hipLaunchKernelGGL((k_fc_tail<1, false, false>), dim3(count * 16), dim3(512), 0, st, A, list, (const float *)h->y2, h->y3t); \
+        } else if (count <= h->fc_quad_max) hipLaunchKernelGGL((k_fc_quad<NV, BN>), dim3(count * 64), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
         else hipLaunchKernelGGL((k_fc_tail<NV, BN>), dim3(count * 16), dim3(512), 0, st, A, list, (const float *)h->y2, h->y3t); \
         if (!out_fused) hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->y3, h->action, logits); \
     } while (0)

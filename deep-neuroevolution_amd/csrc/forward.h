@@ -1518,57 +1518,54 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
 // 44 k-values, weights are formed per lane as theta + sigma*eps straight into the B operand.  The MFMA's
 // k-ordered fmaf chain per slice + the ((s0+s1)+(s2+s3)) + bias combine (k_bn3_partials) are the oracle's order.
 template <int MT>
-__global__ __launch_bounds__(MT == 8 ? 512 : 256) void k_fc_ref(FwdArgs A, int n_local, int member0, const float *__restrict__ y2,
-                                                                float *__restrict__ y3p /*[n_local][4][F][256]*/) {
-    // One workgroup per (member, quarter); a wave owns a block of 16 CW columns as CW interleaved 16-column MFMA tiles (tile j =
-    // columns CW * (16 w + lane) + j), so a lane's CW B operands of a k-row are one load, and the member's activations and weights
-    // each cross the memory system once.  8-row stages through a double-buffered LDS tile.
-    // Up to 64 frames: 4 waves x 64 columns.  With 128 frames a wave of that shape would hold 32 accumulator tiles AND as many for
-    // the running fold over the sub-slices (oracle fc_raw) -- more than half the register file; 8 waves x 32 columns (16 + 16 tiles
-    // each) keep two waves per SIMD, and no weight is loaded twice.
-    // The stages of one sub-slice are the inner loop and the fold sits between two runs of it: with the fold as a conditional INSIDE
-    // the stage loop the compiler copied every accumulator around it on every stage (128 register moves per 32 MFMAs: 2.7 - 3.0 ms per
-    // chunk of 512 members instead of 1.7, rocprofv3 kernel stats of round 3).
-    constexpr int F = MT * 16, KC = 8, XS = KC + 2, NST = 968 / KC, KK = KC / 4;   // XS = 10: lanes (frame, k) of a half-wave hit 32 distinct banks
-    constexpr int NW = MT == 8 ? 8 : 4, NT = 64 * NW, CW = 256 / (16 * NW);        // waves, threads, column tiles per wave (2 or 4)
-    constexpr int LD = (F * KC + NT - 1) / NT;
-    typedef float fcw_u __attribute__((ext_vector_type(CW), aligned(4)));          // CW consecutive floats at 4-byte alignment
-    typedef float fcw_a __attribute__((ext_vector_type(CW)));
-    __shared__ float xs[2][F * XS];
+__global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int member0, int F /* reference frames per member: MT * 16 * frame groups */,
+                                                const float *__restrict__ y2, float *__restrict__ y3p /*[n_local][4][F][256]*/) {
+    // One workgroup of 4 waves per (member, quarter, group of MT * 16 frames); wave w owns columns 64w .. 64w+63 as four interleaved
+    // 16-column MFMA tiles (tile c = columns 64w + 4*lane + c), so a lane's four B operands of a k-row are one 16-byte load.  8-row
+    // stages through a double-buffered LDS tile.
+    // MT <= 4: a wave's 16 MT accumulator registers and as many for the running fold over the sub-slices (oracle fc_raw) leave two
+    // waves per SIMD.  128 reference frames therefore run as TWO frame groups of 64 (MT = 4) per (member, quarter): the pair streams
+    // the same weight rows side by side on one XCD (the second reader finds them in L2), the activations are staged once.
+    // (Round 3 measured the alternatives at 128 frames in one workgroup: 8 waves x 32 columns 2.7 ms per chunk of 512 members,
+    // two 4-wave workgroups per quarter split by columns 3.0 ms, against 1.7 ms for the round-2 kernel without the fold.)
+    constexpr int FG = MT * 16, KC = 8, XS = KC + 2, NST = 968 / KC, KK = KC / 4;   // XS = 10: lanes (frame, k) of a half-wave hit 32 distinct banks
+    constexpr int LD = (FG * KC + 255) / 256;
+    __shared__ float xs[2][FG * XS];
     __shared__ float bn2[64];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
     const Layout &L = A.L;
-    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;          // the four quarters of a member stay on one XCD (block b -> XCD b % 8)
-    const int mloc = (q >> 2) * 8 + x, sl = q & 3;
+    const int ngrp = F / FG;                                    // frame groups per member (1, or 2 at 128 frames)
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;          // the workgroups of a member stay on one XCD (block b -> XCD b % 8)
+    const int sl = q & 3, fg = (q >> 2) % ngrp, mloc = (q / (4 * ngrp)) * 8 + x;
     if (mloc >= n_local) return;
     const int member = member0 + mloc;
     const float sc = A.m_scale[member];
-    const int kbeg = 968 * sl, col0 = CW * (16 * wv + lp);
+    const int kbeg = 968 * sl, col0 = 64 * wv + 4 * lp;
     const float *eps = A.noise + A.m_off[member] + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
     const float *th = A.bases + (size_t)A.m_slot[member] * A.base_stride + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
-    const float *ysrc = y2 + (size_t)mloc * F * 3872 + kbeg;
+    const float *ysrc = y2 + ((size_t)mloc * F + (size_t)fg * FG) * 3872 + kbeg;
     if (tid < 64) bn2[tid] = A.bn[(size_t)member * 608 + 32 + tid];   // scale[32] then shift[32]
     float yr[LD];
-    fcw_u er[KK];
-    fcw_a tr[KK];
+    f4u er[KK];
+    f4a tr[KK];
     auto load_stage = [&](int st) {
 #pragma unroll
         for (int j = 0; j < LD; j++) {
-            const int e = tid + NT * j;
-            yr[j] = e < F * KC ? ysrc[(size_t)(e / KC) * 3872 + st * KC + e % KC] : 0.0f;
+            const int e = tid + 256 * j;
+            yr[j] = e < FG * KC ? ysrc[(size_t)(e / KC) * 3872 + st * KC + e % KC] : 0.0f;
         }
 #pragma unroll
         for (int kk = 0; kk < KK; kk++) {
             const size_t ro = (size_t)(st * KC + 4 * kk) * 256;
-            er[kk] = *(const fcw_u *)(eps + ro);
-            tr[kk] = *(const fcw_a *)(th + ro);
+            er[kk] = *(const f4u *)(eps + ro);
+            tr[kk] = *(const f4a *)(th + ro);
         }
     };
     auto store_stage = [&](int st, int buf) {
 #pragma unroll
         for (int j = 0; j < LD; j++) {
-            const int e = tid + NT * j;
-            if (e < F * KC) {
+            const int e = tid + 256 * j;
+            if (e < FG * KC) {
                 const int ch = (kbeg + st * KC + e % KC) & 31;
                 float t = yr[j] * bn2[ch];
                 t = t + bn2[32 + ch];
@@ -1576,17 +1573,17 @@ __global__ __launch_bounds__(MT == 8 ? 512 : 256) void k_fc_ref(FwdArgs A, int n
             }
         }
     };
-    f32x4 acc[MT][CW], fold[MT][CW];
+    f32x4 acc[MT][4], fold[MT][4];
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
-        for (int c = 0; c < CW; c++) acc[m][c] = fold[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float w[KK][CW];
+        for (int c = 0; c < 4; c++) acc[m][c] = fold[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float w[KK][4];
     auto form_w = [&]() {
 #pragma unroll
         for (int kk = 0; kk < KK; kk++)
 #pragma unroll
-            for (int c = 0; c < CW; c++) { float pv = sc * er[kk][c]; w[kk][c] = tr[kk][c] + pv; }
+            for (int c = 0; c < 4; c++) { float pv = sc * er[kk][c]; w[kk][c] = tr[kk][c] + pv; }
     };
     load_stage(0);
     __syncthreads();          // bn2 visible
@@ -1595,8 +1592,8 @@ __global__ __launch_bounds__(MT == 8 ? 512 : 256) void k_fc_ref(FwdArgs A, int n
     __syncthreads();
     int st = 0;
 #pragma unroll 1
-    for (int sub = 0; sub < 8; sub++) {
-        const int end_st = (FC_SUB0 + sub * FC_SUBN) / KC;      // stages 16, 31, 46, ..., 121: the ends of the sub-slices
+    for (int sub = 0; sub < 8; sub++) {   // the stages of one sub-slice are the inner loop; the fold sits between two runs of it
+        const int end_st = (FC_SUB0 + sub * FC_SUBN) / KC;      // stages 16, 31, 46, ..., 121
 #pragma unroll 1
         for (; st < end_st; st++) {
             const int buf = st & 1;
@@ -1607,7 +1604,7 @@ __global__ __launch_bounds__(MT == 8 ? 512 : 256) void k_fc_ref(FwdArgs A, int n
                 for (int m = 0; m < MT; m++) {
                     const float a = xs[buf][(m * 16 + lp) * XS + 4 * kk + lk];
 #pragma unroll
-                    for (int c = 0; c < CW; c++) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[kk][c], acc[m][c], 0, 0, 0);
+                    for (int c = 0; c < 4; c++) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[kk][c], acc[m][c], 0, 0, 0);
                 }
             }
             if (st + 1 < NST) {
@@ -1620,21 +1617,17 @@ __global__ __launch_bounds__(MT == 8 ? 512 : 256) void k_fc_ref(FwdArgs A, int n
 #pragma unroll
         for (int m = 0; m < MT; m++)
 #pragma unroll
-            for (int c = 0; c < CW; c++) {
+            for (int c = 0; c < 4; c++) {
                 fold[m][c] = sub == 0 ? acc[m][c] : fold[m][c] + acc[m][c];
                 acc[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
     }
-    float *out = y3p + ((size_t)(mloc * 4 + sl) * F) * 256 + col0;
+    float *out = y3p + (((size_t)(mloc * 4 + sl) * F) + (size_t)fg * FG) * 256 + col0;
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {   // D[row = 4*(l>>4) + r][col = l&15] of tile c -> frame m*16 + 4*lk + r, column col0 + c
-            fcw_a o;
-#pragma unroll
-            for (int c = 0; c < CW; c++) o[c] = fold[m][c][r];
-            *(fcw_a *)(out + (size_t)(m * 16 + lk * 4 + r) * 256) = o;
-        }
+        for (int r = 0; r < 4; r++)   // D[row = 4*(l>>4) + r][col = l&15] of tile c -> frame m*16 + 4*lk + r, column col0 + c
+            *(f32x4 *)(out + (size_t)(m * 16 + lk * 4 + r) * 256) = f32x4{fold[m][0][r], fold[m][1][r], fold[m][2][r], fold[m][3][r]};
 }
 
 // bn3 statistics from the four k-slice partials: y3 = ((p0+p1)+(p2+p3)) + bias per frame, then the batch
@@ -1700,7 +1693,7 @@ struct QuadLds {
     float comb[8][NV][16];
 };
 
-template <int NV, bool HAS_BN, bool TT>
+template <int NV, bool HAS_BN, bool TT, bool NOISE = true>
 __device__ __forceinline__ void fc_quad_body(QuadLds<NV> &S, const FwdArgs &A, const int *__restrict__ list, int item /* position of the group in the window */,
                                              int cg, int sl, const float *__restrict__ y2,
                                              float *__restrict__ y3t /*[member][4 quarters][256]*/) {
@@ -1749,7 +1742,7 @@ __device__ __forceinline__ void fc_quad_body(QuadLds<NV> &S, const FwdArgs &A, c
 #pragma unroll
     for (int i = 0; i < GW; i++) {
         const int ii = i < ng ? i : ng - 1;                  // wave-uniform clamp: loads 61 and 62 of a 60-group wave are repeats
-        e[i] = eps[(size_t)(4 * ii) * 256];
+        e[i] = NOISE ? eps[(size_t)(4 * ii) * 256] : 0.0f;
         t[i] = th[(size_t)(4 * ii) * 256];
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1772,8 +1765,8 @@ __device__ __forceinline__ void fc_quad_body(QuadLds<NV> &S, const FwdArgs &A, c
 #pragma unroll
     for (int i = 0; i < GW; i++) {
         const float ee = e[i], tt = t[i];
-        float pv = scale[0] * ee;
-        e[i] = tt + pv;
+        float pv = NOISE ? scale[0] * ee : 0.0f;
+        e[i] = NOISE ? tt + pv : tt;
         if (NV == 2) {
             float pw = scale[NV - 1] * ee;
             t[i] = tt + pw;
@@ -1841,13 +1834,13 @@ __device__ __forceinline__ void fc_quad_body(QuadLds<NV> &S, const FwdArgs &A, c
     }
 }
 
-template <int NV, bool HAS_BN>
+template <int NV, bool HAS_BN, bool NOISE = true>
 __global__ __launch_bounds__(256) void k_fc_quad(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
                                                  float *__restrict__ y3t /*[member][4 quarters][256]*/) {
     __shared__ QuadLds<NV> S;
     const int item = blockIdx.x >> 6, cg = (blockIdx.x >> 2) & 15, sl = blockIdx.x & 3;
-    if (A.tt.n > 0) fc_quad_body<NV, HAS_BN, true>(S, A, list, item, cg, sl, y2, y3t);
-    else fc_quad_body<NV, HAS_BN, false>(S, A, list, item, cg, sl, y2, y3t);
+    if (A.tt.n > 0) fc_quad_body<NV, HAS_BN, true, NOISE>(S, A, list, item, cg, sl, y2, y3t);
+    else fc_quad_body<NV, HAS_BN, false, NOISE>(S, A, list, item, cg, sl, y2, y3t);
 }
 
 // ------------------------------------------------------------ fc for the tail of a generation (at most ~100 active groups), round 3
@@ -1864,7 +1857,7 @@ struct TailFcLds {
     float comb[8][NV][64];
 };
 
-template <int NV, bool HAS_BN, bool TT>
+template <int NV, bool HAS_BN, bool TT, bool NOISE>
 __device__ __forceinline__ void fc_tail_body(TailFcLds<NV> &S, const FwdArgs &A, const int *__restrict__ list, int item, int sl, int cb,
                                              const float *__restrict__ y2, float *__restrict__ y3t /*[member][4 quarters][256]*/) {
     constexpr int D = 8;                                     // row groups in flight per wave (16: 203 VGPRs instead of 123, one workgroup per CU instead of two -- measured slower at every count)
@@ -1904,11 +1897,11 @@ __device__ __forceinline__ void fc_tail_body(TailFcLds<NV> &S, const FwdArgs &A,
             h2[v][j] = HAS_BN && in ? A.bn[(size_t)member[v] * 608 + 64 + ch] : 0.0f;
         }
     __builtin_amdgcn_sched_barrier(0);
-    f4u e[D];
+    f4u e[D];                                                // NOISE = false (GA children written out: plain rows): never loaded
     f4a t[D];
 #pragma unroll
     for (int i = 0; i < D; i++) {
-        e[i] = *(const f4u *)(ep + (size_t)i * 1024);
+        if (NOISE) e[i] = *(const f4u *)(ep + (size_t)i * 1024);
         t[i] = *(const f4a *)(tp + (size_t)i * 1024);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1943,12 +1936,12 @@ __device__ __forceinline__ void fc_tail_body(TailFcLds<NV> &S, const FwdArgs &A,
                 x4[v] = *(const f4a *)&S.xs[v][beg + 4 * g];        // rows 4g .. 4g+3 of the sub-slice (broadcast read)
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    float pv = scale[v] * e[slot][q];
-                    w[v][q] = t[slot][q] + pv;
+                    float pv = NOISE ? scale[v] * e[slot][q] : 0.0f;
+                    w[v][q] = NOISE ? t[slot][q] + pv : t[slot][q];
                 }
             }
-            if (g + D < ng) {                                       // this slot's registers take the group sixteen ahead
-                e[slot] = *(const f4u *)(ep + (size_t)(g + D) * 1024);
+            if (g + D < ng) {                                       // this slot's registers take the group D ahead
+                if (NOISE) e[slot] = *(const f4u *)(ep + (size_t)(g + D) * 1024);
                 t[slot] = *(const f4a *)(tp + (size_t)(g + D) * 1024);
             }
             // row 4g + j's weights sit in lane j of the quad and enter the fused multiply-add as a DPP operand (v_fmac_f32 = the same
@@ -2029,13 +2022,13 @@ __device__ __forceinline__ void fc_tail_body(TailFcLds<NV> &S, const FwdArgs &A,
     }
 }
 
-template <int NV, bool HAS_BN>
+template <int NV, bool HAS_BN, bool NOISE = true>
 __global__ __launch_bounds__(512) void k_fc_tail(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
                                                  float *__restrict__ y3t /*[member][4 quarters][256]*/) {
     __shared__ TailFcLds<NV> S;
     const int item = blockIdx.x >> 4, sl = (blockIdx.x >> 2) & 3, cb = blockIdx.x & 3;
-    if (A.tt.n > 0) fc_tail_body<NV, HAS_BN, true>(S, A, list, item, sl, cb, y2, y3t);
-    else fc_tail_body<NV, HAS_BN, false>(S, A, list, item, sl, cb, y2, y3t);
+    if (A.tt.n > 0) fc_tail_body<NV, HAS_BN, true, NOISE>(S, A, list, item, sl, cb, y2, y3t);
+    else fc_tail_body<NV, HAS_BN, false, NOISE>(S, A, list, item, sl, cb, y2, y3t);
 }
 
 // fc slice combine + bias, bn3 + relu, output layer (out_products / out_wave_sums: thread = input k) + first-max argmax from the
