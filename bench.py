@@ -414,7 +414,10 @@ def run_rank(args):
     config = es.Config(**EXP["config"])
     my_pairs = len(es.shard_pairs(n_pairs, rank, world))
     try:
-        ndev = _lib.device_count()
+        try:
+            ndev = _lib.device_count()
+        except AttributeError:      # DNE_LIB_PATH points at a build that predates dne_device_count
+            ndev = local_rank + 1
         if local_rank >= max(ndev, 1):
             raise _lib.DneError("rank %d wants device %d, this box shows %d" % (rank, local_rank, ndev))
         engine = _lib.Engine(_lib.KIND_ES, 18, max_members=2 * my_pairs, ref_count=128, device_id=local_rank,

@@ -554,7 +554,7 @@ struct dne_handle {
     int fc_duo = 1, fc_duo_min = 800;   // DNE_FC_DUO / DNE_FC_DUO_MIN: table-ordered fc (k_unit_order + k_fc_duo + k_out) from this many active groups
     bool duo_now = false;            // decided per burst by eval_core (the unit order of each window is rebuilt then)
     int *unit_order = nullptr;       // [4 * groups]: per window, its (group, k-slice) units in noise-table order
-    int spec_max = 8;                // DNE_SPEC_MAX: a single window of up to this many members (4 antithetic pairs) steps speculatively -- every action's outcome is worked out under the forward pass; 0 = off
+    int spec_max = 4;                // DNE_SPEC_MAX: a single window of up to this many members (2 antithetic pairs; round 2: 8 -- the faster tail kernels of round 3 beat speculation at 4 pairs, 47 vs 56 us) steps speculatively -- every action's outcome is worked out under the forward pass; 0 = off
     uint8_t *spec_prev = nullptr, *spec_cur = nullptr, *spec_stacks = nullptr;
     int32_t *spec_rw = nullptr;
     float *spec_y1 = nullptr;
@@ -564,6 +564,7 @@ struct dne_handle {
     int render_bands = 4, band_threads = 512;   // tail: workgroups per frame (DNE_RENDER_BANDS, 1 = render inside k_tail_step) and their size
     int tail_fused_max = 200;        // up to this many active groups (all windows) k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
     int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_rb = 4, fc_chain_min = 1 << 30;
+    int fc_tailk_max = 32;           // DNE_FC_TAILK_MAX: up to this many groups per window k_fc_tail (16 workgroups per group), above it k_fc_cols (4 lean ones)
     int fc_quad_max = 4;             // DNE_FC_QUAD_MAX: up to this many groups per window the 64-workgroups-per-group fc (k_fc_quad); above it k_fc_tail
     int M = 0, F = 0, ref_chunk = 0;
     size_t base_stride = 0;
@@ -912,6 +913,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
     env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
     env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
+    env_int("DNE_FC_TAILK_MAX", 0, 1 << 20, &h->fc_tailk_max);
     env_int("DNE_DEBUG_SKIP", 0, 7, &h->dbg_skip);
     env_int("DNE_DEBUG_IMMORTAL", 0, 1, &h->dbg_immortal);
     env_int("DNE_TAIL_TABLE", 0, 1, &h->tt_enable);
@@ -1479,7 +1481,8 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
             if (count <= h->fc_quad_max) hipLaunchKernelGGL((k_fc_quad<1, false, false>), dim3(count * 64), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
             else hipLaunchKernelGGL((k_fc_tail<1, false, false>), dim3(count * 16), dim3(512), 0, st, A, list, (const float *)h->y2, h->y3t); \
         } else if (count <= h->fc_quad_max) hipLaunchKernelGGL((k_fc_quad<NV, BN>), dim3(count * 64), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
-        else hipLaunchKernelGGL((k_fc_tail<NV, BN>), dim3(count * 16), dim3(512), 0, st, A, list, (const float *)h->y2, h->y3t); \
+        else if (count <= h->fc_tailk_max) hipLaunchKernelGGL((k_fc_tail<NV, BN>), dim3(count * 16), dim3(512), 0, st, A, list, (const float *)h->y2, h->y3t); \
+        else hipLaunchKernelGGL((k_fc_cols<NV, BN>), dim3(count * 4), dim3(256), 0, st, A, list, (const float *)h->y2, h->y3t); \
         if (!out_fused) hipLaunchKernelGGL((k_out<NV, BN>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->y3, h->action, logits); \
     } while (0)
         if (gsize == 2) { if (es) FCT(2, true); else FCT(2, false); }

@@ -2031,6 +2031,111 @@ __global__ __launch_bounds__(512) void k_fc_tail(FwdArgs A, const int *__restric
     else fc_tail_body<NV, HAS_BN, false, NOISE>(S, A, list, item, sl, cb, y2, y3t);
 }
 
+// Upper part of the tail (more than ~32 groups per window, several windows at once): 4 workgroups per group (one per 64-column
+// block), wave = quarter, lane = ONE output column with 2 x 40 rows in flight -- few, lean workgroups: where k_fc_tail's 16
+// workgroups of 512 threads per group no longer fit the chip at once this form is faster (round 3 same-box: 312 pairs in 4 windows).
+// The wave walks its quarter row by row, so the sub-slices (oracle fc_raw) are a running fold: 8 rows, then 24 batches of 40 --
+// the boundaries 128, 248, ..., 968 fall after every third batch.
+template <int NV, bool HAS_BN>
+__global__ __launch_bounds__(256) void k_fc_cols(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y2,
+                                                 float *__restrict__ y3t /*[member][4 quarters][256]*/) {
+    __shared__ float xs[4][NV][968];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const Layout &L = A.L;
+    const int item = blockIdx.x >> 2, cq = blockIdx.x & 3;
+    const int g = list ? list[item] : item;
+    int member[NV];
+    float scale[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) { member[v] = g * NV + v; scale[v] = A.m_scale[member[v]]; }
+    if (A.done) {   // finished group still in the list: nothing to compute
+        bool all_done = true;
+#pragma unroll
+        for (int v = 0; v < NV; v++) all_done = all_done && A.done[member[v]] != 0;
+        if (all_done) return;
+    }
+    const int64_t off = A.m_off[member[0]];
+    const float *base = A.bases + (size_t)A.m_slot[member[0]] * A.base_stride;
+    const int col = cq * 64 + lane;
+    const int kbeg = 968 * wv;
+    const float *eps = A.noise + off + L.fcw + (size_t)kbeg * 256 + col;
+    const float *th = base + L.fcw + (size_t)kbeg * 256 + col;
+    constexpr int RB = 40, R0 = FC_SUB0 - 3 * RB;   // 8 leading rows, then 24 batches of 40
+    static_assert(R0 == 8 && FC_SUBN == 3 * RB && R0 + 24 * RB == 968, "batches must end on the sub-slice boundaries");
+    float e0[R0], t0[R0], e_cur[RB], t_cur[RB], e_nxt[RB], t_nxt[RB];
+#pragma unroll
+    for (int i = 0; i < R0; i++) { e0[i] = eps[(size_t)i * 256]; t0[i] = th[(size_t)i * 256]; }
+#pragma unroll
+    for (int i = 0; i < RB; i++) { e_cur[i] = eps[(size_t)(R0 + i) * 256]; t_cur[i] = th[(size_t)(R0 + i) * 256]; }
+    {
+        float yv[NV][16], s2[NV], h2[NV];
+        const int ch = (kbeg + lane) & 31;
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            s2[v] = HAS_BN ? A.bn[(size_t)member[v] * 608 + 32 + ch] : 1.0f;
+            h2[v] = HAS_BN ? A.bn[(size_t)member[v] * 608 + 64 + ch] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int i = lane + 64 * j;
+                yv[v][j] = i < 968 ? y2[(size_t)member[v] * 3872 + kbeg + i] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++)
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int i = lane + 64 * j;
+                if (i < 968) {
+                    float t = yv[v][j];
+                    if (HAS_BN) {
+                        t = t * s2[v];
+                        t = t + h2[v];
+                    }
+                    xs[wv][v][i] = t > 0.0f ? t : 0.0f;
+                }
+            }
+    }
+    __syncthreads();
+    float acc[NV], fold[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) acc[v] = fold[v] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < R0; i++) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            float pv = scale[v] * e0[i];
+            const float w = t0[i] + pv;
+            acc[v] = __builtin_fmaf(xs[wv][v][i], w, acc[v]);
+        }
+    }
+    for (int bt = 0; bt < 24; bt++) {
+        if (bt + 1 < 24) {
+#pragma unroll
+            for (int i = 0; i < RB; i++) {
+                e_nxt[i] = eps[(size_t)(R0 + (bt + 1) * RB + i) * 256];
+                t_nxt[i] = th[(size_t)(R0 + (bt + 1) * RB + i) * 256];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; i++) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                float pv = scale[v] * e_cur[i];
+                const float w = t_cur[i] + pv;
+                acc[v] = __builtin_fmaf(xs[wv][v][R0 + bt * RB + i], w, acc[v]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; i++) { e_cur[i] = e_nxt[i]; t_cur[i] = t_nxt[i]; }
+        if (bt % 3 == 2) {   // rows 128, 248, ..., 968 done: the end of a sub-slice
+#pragma unroll
+            for (int v = 0; v < NV; v++) { fold[v] = bt == 2 ? acc[v] : fold[v] + acc[v]; acc[v] = 0.0f; }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; v++) y3t[((size_t)member[v] * 4 + wv) * 256 + col] = fold[v];
+}
+
 // fc slice combine + bias, bn3 + relu, output layer (out_products / out_wave_sums: thread = input k) + first-max argmax from the
 // fc partial sums, one workgroup per group.  The members of a group share base vector and noise slice (antithetic pair).
 template <int NV, bool HAS_BN>

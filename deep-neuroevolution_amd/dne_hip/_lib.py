@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libdne_hip.so")
+LIB_PATH = os.environ.get("DNE_LIB_PATH") or os.path.join(_CSRC, "libdne_hip.so")   # DNE_LIB_PATH: another build of the same ABI (same-box A/B of whole builds)
 
 KIND_ES, KIND_GA, KIND_GA_LARGE = 0, 1, 2   # DNE_KIND_* (include/dne_hip.h); 2 = the GPU tree's LargeModel (models/dqn.py:39-47)
 PROC_MODES = {"centered_rank": 0, "sign": 1, "centered_sign_rank": 2}

@@ -162,6 +162,8 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
     {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0"},                      # k_fc_tail down to the last pair
     {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0", "DNE_TAIL_TABLE": "0"},   # ... reading the member descriptors from memory
     {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "64"},                     # k_fc_quad (64 workgroups per pair) at every count
+    {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0", "DNE_FC_TAILK_MAX": "0"},   # k_fc_cols (4 workgroups per pair, the form for > 32 pairs per window) at every count
+    {"DNE_SPEC_MAX": "8"},                                              # speculative tail from four pairs on (round 2's default; now two)
     {"DNE_RENDER_BANDS": "1"},                                          # k_fc_tail + tail step rendering in place
     {"DNE_CONV1_FPW": "1"},                                             # reference-pass conv1 with one frame per workgroup (default 8)
     {"DNE_CONV1_FPW": "4"},
@@ -321,6 +323,9 @@ def test_reference_batch_sizes(nref, members, oracle, small_noise):
     {"DNE_GA_MATERIALIZE": "0", "DNE_FC_TAIL_MAX": "1"},                                              # ... through the streaming fc at every count
     {"DNE_FC_TAIL_MAX": "1"},                                                                         # children written out (default), noise-free streaming fc at every count
     {"DNE_FC_TAIL_MAX": "1", "DNE_FC_RB": "8"},                                                       # ... with 8-row batches
+    {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0", "DNE_FC_TAILK_MAX": "0"},                           # k_fc_cols<1>
+    {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0"},                                                    # k_fc_tail<1> (noise-free form: children written out)
+    {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "64"},                                                   # k_fc_quad<1>
 ])
 def test_ga_step_kernel_variants_are_bit_exact(knobs, oracle, small_noise, monkeypatch):
     """the GA evaluation (single members, one base vector per parent, final-RAM behaviour characterisation) through the kernel

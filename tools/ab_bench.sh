@@ -5,6 +5,6 @@
 cd ${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=gpurun_out/${AB_TAG:-ab}; mkdir -p $O
 for e in "$@"; do
-  env $e timeout 900 python bench.py --gpus 1 --steps ${AB_STEPS:-20} --warmup ${AB_WARMUP:-5} --no-cpu-baseline --extra none > $O/b.json 2> $O/b.err
+  env $e timeout 900 python bench.py --gpus 1 --steps ${AB_STEPS:-20} --warmup ${AB_WARMUP:-5} --no-cpu-baseline --extra none ${AB_ARGS:-} > $O/b.json 2> $O/b.err
   echo "$e: $(tail -1 $O/b.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2), 'ms/generation', round(d['value']), 'env-steps/s')")" | tee -a $O/ab.log
 done
