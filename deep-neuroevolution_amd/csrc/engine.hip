@@ -550,6 +550,7 @@ struct dne_handle {
     int duo_head_fused = 0;          // DNE_DUO_HEAD_FUSED: behind k_fc_duo the policy head and the emulator step share a launch (k_tail_step) instead of
                                      // k_out + k_env_logic; same-box A/B: 402.7 ms fused, 403.3 separate, 399.8 separate with k_out at two workgroups per CU -> off
     int fc_duo_ga = 0;               // DNE_FC_DUO_GA: the table-ordered fc for GA evaluations too (single members, one base vector per parent); measured slower, off
+    int fc_prio = 3;                 // DNE_FC_PRIO: s_setprio of k_fc_duo's waves (0-3)
     int duo_lag = 0;                 // DNE_DUO_LAG: extra row batches by which the second unit of a duo trails the first
     int fc_duo = 1, fc_duo_min = 800;   // DNE_FC_DUO / DNE_FC_DUO_MIN: table-ordered fc (k_unit_order + k_fc_duo + k_out) from this many active groups
     bool duo_now = false;            // decided per burst by eval_core (the unit order of each window is rebuilt then)
@@ -931,6 +932,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_SPEC_CONV1", 0, 1, &h->spec_conv1);
     env_int("DNE_FC_DUO", 0, 1, &h->fc_duo);
     env_int("DNE_DUO_LAG", 0, 64, &h->duo_lag);
+    env_int("DNE_FC_PRIO", 0, 3, &h->fc_prio);
     env_int("DNE_DUO_SOLO_BELOW", 0, 1 << 30, &h->duo_solo_below);
     env_int("DNE_DUO_HEAD_FUSED", 0, 1, &h->duo_head_fused);
     env_int("DNE_OUT_LDS_KB", 0, 64, &h->out_lds_kb);
@@ -1494,8 +1496,8 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         const bool solo = h->duo_solo_now;
         const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 3) / 4, blocks = std::min(items, h->fc_grid);
         const size_t out_lds = (size_t)h->out_lds_kb * 1024;   // an LDS reservation nobody uses: it only bounds k_out's workgroups per CU next to the streaming fc
-        if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0));
-        else hipLaunchKernelGGL((k_fc_duo<1, false>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0));
+        if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9));
+        else hipLaunchKernelGGL((k_fc_duo<1, false>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9));
         if (after_stream_kernel) hipEventRecord(after_stream_kernel, st);
         if (out_fused) return;   // the caller runs k_tail_step: policy head + emulator step in one launch
         if (es) hipLaunchKernelGGL((k_out<2, true>), dim3(count), dim3(256), out_lds, st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);

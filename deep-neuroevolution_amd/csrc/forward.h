@@ -1299,7 +1299,12 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
     const int tid = threadIdx.x, wv = uni(tid >> 6), lane = tid & 63;
     const unsigned voff = lane * 16;
     const Layout &L = A.L;
-    __builtin_amdgcn_s_setprio(3);
+    {   // wave priority of the HBM stream against co-resident conv / emulator waves (DNE_FC_PRIO, bits 9-10 of `lag`; default 3)
+        const int prio = (lag >> 9) & 3;
+        if (prio == 3) __builtin_amdgcn_s_setprio(3);
+        else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    }
     const bool solo = (lag & 256) != 0;   // sparse windows: one unit per wave (twice the waves, nothing to share anyway)
     lag &= 255;
     const int n_duos = solo ? n_units : (n_units + 1) >> 1, n_items = (n_duos + 3) >> 2;
@@ -1518,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
 // 44 k-values, weights are formed per lane as theta + sigma*eps straight into the B operand.  The MFMA's
 // k-ordered fmaf chain per slice + the ((s0+s1)+(s2+s3)) + bias combine (k_bn3_partials) are the oracle's order.
 template <int MT>
-__global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int member0, int F /* reference frames per member: MT * 16 * frame groups */,
+__global__ __launch_bounds__(256, 2) void k_fc_ref(FwdArgs A, int n_local, int member0, int F /* reference frames per member: MT * 16 * frame groups */,
                                                 const float *__restrict__ y2, float *__restrict__ y3p /*[n_local][4][F][256]*/) {
     // One workgroup of 4 waves per (member, quarter, group of MT * 16 frames); wave w owns columns 64w .. 64w+63 as four interleaved
     // 16-column MFMA tiles (tile c = columns 64w + 4*lane + c), so a lane's four B operands of a k-row are one 16-byte load.  8-row
@@ -1530,7 +1535,9 @@ __global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int memb
     // two 4-wave workgroups per quarter split by columns 3.0 ms, against 1.7 ms for the round-2 kernel without the fold.)
     constexpr int FG = MT * 16, KC = 8, XS = KC + 2, NST = 968 / KC, KK = KC / 4;   // XS = 10: lanes (frame, k) of a half-wave hit 32 distinct banks
     constexpr int LD = (FG * KC + 255) / 256;
-    __shared__ float xs[2][FG * XS];
+    // Stages travel in units of two (one where a sub-slice has an odd stage left): one barrier and one round of loads per unit --
+    // with 64 frames per workgroup a single 8-row stage is only 32 MFMAs per wave, too little to hide a barrier behind.
+    __shared__ float xs[4][FG * XS];                            // stage s lives in buffer s & 3: the current unit and the next
     __shared__ float bn2[64];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
     const Layout &L = A.L;
@@ -1545,73 +1552,87 @@ __global__ __launch_bounds__(256) void k_fc_ref(FwdArgs A, int n_local, int memb
     const float *th = A.bases + (size_t)A.m_slot[member] * A.base_stride + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
     const float *ysrc = y2 + ((size_t)mloc * F + (size_t)fg * FG) * 3872 + kbeg;
     if (tid < 64) bn2[tid] = A.bn[(size_t)member * 608 + 32 + tid];   // scale[32] then shift[32]
-    float yr[LD];
-    f4u er[KK];
-    f4a tr[KK];
-    auto load_stage = [&](int st) {
-#pragma unroll
-        for (int j = 0; j < LD; j++) {
-            const int e = tid + 256 * j;
-            yr[j] = e < FG * KC ? ysrc[(size_t)(e / KC) * 3872 + st * KC + e % KC] : 0.0f;
-        }
-#pragma unroll
-        for (int kk = 0; kk < KK; kk++) {
-            const size_t ro = (size_t)(st * KC + 4 * kk) * 256;
-            er[kk] = *(const f4u *)(eps + ro);
-            tr[kk] = *(const f4a *)(th + ro);
-        }
+    // stages of the unit that starts at stage s: 2, or 1 when s is the last stage of its sub-slice (16, 15, 15, ... stages)
+    auto unit_len = [](int s) {
+        const int end = s < FC_SUB0 / KC ? FC_SUB0 / KC : FC_SUB0 / KC + ((s - FC_SUB0 / KC) / (FC_SUBN / KC) + 1) * (FC_SUBN / KC);
+        return end - s < 2 ? end - s : 2;
     };
-    auto store_stage = [&](int st, int buf) {
+    float yr[2][LD];
+    f4u er[2][KK];
+    f4a tr[2][KK];
+    auto load_unit = [&](int s0, int n) {
 #pragma unroll
-        for (int j = 0; j < LD; j++) {
-            const int e = tid + 256 * j;
-            if (e < FG * KC) {
-                const int ch = (kbeg + st * KC + e % KC) & 31;
-                float t = yr[j] * bn2[ch];
-                t = t + bn2[32 + ch];
-                xs[buf][(e / KC) * XS + e % KC] = t > 0.0f ? t : 0.0f;
+        for (int u = 0; u < 2; u++)
+            if (u < n) {
+#pragma unroll
+                for (int j = 0; j < LD; j++) {
+                    const int e = tid + 256 * j;
+                    yr[u][j] = e < FG * KC ? ysrc[(size_t)(e / KC) * 3872 + (s0 + u) * KC + e % KC] : 0.0f;
+                }
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) {
+                    const size_t ro = (size_t)((s0 + u) * KC + 4 * kk) * 256;
+                    er[u][kk] = *(const f4u *)(eps + ro);
+                    tr[u][kk] = *(const f4a *)(th + ro);
+                }
             }
-        }
+    };
+    float w[2][KK][4];
+    auto store_unit = [&](int s0, int n) {   // activations of the unit into their LDS buffers, its weights into w
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (u < n) {
+#pragma unroll
+                for (int j = 0; j < LD; j++) {
+                    const int e = tid + 256 * j;
+                    if (e < FG * KC) {
+                        const int ch = (kbeg + (s0 + u) * KC + e % KC) & 31;
+                        float t = yr[u][j] * bn2[ch];
+                        t = t + bn2[32 + ch];
+                        xs[(s0 + u) & 3][(e / KC) * XS + e % KC] = t > 0.0f ? t : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { float pv = sc * er[u][kk][c]; w[u][kk][c] = tr[u][kk][c] + pv; }
+            }
     };
     f32x4 acc[MT][4], fold[MT][4];
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
         for (int c = 0; c < 4; c++) acc[m][c] = fold[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float w[KK][4];
-    auto form_w = [&]() {
-#pragma unroll
-        for (int kk = 0; kk < KK; kk++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) { float pv = sc * er[kk][c]; w[kk][c] = tr[kk][c] + pv; }
-    };
-    load_stage(0);
+    load_unit(0, 2);
     __syncthreads();          // bn2 visible
-    store_stage(0, 0);
-    form_w();
+    store_unit(0, 2);
     __syncthreads();
     int st = 0;
 #pragma unroll 1
-    for (int sub = 0; sub < 8; sub++) {   // the stages of one sub-slice are the inner loop; the fold sits between two runs of it
+    for (int sub = 0; sub < 8; sub++) {   // the units of one sub-slice are the inner loop; the fold sits between two runs of it
         const int end_st = (FC_SUB0 + sub * FC_SUBN) / KC;      // stages 16, 31, 46, ..., 121
 #pragma unroll 1
-        for (; st < end_st; st++) {
-            const int buf = st & 1;
-            if (st + 1 < NST) load_stage(st + 1);
+        while (st < end_st) {
+            const int n = end_st - st < 2 ? end_st - st : 2, ns = st + n;
+            const int nn = ns < NST ? unit_len(ns) : 0;
+            if (nn) load_unit(ns, nn);
 #pragma unroll
-            for (int kk = 0; kk < KK; kk++) {
+            for (int u = 0; u < 2; u++)
+                if (u < n) {
+                    const float *xb = xs[(st + u) & 3];
 #pragma unroll
-                for (int m = 0; m < MT; m++) {
-                    const float a = xs[buf][(m * 16 + lp) * XS + 4 * kk + lk];
+                    for (int kk = 0; kk < KK; kk++) {
 #pragma unroll
-                    for (int c = 0; c < 4; c++) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[kk][c], acc[m][c], 0, 0, 0);
+                        for (int m = 0; m < MT; m++) {
+                            const float a = xb[(m * 16 + lp) * XS + 4 * kk + lk];
+#pragma unroll
+                            for (int c = 0; c < 4; c++) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[u][kk][c], acc[m][c], 0, 0, 0);
+                        }
+                    }
                 }
-            }
-            if (st + 1 < NST) {
-                store_stage(st + 1, buf ^ 1);
-                form_w();
-            }
+            if (nn) store_unit(ns, nn);   // into the two buffers the unit just computed did not read
             __syncthreads();
+            st = ns;
         }
         // end of a sub-slice: the chains join the quarter's running fold and start again from 0
 #pragma unroll
