@@ -550,6 +550,7 @@ struct dne_handle {
     int duo_head_fused = 0;          // DNE_DUO_HEAD_FUSED: behind k_fc_duo the policy head and the emulator step share a launch (k_tail_step) instead of
                                      // k_out + k_env_logic; same-box A/B: 402.7 ms fused, 403.3 separate, 399.8 separate with k_out at two workgroups per CU -> off
     int fc_duo_ga = 0;               // DNE_FC_DUO_GA: the table-ordered fc for GA evaluations too (single members, one base vector per parent); measured slower, off
+    int fcref_mt8 = 0;               // DNE_FCREF_MT8
     int fc_prio = 3;                 // DNE_FC_PRIO: s_setprio of k_fc_duo's waves (0-3)
     int duo_lag = 0;                 // DNE_DUO_LAG: extra row batches by which the second unit of a duo trails the first
     int fc_duo = 1, fc_duo_min = 800;   // DNE_FC_DUO / DNE_FC_DUO_MIN: table-ordered fc (k_unit_order + k_fc_duo + k_out) from this many active groups
@@ -933,6 +934,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_DUO", 0, 1, &h->fc_duo);
     env_int("DNE_DUO_LAG", 0, 64, &h->duo_lag);
     env_int("DNE_FC_PRIO", 0, 3, &h->fc_prio);
+    env_int("DNE_FCREF_MT8", 0, 1, &h->fcref_mt8);
     env_int("DNE_DUO_SOLO_BELOW", 0, 1 << 30, &h->duo_solo_below);
     env_int("DNE_DUO_HEAD_FUSED", 0, 1, &h->duo_head_fused);
     env_int("DNE_OUT_LDS_KB", 0, 64, &h->out_lds_kb);
@@ -1373,7 +1375,7 @@ static int ref_pass(dne_handle *h, int n) {
         if (F == 16 || F == 32 || F == 64 || F == 128) {   // matrix-core path
             const int grid = (nc + 7) / 8 * 8 * 4;   // (member, quarter) workgroups, those of a member on one XCD
 #define FCREF(MT, NG) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid * NG), dim3(256), 0, st, A, nc, m0, F, (const float *)y2, y3p)
-            if (F == 16) FCREF(1, 1); else if (F == 32) FCREF(2, 1); else if (F == 64) FCREF(4, 1); else FCREF(4, 2);   // 128 frames: two groups of 64
+            if (F == 16) FCREF(1, 1); else if (F == 32) FCREF(2, 1); else if (F == 64) FCREF(4, 1); else if (h->fcref_mt8) FCREF(8, 1); else FCREF(4, 2);   // 128 frames: two groups of 64 (DNE_FCREF_MT8: one group of 128, one wave per SIMD)
 #undef FCREF
             hipLaunchKernelGGL(k_bn3_partials, dim3(nc), dim3(256), 0, st, A, m0, F, (const float *)y3p);
         } else {

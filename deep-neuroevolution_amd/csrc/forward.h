@@ -1523,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
 // 44 k-values, weights are formed per lane as theta + sigma*eps straight into the B operand.  The MFMA's
 // k-ordered fmaf chain per slice + the ((s0+s1)+(s2+s3)) + bias combine (k_bn3_partials) are the oracle's order.
 template <int MT>
-__global__ __launch_bounds__(256, 2) void k_fc_ref(FwdArgs A, int n_local, int member0, int F /* reference frames per member: MT * 16 * frame groups */,
+__global__ __launch_bounds__(256, MT == 8 ? 1 : 2) void k_fc_ref(FwdArgs A, int n_local, int member0, int F /* reference frames per member: MT * 16 * frame groups */,
                                                 const float *__restrict__ y2, float *__restrict__ y3p /*[n_local][4][F][256]*/) {
     // One workgroup of 4 waves per (member, quarter, group of MT * 16 frames); wave w owns columns 64w .. 64w+63 as four interleaved
     // 16-column MFMA tiles (tile c = columns 64w + 4*lane + c), so a lane's four B operands of a k-row are one 16-byte load.  8-row
@@ -1552,60 +1552,58 @@ __global__ __launch_bounds__(256, 2) void k_fc_ref(FwdArgs A, int n_local, int m
     const float *th = A.bases + (size_t)A.m_slot[member] * A.base_stride + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
     const float *ysrc = y2 + ((size_t)mloc * F + (size_t)fg * FG) * 3872 + kbeg;
     if (tid < 64) bn2[tid] = A.bn[(size_t)member * 608 + 32 + tid];   // scale[32] then shift[32]
-    // stages of the unit that starts at stage s: 2, or 1 when s is the last stage of its sub-slice (16, 15, 15, ... stages)
-    auto unit_len = [](int s) {
-        const int end = s < FC_SUB0 / KC ? FC_SUB0 / KC : FC_SUB0 / KC + ((s - FC_SUB0 / KC) / (FC_SUBN / KC) + 1) * (FC_SUBN / KC);
-        return end - s < 2 ? end - s : 2;
-    };
+    // Loads and LDS stores of a unit are unconditional: a unit whose second stage does not exist (the odd stage that ends a
+    // sub-slice, the end of the quarter) fetches a clamped stage into a buffer nobody reads.  With the loads under `if (u < n)`
+    // the compiler could not pair them with their waits and put s_waitcnt vmcnt(0) between the two stages' loads.
     float yr[2][LD];
     f4u er[2][KK];
     f4a tr[2][KK];
-    auto load_unit = [&](int s0, int n) {
+    auto load_unit = [&](int s0) {
 #pragma unroll
-        for (int u = 0; u < 2; u++)
-            if (u < n) {
+        for (int u = 0; u < 2; u++) {
+            const int s = s0 + u < NST ? s0 + u : NST - 1;
 #pragma unroll
-                for (int j = 0; j < LD; j++) {
-                    const int e = tid + 256 * j;
-                    yr[u][j] = e < FG * KC ? ysrc[(size_t)(e / KC) * 3872 + (s0 + u) * KC + e % KC] : 0.0f;
-                }
-#pragma unroll
-                for (int kk = 0; kk < KK; kk++) {
-                    const size_t ro = (size_t)((s0 + u) * KC + 4 * kk) * 256;
-                    er[u][kk] = *(const f4u *)(eps + ro);
-                    tr[u][kk] = *(const f4a *)(th + ro);
-                }
+            for (int j = 0; j < LD; j++) {
+                const int e = tid + 256 * j;
+                yr[u][j] = e < FG * KC ? ysrc[(size_t)(e / KC) * 3872 + s * KC + e % KC] : 0.0f;
             }
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++) {
+                const size_t ro = (size_t)(s * KC + 4 * kk) * 256;
+                er[u][kk] = *(const f4u *)(eps + ro);
+                tr[u][kk] = *(const f4a *)(th + ro);
+            }
+        }
     };
     float w[2][KK][4];
-    auto store_unit = [&](int s0, int n) {   // activations of the unit into their LDS buffers, its weights into w
+    auto store_unit = [&](int s0) {   // activations of the unit into their LDS buffers, its weights into w
 #pragma unroll
-        for (int u = 0; u < 2; u++)
-            if (u < n) {
+        for (int u = 0; u < 2; u++) {
+            const int s = s0 + u < NST ? s0 + u : NST - 1;
 #pragma unroll
-                for (int j = 0; j < LD; j++) {
-                    const int e = tid + 256 * j;
-                    if (e < FG * KC) {
-                        const int ch = (kbeg + (s0 + u) * KC + e % KC) & 31;
-                        float t = yr[u][j] * bn2[ch];
-                        t = t + bn2[32 + ch];
-                        xs[(s0 + u) & 3][(e / KC) * XS + e % KC] = t > 0.0f ? t : 0.0f;
-                    }
+            for (int j = 0; j < LD; j++) {
+                const int e = tid + 256 * j;
+                if (e < FG * KC) {
+                    const int ch = (kbeg + s * KC + e % KC) & 31;
+                    float t = yr[u][j] * bn2[ch];
+                    t = t + bn2[32 + ch];
+                    xs[(s0 + u) & 3][(e / KC) * XS + e % KC] = t > 0.0f ? t : 0.0f;
                 }
-#pragma unroll
-                for (int kk = 0; kk < KK; kk++)
-#pragma unroll
-                    for (int c = 0; c < 4; c++) { float pv = sc * er[u][kk][c]; w[u][kk][c] = tr[u][kk][c] + pv; }
             }
+#pragma unroll
+            for (int kk = 0; kk < KK; kk++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) { float pv = sc * er[u][kk][c]; w[u][kk][c] = tr[u][kk][c] + pv; }
+        }
     };
     f32x4 acc[MT][4], fold[MT][4];
 #pragma unroll
     for (int m = 0; m < MT; m++)
 #pragma unroll
         for (int c = 0; c < 4; c++) acc[m][c] = fold[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    load_unit(0, 2);
+    load_unit(0);
     __syncthreads();          // bn2 visible
-    store_unit(0, 2);
+    store_unit(0);
     __syncthreads();
     int st = 0;
 #pragma unroll 1
@@ -1613,9 +1611,8 @@ __global__ __launch_bounds__(256, 2) void k_fc_ref(FwdArgs A, int n_local, int m
         const int end_st = (FC_SUB0 + sub * FC_SUBN) / KC;      // stages 16, 31, 46, ..., 121
 #pragma unroll 1
         while (st < end_st) {
-            const int n = end_st - st < 2 ? end_st - st : 2, ns = st + n;
-            const int nn = ns < NST ? unit_len(ns) : 0;
-            if (nn) load_unit(ns, nn);
+            const int n = end_st - st < 2 ? end_st - st : 2, ns = st + n;   // 2 stages, or the odd one that ends the sub-slice
+            load_unit(ns);
 #pragma unroll
             for (int u = 0; u < 2; u++)
                 if (u < n) {
@@ -1630,7 +1627,7 @@ __global__ __launch_bounds__(256, 2) void k_fc_ref(FwdArgs A, int n_local, int m
                         }
                     }
                 }
-            if (nn) store_unit(ns, nn);   // into the two buffers the unit just computed did not read
+            store_unit(ns);   // into the two buffers the unit just computed did not read
             __syncthreads();
             st = ns;
         }
