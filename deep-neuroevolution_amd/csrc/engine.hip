@@ -551,6 +551,7 @@ struct dne_handle {
                                      // k_out + k_env_logic; same-box A/B: 402.7 ms fused, 403.3 separate, 399.8 separate with k_out at two workgroups per CU -> off
     int fc_duo_ga = 0;               // DNE_FC_DUO_GA: the table-ordered fc for GA evaluations too (single members, one base vector per parent); measured slower, off
     int fcref_mt8 = 0;               // DNE_FCREF_MT8
+    int conv2_ref_fpw = 8;           // DNE_CONV2_REF_FPW: reference frames per conv2 workgroup (8, 4, or 1 = the lock-step kernel)
     int fc_prio = 3;                 // DNE_FC_PRIO: s_setprio of k_fc_duo's waves (0-3)
     int duo_lag = 0;                 // DNE_DUO_LAG: extra row batches by which the second unit of a duo trails the first
     int fc_duo = 1, fc_duo_min = 800;   // DNE_FC_DUO / DNE_FC_DUO_MIN: table-ordered fc (k_unit_order + k_fc_duo + k_out) from this many active groups
@@ -935,6 +936,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_DUO_LAG", 0, 64, &h->duo_lag);
     env_int("DNE_FC_PRIO", 0, 3, &h->fc_prio);
     env_int("DNE_FCREF_MT8", 0, 1, &h->fcref_mt8);
+    env_int("DNE_CONV2_REF_FPW", 1, 8, &h->conv2_ref_fpw);
     env_int("DNE_DUO_SOLO_BELOW", 0, 1 << 30, &h->duo_solo_below);
     env_int("DNE_DUO_HEAD_FUSED", 0, 1, &h->duo_head_fused);
     env_int("DNE_OUT_LDS_KB", 0, 64, &h->out_lds_kb);
@@ -1368,8 +1370,13 @@ static int ref_pass(dne_handle *h, int n) {
         // the convolutions leave per-frame moments behind; scale / shift per member is a 128-term sum per channel
         hipLaunchKernelGGL((k_bn_finalize<16>), dim3((nc * 16 + 255) / 256), dim3(256), 0, st, A, m0, nc, F, (const float *)fr1, 441, 0,
                            h->L.c1b, h->L.bn1b, h->L.bn1g);
-        hipLaunchKernelGGL((k_conv2<true>), dim3(nc * F), dim3(256), 0, st, A, (const int *)nullptr, 1, F, m0,
-                           (const float *)y1, y2, 1, fr2);
+        if (F % 8 == 0 && h->conv2_ref_fpw == 8)
+            hipLaunchKernelGGL((k_conv2_ref<8>), dim3(nc * (F / 8)), dim3(256), 0, st, A, F, m0, (const float *)y1, y2, fr2);
+        else if (F % 4 == 0 && h->conv2_ref_fpw >= 4)
+            hipLaunchKernelGGL((k_conv2_ref<4>), dim3(nc * (F / 4)), dim3(256), 0, st, A, F, m0, (const float *)y1, y2, fr2);
+        else
+            hipLaunchKernelGGL((k_conv2<true>), dim3(nc * F), dim3(256), 0, st, A, (const int *)nullptr, 1, F, m0,
+                               (const float *)y1, y2, 1, fr2);
         hipLaunchKernelGGL((k_bn_finalize<32>), dim3((nc * 32 + 255) / 256), dim3(256), 0, st, A, m0, nc, F, (const float *)fr2, 121, 32,
                            h->L.c2b, h->L.bn2b, h->L.bn2g);
         if (F == 16 || F == 32 || F == 64 || F == 128) {   // matrix-core path

@@ -594,6 +594,111 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
     }
 }
 
+// Reference-pass conv2: one workgroup takes FPW consecutive reference frames of ONE member through the layer, so the member's
+// perturbed weights (64 B fragments per lane) and bn1 scale / shift are formed once per FPW frames instead of once per frame
+// (k_conv2<true> with one frame per workgroup re-read 64 KB of theta + eps for every 28 KB of activations), and the next
+// frame's conv1 output is fetched into registers under the MFMAs of the current one.  Same tiles, same MFMA order, same
+// moment tree as conv2_body -- same bits.
+template <int FPW>
+__global__ __launch_bounds__(256, 2) void k_conv2_ref(FwdArgs A, int F, int member0, const float *__restrict__ y1 /*[n_local * F][441][16]*/,
+                                                   float *__restrict__ y2 /*[n_local * F][121][32]*/,
+                                                   float *__restrict__ fr /*[n_local * F][2][32]*/) {
+    constexpr int PS = C2_PS, RW = C2_RW;
+    __shared__ Conv2Lds S;
+    float (&a_s)[24 * C2_RW * C2_PS] = S.a_s;
+    float (&wsum)[4][2][16] = S.wsum;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
+    const int nt = wv & 1, mt0 = 4 * (wv >> 1);
+    const int gpm = F / FPW, mloc = blockIdx.x / gpm, f0 = (blockIdx.x % gpm) * FPW, member = member0 + mloc;
+    const float *base = A.bases + (size_t)A.m_slot[member] * A.base_stride + A.L.c2w;
+    const float *eps = A.noise + A.m_off[member] + A.L.c2w;
+    const float sc = A.m_scale[member];
+    const float *bn = A.bn + (size_t)member * 608;
+    float yv[28];
+    auto fetch = [&](int f) {
+        const float *src = y1 + ((size_t)mloc * F + f) * 7056;
+#pragma unroll
+        for (int j = 0; j < 28; j++) {
+            const int e = tid + 256 * j;
+            yv[j] = e < 7056 ? src[e] : 0.0f;
+        }
+    };
+    fetch(f0);
+    const float s1 = bn[tid & 15], h1 = bn[16 + (tid & 15)];
+    float b[64];
+#pragma unroll
+    for (int kk = 0; kk < 64; kk++) {
+        const int o = (4 * kk + lk) * 32 + nt * 16 + lp;
+        float v = sc * eps[o];
+        b[kk] = base[o] + v;
+    }
+    float pb = sc * eps[8192 + nt * 16 + lp];
+    const float bias = base[8192 + nt * 16 + lp] + pb;
+    for (int pix = tid; pix < 24 * 24; pix += 256) {   // the SAME-padding ring, once: the fills never touch it
+        const int y = pix / 24, x = pix % 24;
+        if (y < 1 || y > 21 || x < 1 || x > 21)
+#pragma unroll
+            for (int c = 0; c < 16; c++) a_s[(y * RW + x) * PS + c] = 0.0f;
+    }
+    int off[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int p = min((mt0 + m) * 16 + lp, 120);
+        off[m] = ((p / 11) * 2 * RW + (p % 11) * 2) * PS + lk;
+    }
+    for (int fi = 0; fi < FPW; fi++) {
+#pragma unroll
+        for (int j = 0; j < 28; j++) {
+            const int e = tid + 256 * j;
+            if (e < 7056) {
+                const int c = e & 15, pix = e >> 4;
+                float t = yv[j] * s1;
+                t = t + h1;
+                t = t > 0.0f ? t : 0.0f;
+                a_s[((pix / 21 + 1) * RW + pix % 21 + 1) * PS + c] = t;
+            }
+        }
+        __syncthreads();
+        if (fi + 1 < FPW) fetch(f0 + fi + 1);        // in flight under the MFMAs below
+        f32x4 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 4; kh++) {
+#pragma unroll
+            for (int kw = 0; kw < 4; kw++) {
+#pragma unroll
+                for (int c4 = 0; c4 < 4; c4++) {   // k = (kh*4+kw)*16 + c4*4 + (l>>4)
+                    const int kk = (kh * 4 + kw) * 4 + c4;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        const float x = a_s[off[m] + (kh * RW + kw) * PS + c4 * 4];
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, b[kk], acc[m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        const size_t row = (size_t)mloc * F + f0 + fi;
+        float *o = y2 + row * 3872;
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {   // D[row = 4*(l>>4) + r][col = l&15]
+                const int pos = (mt0 + m) * 16 + lk * 4 + r;
+                if (pos < 121) o[pos * 32 + nt * 16 + lp] = acc[m][r] + bias;
+            }
+        float Ws = 0.0f, Wq = 0.0f;                  // this wave's four tiles in tile order, then (tiles 0-3) + (tiles 4-7)
+#pragma unroll
+        for (int m = 0; m < 4; m++) tile_moments(acc[m], (mt0 + m) * 16 + lk * 4, 121, Ws, Wq);
+        if (lk == 0) { wsum[wv][0][lp] = Ws; wsum[wv][1][lp] = Wq; }
+        __syncthreads();                             // also: every wave is done reading this frame's image
+        if (tid < 64) {
+            const int k = tid >> 5, c = tid & 31, h = c >> 4, l = c & 15;
+            fr[(row * 2 + k) * 32 + c] = wsum[h][k][l] + wsum[h + 2][k][l];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- conv1 -> conv2 in one kernel (lock-steps)
 // At full width a window's lock-step is a serial chain conv1 -> conv2 -> fc -> emulator, each link stretched by the other
 // windows' HBM streams; y1 (28 KB per member) made a round trip through the memory system between the first two.  Here one
