@@ -183,10 +183,13 @@ __device__ __forceinline__ void render_body(EnvLds &s, const EnvArgs &E, int m, 
 __global__ __launch_bounds__(1024) void k_env_render(EnvArgs E, const int *__restrict__ list, int gsize, int fill, int nbands) {
     __shared__ __attribute__((aligned(16))) EnvLds s;
     const int b = blockIdx.x / nbands, band = blockIdx.x % nbands;
+    DNE_PHASE(0, 0);
     const int m = env_member(E, list, gsize, b);
-    if (!E.stepped[m]) return;
+    const int stepped = E.stepped[m];   // asked for first, looked at once the tables are on their way
     synth_load_tables(s, E.T);
+    if (!stepped) return;
     render_body(s, E, m, fill != 0, band, nbands);
+    DNE_PHASE(0, 4);
 }
 
 // Tail of a generation (a few dozen members left, every kernel boundary is a visible bubble): one workgroup per
@@ -265,6 +268,7 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
     }
     if constexpr (RENDER) synth_load_tables(s, E.T);
     if (!wait()) return;
+    DNE_PHASE(3, 1);
     if (tid < 256) {
         const float *p = y3t + (size_t)m * 4 * 256 + tid;
         const float s01 = p[0] + p[256];
@@ -289,6 +293,7 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
         out_wave_sums<1>(pr, nact, H.red[wv], lane);
     }
     __syncthreads();
+    DNE_PHASE(3, 2);
     if (tid < nact) {
         const float s01 = H.red[0][0][tid] + H.red[1][0][tid];
         const float s23 = H.red[2][0][tid] + H.red[3][0][tid];
@@ -298,6 +303,7 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
         lg[tid] = t + bias;
     }
     __syncthreads();
+    DNE_PHASE(3, 3);
     if (spec_pos >= 0) {   // the emulator + renderer outcome of every action is on the table: every thread finds the policy's
         int best = 0;      // choice, the thread that read that candidate commits it, all copy its frame stack
         for (int a = 1; a < nact; a++)
@@ -344,10 +350,15 @@ __global__ __launch_bounds__(1024) void k_tail_step(FwdArgs A, EnvArgs E, const 
                                                      int32_t *__restrict__ actions) {
     __shared__ HeadLds<RENDER> H;
     const int b = blockIdx.x;
+    DNE_PHASE(3, 0);
     const int m = env_member(E, list, gsize, b);
     if (E.done[m]) { if (threadIdx.x == 0) E.stepped[m] = 0; return; }
     if (A.tt.n > 0) head_body<HAS_BN, RENDER, true>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b);
     else head_body<HAS_BN, RENDER, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b);
+#ifdef DNE_PHASE_CLOCK
+    __syncthreads();
+    DNE_PHASE(3, 4);
+#endif
 }
 
 // The two speculative kernels ride in launches of the forward pass (same stream, no event traffic -- a cross-stream event
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(256) void k_tail_select_conv1(FwdArgs A, EnvArgs E,
         const int m = env_member(E, list, gsize, b);
         if (E.done[m]) { if (threadIdx.x == 0) E.stepped[m] = 0; return; }
         if (A.tt.n > 0) head_body<HAS_BN, false, true>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b, b);
-    else head_body<HAS_BN, false, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b, b);
+        else head_body<HAS_BN, false, false>(H, A, E, m, tslimit, y3t, y3, actions, NoWait{}, b, b);
         return;
     }
     Conv1Lds &S = *reinterpret_cast<Conv1Lds *>(lds);
@@ -538,6 +549,7 @@ struct dne_handle {
     int render_threads = 256;
     int conv1_fpw = 8;               // reference pass: frames per conv1 workgroup (DNE_CONV1_FPW: 1, 2, 4, 8)
     int conv_fused = 1, conv_fused_min = 129;   // DNE_CONV_FUSED / DNE_CONV_FUSED_MIN: conv1 + conv2 in one kernel from this many members
+    int conv12t_max = 64;            // members up to which conv1 -> conv2 is one launch of four workgroups per member (DNE_CONV12T_MAX, 0 = off)
     int conv_split_max = 32;         // members up to which the convolutions use their finest split (DNE_CONV_SPLIT_MAX)
     int conv_split_mid = 256;        // ... their middle split: conv1 over 4 workgroups up to this many members, conv2 over 2 up to twice as many (DNE_CONV_SPLIT_MID)
     int fc_pairs = 2;                // ES full-width fc: antithetic pairs per work item (DNE_FC_PAIRS, 1 = k_fc<2>)
@@ -904,6 +916,8 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_CONV_FUSED_MIN", 1, 1 << 20, &h->conv_fused_min);
     CH(hipFuncSetAttribute((const void *)k_conv12<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
     CH(hipFuncSetAttribute((const void *)k_conv12<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
+    CH(hipFuncSetAttribute((const void *)k_conv12t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
+    CH(hipFuncSetAttribute((const void *)k_conv12t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
     CH(hipFuncSetAttribute((const void *)k_unit_order, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CH(hipFuncSetAttribute((const void *)k_lconv_mfma<32, 64, 4, 2, 21, 11, 1, 34, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<32, 4, 2, 11, 34>()));
     CH(hipFuncSetAttribute((const void *)k_lconv_mfma<64, 64, 3, 1, 11, 11, 1, 68, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<64, 3, 1, 11, 68>()));
@@ -927,6 +941,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_PAIRS", 1, 2, &h->fc_pairs);
     env_int("DNE_CONV1_FPW", 1, 8, &h->conv1_fpw);
     env_int("DNE_CONV_SPLIT_MAX", 0, 1 << 20, &h->conv_split_max);
+    env_int("DNE_CONV12T_MAX", 0, 1 << 20, &h->conv12t_max);
     env_int("DNE_CONV_SPLIT_MID", 0, 1 << 20, &h->conv_split_mid);
     env_int("DNE_FC2_MIN", 2, 1 << 30, &h->fc2_min_total);
     env_int("DNE_SPEC_MAX", 0, 64, &h->spec_max);
@@ -1401,6 +1416,18 @@ static int ref_pass(dne_handle *h, int n) {
     return 0;
 }
 
+// profiling build (-DDNE_PHASE_CLOCK): the milestones of the last launches, [6 kernels][128 workgroups][8]; -1 in the product library
+extern "C" int dne_debug_phase_clock(dne_handle *h, long long *out) {
+#ifdef DNE_PHASE_CLOCK
+    HCHECK(h, hipDeviceSynchronize());
+    HCHECK(h, hipMemcpyFromSymbol(out, HIP_SYMBOL(dne::g_phase), sizeof(long long) * 6 * 128 * 8));
+    return 0;
+#else
+    (void)out;
+    return h->fail("dne_debug_phase_clock: this library was built without DNE_PHASE_CLOCK (make clock)");
+#endif
+}
+
 extern "C" int dne_ref_pass(dne_handle *h, int n) {
     DeviceGuard dg(h);
     if (check_n(h, n)) return -1;
@@ -1454,6 +1481,12 @@ static void launch_forward(dne_handle *h, const int *list, int count, int gsize,
         float *y1 = use_done ? nullptr : h->y1;                           // dne_act / debug_activations want y1; evaluations do not
         if (es) hipLaunchKernelGGL((k_conv12<true>), dim3(items), dim3(256), sizeof(Conv12Lds), st, A, list, gsize, (const uint8_t *)h->stacks, y1, h->y2);
         else hipLaunchKernelGGL((k_conv12<false>), dim3(items), dim3(256), sizeof(Conv12Lds), st, A, list, gsize, (const uint8_t *)h->stacks, y1, h->y2);
+        return;
+    }
+    if (items <= h->conv12t_max && !h->dbg_skip) {   // the tail: four workgroups per member through both convolutions, no y1 round trip
+        float *y1 = use_done ? nullptr : h->y1;
+        if (es) hipLaunchKernelGGL((k_conv12t<true>), dim3(items * 4), dim3(512), sizeof(Conv12Lds), st, A, list, gsize, (const uint8_t *)h->stacks, y1, h->y2);
+        else hipLaunchKernelGGL((k_conv12t<false>), dim3(items * 4), dim3(512), sizeof(Conv12Lds), st, A, list, gsize, (const uint8_t *)h->stacks, y1, h->y2);
         return;
     }
     if (!(h->dbg_skip & 1))

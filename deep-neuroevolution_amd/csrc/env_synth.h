@@ -17,6 +17,15 @@
 
 namespace dne {
 
+// Profiling build only (make clock -> libdne_hip_clock.so, tools/phase_clock.py): thread 0 of the first 128 workgroups of the
+// tail's kernels leaves the 100 MHz wall clock at a few milestones of its last launch.  Compiled out of the product library.
+#ifdef DNE_PHASE_CLOCK
+__device__ long long g_phase[6][128][8];
+#define DNE_PHASE(K, I) do { if (threadIdx.x == 0 && blockIdx.x < 128) dne::g_phase[K][blockIdx.x][I] = (long long)wall_clock64(); } while (0)
+#else
+#define DNE_PHASE(K, I) do { } while (0)
+#endif
+
 // RAM map (DESIGN.md "SynthAtari")
 enum : int {
     RM_FC = 0, RM_RNG = 2, RM_PX = 6, RM_PROW = 7, RM_LIVES = 8, RM_OVER = 9, RM_TEMP = 10, RM_COOL = 11,
@@ -393,6 +402,7 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     if (tid < 192) s.slot_of_key[tid] = -1;
     if (tid == 0) s.misc[2] = 0;
     __syncthreads();
+    DNE_PHASE(0, 1);
     int key = 0;
     const bool myrow = tid >= ylo && tid < yhi;
     if (myrow) {
@@ -424,6 +434,7 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
         if (lane < 32) row[lane + 128] = (uint8_t)((synth_row_pixel(lane + 128, DNE_ROW_ARGS(a_)) << 4) | synth_row_pixel(lane + 128, DNE_ROW_ARGS(b_)));
     }
     __syncthreads();
+    DNE_PHASE(0, 2);
     for (int i = tid; i < nu * 84; i += nthr) {   // horizontal pass over the unique rows
         const int u = i / 84, xx = i % 84;
         const uint8_t *px = s.img + u * 160 + s.R.xmin[xx];
@@ -434,6 +445,7 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
         s.tmp[i] = (float)acc;
     }
     __syncthreads();
+    DNE_PHASE(0, 3);
     // vertical pass + u8 truncation + stack shift.  The old stack words are fetched VP at a time (all of them before
     // the first barrier when the workgroup covers the stack in one go) so that the global-load latency is paid once
     // per chunk, not once per pixel.

@@ -856,6 +856,162 @@ __global__ __launch_bounds__(256, 2) void k_conv12(FwdArgs A, const int *__restr
         }
 }
 
+// conv1 -> conv2 in one launch for the tail of a generation (a few dozen members left: a lock-step is a chain of launches on a
+// nearly idle chip, and every launch has a floor of 3-4 us whatever it does).  Four workgroups of eight waves per member; each
+// owns two of conv2's eight position tiles (32 of the 121 positions), works out for itself the rows of conv1's output those
+// positions read -- at most 15 of the 28 conv1 tiles, one or two per wave, some of them computed by a neighbour as well (48 tiles
+// per member instead of 28; the matrix cores are idle anyway) -- and runs its conv2 tiles over them on four waves.  No
+// workgroup waits for another; y1 never leaves LDS.  Same tiles, same MFMA order, same bits as k_conv1 + k_conv2.
+template <bool HAS_BN, bool TT>
+__device__ __forceinline__ void conv12t_body(Conv12Lds &S, const FwdArgs &A, const Item &it, int part, float *__restrict__ y1 /*may be null*/,
+                                             float *__restrict__ y2) {
+    constexpr int PS = C2_PS, RW = C2_RW, NT = 512;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, ci = lane >> 4;
+    const float *base = item_base<TT>(A, it);
+    const float *eps = item_eps<TT>(A, it);
+    const float sc = item_scale<TT>(A, it);
+    const float *bn = A.bn + (size_t)it.member * 608;
+    // conv2 positions 32 part .. 32 part + 31 -> conv2 rows oy0 .. oy1 -> conv1 rows ra .. rb (4x4 stride 2, SAME(1,2)) -> tiles t0 .. t1
+    DNE_PHASE(1, 0);
+    const int oy0 = (32 * part) / 11, oy1 = min(32 * part + 31, 120) / 11;
+    const int ra = max(2 * oy0 - 1, 0), rb = min(2 * oy1 + 2, 20);
+    const int t0 = (21 * ra) / 16, t1 = (21 * rb + 20) / 16;
+    uint32_t px[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        const int e = tid + NT * j;
+        px[j] = e < 7056 ? ((const uint32_t *)it.ob)[e] : 0u;
+    }
+    float b[64];
+    {
+        const float *b1 = base + A.L.c1w, *e1 = eps + A.L.c1w;
+#pragma unroll
+        for (int kk = 0; kk < 64; kk++) {
+            float v = sc * e1[64 * kk + lane];
+            b[kk] = b1[64 * kk + lane] + v;
+        }
+    }
+    float pb1 = sc * eps[A.L.c1w + 4096 + lp];
+    const float bias1 = base[A.L.c1w + 4096 + lp] + pb1;
+    const float s1 = HAS_BN ? bn[lp] : 1.0f, h1 = HAS_BN ? bn[16 + lp] : 0.0f;      // conv1's output channel of this lane = lp
+    const int nt = wv & 1, mt = 2 * part + ((wv >> 1) & 1), lk = ci;                  // conv2: waves 0..3, one tile each
+    float pb2 = sc * eps[A.L.c2w + 8192 + nt * 16 + lp];
+    const float bias2 = base[A.L.c2w + 8192 + nt * 16 + lp] + pb2;
+    if (tid < 256) S.lut[tid] = (float)tid / 255.0f;
+    for (int i = tid; i < 688; i += NT) {                                             // conv1's 2-pixel zero border
+        int r, c;
+        if (i < 352) { r = i / 88; r = r < 2 ? r : 84 + r; c = i % 88; }
+        else { const int j = i - 352; r = 2 + j / 4; c = j % 4; c = c < 2 ? c : 84 + c; }
+        S.img[r * 88 + c] = 0u;
+    }
+    for (int pix = tid; pix < 24 * 24; pix += NT) {                                   // conv2's SAME-padding ring
+        const int y = pix / 24, x = pix % 24;
+        if (y < 1 || y > 21 || x < 1 || x > 21)
+#pragma unroll
+            for (int c = 0; c < 16; c++) S.a_s[(y * RW + x) * PS + c] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        const int e = tid + NT * j;
+        if (e < 7056) S.img[(e / 84 + 2) * 88 + e % 84 + 2] = px[j];
+    }
+    __syncthreads();
+    DNE_PHASE(1, 1);
+    float *out1 = y1 ? y1 + (size_t)it.row * 7056 : nullptr;
+    auto run1 = [&](int tA, int tB, auto has_b) {
+        constexpr bool HASB = decltype(has_b)::value;
+        const int pA = min(tA * 16 + lp, 440), pB = HASB ? min(tB * 16 + lp, 440) : 0;
+        const int oA = (pA / 21) * 4 * 88 + (pA % 21) * 4, oB = (pB / 21) * 4 * 88 + (pB % 21) * 4;
+        f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 8; kh++) {
+#pragma unroll
+            for (int kw = 0; kw < 8; kw++) {
+                const float xA = S.lut[(S.img[oA + kh * 88 + kw] >> (8 * ci)) & 255u];
+                accA = __builtin_amdgcn_mfma_f32_16x16x4f32(xA, b[kh * 8 + kw], accA, 0, 0, 0);
+                if (HASB) {
+                    const float xB = S.lut[(S.img[oB + kh * 88 + kw] >> (8 * ci)) & 255u];
+                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(xB, b[kh * 8 + kw], accB, 0, 0, 0);
+                }
+            }
+        }
+        auto emit = [&](const f32x4 &acc, int t) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {   // D[row = 4*(l>>4) + r][col = l&15]
+                const int pos = t * 16 + ci * 4 + r;
+                if (pos < 441) {
+                    const float y = acc[r] + bias1;
+                    if (out1) out1[pos * 16 + lp] = y;
+                    float a = y;
+                    if (HAS_BN) {
+                        a = a * s1;
+                        a = a + h1;
+                    }
+                    S.a_s[((pos / 21 + 1) * RW + pos % 21 + 1) * PS + lp] = a > 0.0f ? a : 0.0f;
+                }
+            }
+        };
+        emit(accA, tA);
+        if (HASB) emit(accB, tB);
+    };
+    {
+        const int tA = t0 + wv, tB = tA + 8;
+        if (tB <= t1) run1(tA, tB, std::true_type{});
+        else if (tA <= t1) run1(tA, tA, std::false_type{});
+    }
+    DNE_PHASE(1, 2);
+    float b2[64];
+    if (wv < 4) {
+        const float *w2 = base + A.L.c2w, *ee = eps + A.L.c2w;
+#pragma unroll
+        for (int kk = 0; kk < 64; kk++) {
+            const int o = (4 * kk + lk) * 32 + nt * 16 + lp;
+            float v = sc * ee[o];
+            b2[kk] = w2[o] + v;
+        }
+    }
+    __syncthreads();
+    DNE_PHASE(1, 3);
+    if (wv >= 4) return;
+    const int p = min(mt * 16 + lp, 120);
+    const int off = ((p / 11) * 2 * RW + (p % 11) * 2) * PS + lk;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 4; kh++) {
+#pragma unroll
+        for (int kw = 0; kw < 4; kw++) {
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++) {   // k = (kh*4+kw)*16 + c4*4 + (l>>4)
+                const float x = S.a_s[off + (kh * RW + kw) * PS + c4 * 4];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x, b2[(kh * 4 + kw) * 4 + c4], acc, 0, 0, 0);
+            }
+        }
+    }
+    float *o = y2 + (size_t)it.row * 3872;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int pos = mt * 16 + lk * 4 + r;
+        if (pos < 121) o[pos * 32 + nt * 16 + lp] = acc[r] + bias2;
+    }
+    DNE_PHASE(1, 4);
+}
+
+template <bool HAS_BN>
+__global__ __launch_bounds__(512) void k_conv12t(FwdArgs A, const int *__restrict__ list, int gsize, const uint8_t *__restrict__ stacks,
+                                                 float *__restrict__ y1 /*may be null*/, float *__restrict__ y2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char conv12_raw[];
+    Conv12Lds &S = *reinterpret_cast<Conv12Lds *>(conv12_raw);
+    // no look at the done flags: a finished member still in the list (until the next compaction, at most 15 lock-steps) costs a
+    // few idle CUs; a dependent global load in front of everything else costs every lock-step a microsecond
+    if (A.tt.n > 0) {
+        const Item it = decode_item<true>(A, blockIdx.x >> 2, list, gsize, 1, 0, stacks, nullptr, nullptr);
+        conv12t_body<HAS_BN, true>(S, A, it, blockIdx.x & 3, y1, y2);
+    } else {
+        const Item it = decode_item(A, blockIdx.x >> 2, list, gsize, 1, 0, stacks, nullptr, nullptr);
+        conv12t_body<HAS_BN, false>(S, A, it, blockIdx.x & 3, y1, y2);
+    }
+}
+
 // ------------------------------------------------------------------------- fc (+ out + argmax)
 // The HBM-bound kernel: streams the 3872x256 noise slice once per workgroup.  4 waves = the 4 k-slices;
 // lane l owns output columns 4l..4l+3 (one 16-byte load per lane per row = 1 KiB per wave-instruction).
@@ -2002,6 +2158,7 @@ __device__ __forceinline__ void fc_tail_body(TailFcLds<NV> &S, const FwdArgs &A,
         for (int v = 0; v < NV; v++) all_done = all_done && A.done[member[v]] != 0;
         if (all_done) return;
     }
+    DNE_PHASE(2, 0);
     const int kbeg = 968 * sl;
     const int beg = wv == 0 ? 0 : FC_SUB0 + FC_SUBN * (wv - 1);     // this wave's sub-slice within the quarter
     const int ng = (wv == 0 ? FC_SUB0 : FC_SUBN) / 4;               // its 4-row groups: 32 or 30
@@ -2043,6 +2200,7 @@ __device__ __forceinline__ void fc_tail_body(TailFcLds<NV> &S, const FwdArgs &A,
             }
         }
     __syncthreads();
+    DNE_PHASE(2, 1);
     float acc[NV][4];
 #pragma unroll
     for (int v = 0; v < NV; v++)
@@ -2135,7 +2293,9 @@ __device__ __forceinline__ void fc_tail_body(TailFcLds<NV> &S, const FwdArgs &A,
 #pragma unroll
             for (int q = 0; q < 4; q++) S.comb[wv][v][c4 * 4 + q] = acc[v][q];
     }
+    DNE_PHASE(2, 2);
     __syncthreads();
+    DNE_PHASE(2, 3);
     if (tid < NV * 64) {   // the quarter's left fold over its eight sub-slices
         const int v = tid >> 6, col = tid & 63;
         float f = S.comb[0][v][col];
@@ -2143,6 +2303,7 @@ __device__ __forceinline__ void fc_tail_body(TailFcLds<NV> &S, const FwdArgs &A,
         for (int i = 1; i < 8; i++) f = f + S.comb[i][v][col];
         y3t[((size_t)(first.member + v) * 4 + sl) * 256 + cb * 64 + col] = f;
     }
+    DNE_PHASE(2, 4);
 }
 
 template <int NV, bool HAS_BN, bool NOISE = true>

@@ -165,6 +165,9 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
     {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0", "DNE_FC_TAILK_MAX": "0"},   # k_fc_cols (4 workgroups per pair, the form for > 32 pairs per window) at every count
     {"DNE_SPEC_MAX": "8"},                                              # speculative tail from four pairs on (round 2's default; now two)
     {"DNE_RENDER_BANDS": "1"},                                          # k_fc_tail + tail step rendering in place
+    {"DNE_SPEC_MAX": "0", "DNE_CONV12T_MAX": "0"},                      # the tail's convolutions as two launches (k_conv1 over 7, k_conv2 over 4 workgroups per member) instead of k_conv12t
+    {"DNE_SPEC_MAX": "0", "DNE_CONV12T_MAX": "0", "DNE_TAIL_TABLE": "0"},
+    {"DNE_SPEC_MAX": "0", "DNE_CONV12T_MAX": "100000", "DNE_CONV_FUSED": "0"},   # k_conv12t at every count
     {"DNE_CONV1_FPW": "1"},                                             # reference-pass conv1 with one frame per workgroup (default 8)
     {"DNE_CONV1_FPW": "4"},
     {"DNE_CONV1_SHARED": "0"},                                          # reference-pass conv1 per member (k_conv1_ref<8>) instead of the shared float image
@@ -326,6 +329,7 @@ def test_reference_batch_sizes(nref, members, oracle, small_noise):
     {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0", "DNE_FC_TAILK_MAX": "0"},                           # k_fc_cols<1>
     {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0"},                                                    # k_fc_tail<1> (noise-free form: children written out)
     {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "64"},                                                   # k_fc_quad<1>
+    {"DNE_SPEC_MAX": "0", "DNE_CONV12T_MAX": "0"},                                                    # k_conv1 + k_conv2 in the tail instead of k_conv12t<false>
 ])
 def test_ga_step_kernel_variants_are_bit_exact(knobs, oracle, small_noise, monkeypatch):
     """the GA evaluation (single members, one base vector per parent, final-RAM behaviour characterisation) through the kernel
