@@ -576,7 +576,8 @@ struct dne_handle {
     int spec_bands = 7;              // DNE_SPEC_BANDS: 256-thread workgroups per candidate frame
     int spec_conv1 = 1;              // DNE_SPEC_CONV1: conv1 of every candidate stack in the launch that picks the action
     bool uniform_base = false;       // every member perturbs base slot 0 (set by dne_es_eval, cleared by dne_set_members)
-    int render_bands = 4, band_threads = 512;   // tail: workgroups per frame (DNE_RENDER_BANDS, 1 = render inside k_tail_step) and their size
+    int render_bands = 8, band_threads = 512;   // tail: workgroups per frame (DNE_RENDER_BANDS, 1 = render inside k_tail_step) and their size
+    int render_wg_max = 512;         // ... halved until members x bands fits this many workgroups (DNE_RENDER_WG_MAX)
     int tail_fused_max = 200;        // up to this many active groups (all windows) k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
     int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_rb = 4, fc_chain_min = 1 << 30;
     int fc_tailk_max = 32;           // DNE_FC_TAILK_MAX: up to this many groups per window k_fc_tail (16 workgroups per group), above it k_fc_cols (4 lean ones)
@@ -957,7 +958,8 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_OUT_LDS_KB", 0, 64, &h->out_lds_kb);
     env_int("DNE_FC_DUO_GA", 0, 1, &h->fc_duo_ga);
     env_int("DNE_FC_DUO_MIN", 2, 1 << 30, &h->fc_duo_min);
-    env_int("DNE_RENDER_BANDS", 1, 12, &h->render_bands);
+    env_int("DNE_RENDER_BANDS", 1, 84, &h->render_bands);
+    env_int("DNE_RENDER_WG_MAX", 1, 1 << 20, &h->render_wg_max);
     env_int("DNE_FC_CHAIN_MIN", 1, 1 << 30, &h->fc_chain_min);
     env_int("DNE_FC_RB", 2, 8, &h->fc_rb);
     env_int("DNE_FC_GRID", 1, 1 << 16, &h->fc_grid);
@@ -1759,10 +1761,12 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 E.step_counter = pe ? h->launch_units + evs.size() : nullptr;
                 if (tail) {
                     const FwdArgs A = h->fwd(false);
-                    const int items = cnt * gsize, nb = h->render_bands;
+                    const int items = cnt * gsize;
+                    int nb = h->render_bands;
+                    while (nb > 1 && items * nb > h->render_wg_max) nb /= 2;
 #define TS(BN, R, THR) hipLaunchKernelGGL((k_tail_step<BN, R>), dim3(items), dim3(THR), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action)
                     const bool es = h->L.kind == DNE_KIND_ES;
-                    if (nb > 1 && items * nb <= 512) {   // few members left: policy head + emulator, then each frame over nb workgroups
+                    if (nb > 1) {   // few members left: policy head + emulator, then each frame over nb workgroups
                         if (es) TS(true, false, h->head_threads); else TS(false, false, h->head_threads);
                         hipLaunchKernelGGL(k_env_render, dim3(items * nb), dim3(h->band_threads), 0, sst, E, lst, gsize, 0, nb);
                     } else if (es) TS(true, true, 1024); else TS(false, true, 1024);

@@ -4,7 +4,8 @@
 #   baselines) and the default command; rocprofv3 kernel stats of the default command; the HBM-traffic PMC passes per regime
 #   (tools/collect_pmc_regimes.sh: FETCH_SIZE / WRITE_SIZE, each in its own run, kernel-trace only); the matrix-core PMC pass
 #   (tools/collect_pmc_mfma.sh); the env-free micro-benchmarks; population shares (what a rank sees at N = 2 / 4 / 8); lock-step
-#   length profiles; tail latency at fixed width + its per-kernel durations; the Deep-GA lock-step profiles.
+#   length profiles; tail latency at fixed width + its per-kernel durations, launch timeline and in-kernel phase clock; the
+#   reference pass alone (chunked and as one chunk under rocprofv3); the launch floor; the Deep-GA lock-step profiles.
 # Outputs land in gpurun_out/<tag>/; `python tools/refresh_profiles.py gpurun_out/<tag> r03` copies the summaries into profiles/.
 set -u
 TAG=${1:-r03p}
@@ -23,6 +24,13 @@ python "$R/tools/len_profile.py" --pairs 312 > "$O/len_profile_312.json" 2>/dev/
 python "$R/tools/len_profile.py" --pairs 2500 > "$O/len_profile_2500.json" 2>/dev/null
 python "$R/tools/tail_bench.py" > "$O/tail_bench.json" 2>/dev/null
 bash "$R/tools/tail_stats.sh" "$TAG" 1 8 24 > "$O/tail_stats.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$O/tl8" -o t -- python "$R/tools/tail_bench.py" 8 --steps 208 > /dev/null 2>&1
+python "$R/tools/tail_timeline.py" "$O/tl8" > "$O/tail_timeline_8.json" 2>/dev/null; rm -rf "$O/tl8"
+for p in 8 24; do DNE_LIB_PATH=$R/deep-neuroevolution_amd/csrc/libdne_hip_clock.so python "$R/tools/phase_clock.py" $p > "$O/phase_clock_$p.json" 2>/dev/null; done
+python "$R/tools/ref_bench.py" > "$O/ref_bench.json" 2>/dev/null
+REF_CHUNK=5000 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ref_alone" -o r -- python "$R/tools/ref_bench.py" > "$O/ref_bench_one_chunk.json" 2>/dev/null
+cp "$(find "$O/ref_alone" -name '*kernel_stats.csv' | head -1)" "$O/ref_pass_one_chunk_kernel_stats.csv" 2>/dev/null; rm -rf "$O/ref_alone"
+"$R/tools/micro/launch_floor" > "$O/launch_floor.jsonl" 2>/dev/null
 python "$R/tools/ga_lockstep_profile.py" > "$O/ga_lockstep_profile.json" 2> "$O/ga_lockstep_profile.err"
 python "$R/tools/ga_lockstep_profile.py" --large > "$O/ga_large_lockstep_profile.json" 2> "$O/ga_large_lockstep_profile.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ga_large_stats" -o g -- python "$R/tools/ga_bench.py" --large > /dev/null 2>&1

@@ -25,7 +25,11 @@ for src, dst in (('bench_default.json', 'bench_default.json'), ('bench_driver_cm
                  ('ga_large_bench.jsonl', 'ga_large_bench.jsonl'), ('ga_large_kernel_stats.csv', 'ga_large_kernel_stats.csv'),
                  ('six_game_sweep.jsonl', 'six_game_sweep.jsonl'), ('ga_lockstep_profile.json', 'ga_lockstep_profile.json'),
                  ('ga_large_lockstep_profile.json', 'ga_large_lockstep_profile.json'), ('ga_kernel_stats.csv', 'ga_kernel_stats.csv'),
-                 ('tail_stats_1.csv', 'tail_stats_1_pair.csv'), ('tail_stats_8.csv', 'tail_stats_8_pairs.csv'), ('tail_stats_24.csv', 'tail_stats_24_pairs.csv')):
+                 ('tail_stats_1.csv', 'tail_stats_1_pair.csv'), ('tail_stats_8.csv', 'tail_stats_8_pairs.csv'), ('tail_stats_24.csv', 'tail_stats_24_pairs.csv'),
+                 ('tail_timeline_8.json', 'tail_timeline_8_pairs.json'), ('phase_clock_8.json', 'tail_phase_clock_8_pairs.json'),
+                 ('phase_clock_24.json', 'tail_phase_clock_24_pairs.json'), ('ref_bench.json', 'ref_pass.json'),
+                 ('ref_bench_one_chunk.json', 'ref_pass_one_chunk.json'), ('ref_pass_one_chunk_kernel_stats.csv', 'ref_pass_one_chunk_kernel_stats.csv'),
+                 ('launch_floor.jsonl', 'launch_floor.jsonl')):
     if os.path.exists(os.path.join(R, src)):
         shutil.copy(os.path.join(R, src), os.path.join(P, '%s_%s' % (PFX, dst)))
 ks = glob.glob(R + '/stats/**/*kernel_stats.csv', recursive=True)
