@@ -1552,10 +1552,19 @@ __device__ __forceinline__ void wait_rows(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d
     asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : [n] "n"(N));
 }
 
-template <int NV, bool HAS_BN>
+// SWEEP (round 3): the four waves of a workgroup hold four ADJACENT duos of the table order -- eight units whose slices overlap --
+// but started together each wave reads a given table row ~24 row blocks (~100 us) after its neighbour did, long after the line has
+// left every cache.  Here the workgroup walks ONE table timeline: the wave with the lowest table address starts, the others join
+// when the front reaches their unit's first row (a wave-uniform count of s_barrier, no fence: the rolling loads stay in flight), and
+// one s_barrier per row block keeps the four in table lock-step, so that all eight units ask for a table row within the same few
+// loads and HBM delivers it once.  A schedule, not arithmetic: same chains, same bits.
+template <int NV, bool HAS_BN, bool SWEEP = false>
 __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict__ order, int n_units,
                                                 const float *__restrict__ y2, float *__restrict__ y3t, int lag) {
     constexpr int W = 8;                          // rows in flight per stream
+    __shared__ long long sw_key[2][4];            // SWEEP: the waves' first table addresses / row-block counts, double-buffered by item parity
+    __shared__ int sw_len[2][4];
+    int sw_par = 0;
     constexpr int NBLK = 968 / W, BPC = 64 / W;   // row blocks per unit, per 64-row activation chunk
     const int tid = threadIdx.x, wv = uni(tid >> 6), lane = tid & 63;
     const unsigned voff = lane * 16;
@@ -1572,9 +1581,10 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
     typedef DuoSide<NV> Side;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int d = item * 4 + wv;
-        if (d >= n_duos) continue;
-        int uA = uni(order[solo ? d : 2 * d]), uB = !solo && 2 * d + 1 < n_units ? uni(order[2 * d + 1]) : -1;
-        if (A.done) {
+        if (!SWEEP && d >= n_duos) continue;
+        const bool in_range = d < n_duos;
+        int uA = in_range ? uni(order[solo ? d : 2 * d]) : -1, uB = in_range && !solo && 2 * d + 1 < n_units ? uni(order[2 * d + 1]) : -1;
+        if (A.done && in_range) {
             auto finished = [&](int uu) {
                 int all_done = 1;
 #pragma unroll
@@ -1585,7 +1595,12 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
             if (uB >= 0 && finished(uB)) uB = -1;
         }
         if (uA < 0) { uA = uB; uB = -1; }
-        if (uA < 0) continue;
+        bool has = true;
+        if (uA < 0) {
+            if (!SWEEP) continue;
+            has = false;      // SWEEP: a wave without work still takes part in the workgroup's barriers
+            uA = uni(order[0]);
+        }
         const bool b_on = uB >= 0;
         if (!b_on) uB = uA;   // valid addresses for the side that is never computed or stored
 
@@ -1620,6 +1635,41 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
         if (b_on) {
             const long long delta = SB.key - SA.key;
             gb = delta < 0 ? 0 : (int)min((long long)NBLK, delta / (256 * W) + lag);
+        }
+
+        int sw_tail = 0;
+        if constexpr (SWEEP) {
+            const int par = sw_par;
+            sw_par ^= 1;
+            const int len = !has ? 0 : b_on ? NBLK + gb : NBLK;
+            if (lane == 0) { sw_key[par][wv] = SA.key; sw_len[par][wv] = len; }
+            __syncthreads();
+            // the waves' keys ascend with the wave index (table order); a wave starts when the front reaches its first row, unless its
+            // predecessor is a whole unit away (nothing to share: no point in waiting)
+            int delay = 0, mine = 0, tmax = 0;
+            long long prev = 0;
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const long long kj = sw_key[par][j];
+                const int lj = sw_len[par][j];
+                if (lj == 0) continue;
+                if (any) {
+                    const long long gap = (kj - prev) / (256 * W);
+                    delay += gap > 0 && gap < NBLK ? (int)gap : 0;
+                }
+                any = true;
+                prev = kj;
+                if (j == wv) mine = delay;
+                tmax = max(tmax, delay + lj);
+            }
+            mine = uni(mine); tmax = uni(tmax);
+            if (!has) {
+                for (int i = 0; i < tmax; i++) __builtin_amdgcn_s_barrier();
+                continue;
+            }
+            for (int i = 0; i < mine; i++) __builtin_amdgcn_s_barrier();
+            sw_tail = tmax - mine - len;
         }
 
         // activations: chunk c = rows 64c .. 64c+63 of the unit's slice, one row per lane.  The raw values of chunk c + 1 are
@@ -1747,6 +1797,7 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
                 one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
                 if (DA) end_block(SA);
                 if (DB) end_block(SB);
+                if constexpr (SWEEP) __builtin_amdgcn_s_barrier();   // the workgroup's four waves advance one row block at a time
             }
         };
         request_x(SA, 0);
@@ -1773,6 +1824,8 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
         };
         store(SA);
         if (b_on) store(SB);
+        if constexpr (SWEEP)
+            for (int i = 0; i < sw_tail; i++) __builtin_amdgcn_s_barrier();
     }
 }
 
