@@ -564,6 +564,7 @@ struct dne_handle {
     int fc_duo_ga = 0;               // DNE_FC_DUO_GA: the table-ordered fc for GA evaluations too (single members, one base vector per parent); measured slower, off
     int fcref_mt8 = 0;               // DNE_FCREF_MT8
     int conv2_ref_fpw = 8;           // DNE_CONV2_REF_FPW: reference frames per conv2 workgroup (8, 4, or 1 = the lock-step kernel)
+    int duo_sync = 1;                // DNE_DUO_SYNC: row blocks per barrier of the sweep (1-8)
     int duo_sweep = 2;               // DNE_DUO_SWEEP (0 = off): the four waves of a k_fc_duo workgroup walk one table timeline (1: two units per wave only, 2: also one unit per wave)
     int fc_prio = 3;                 // DNE_FC_PRIO: s_setprio of k_fc_duo's waves (0-3)
     int duo_lag = 0;                 // DNE_DUO_LAG: extra row batches by which the second unit of a duo trails the first
@@ -580,6 +581,7 @@ struct dne_handle {
     int render_bands = 8, band_threads = 512;   // tail: workgroups per frame (DNE_RENDER_BANDS, 1 = render inside k_tail_step) and their size
     int render_wg_max = 512;         // ... halved until members x bands fits this many workgroups (DNE_RENDER_WG_MAX)
     int tail_fused_max = 200;        // up to this many active groups (all windows) k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
+    int nsub_full = 4;               // DNE_NSUB_FULL: windows at full width (>= 1900 active groups)
     int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_rb = 4, fc_chain_min = 1 << 30;
     int fc_tailk_max = 32;           // DNE_FC_TAILK_MAX: up to this many groups per window k_fc_tail (16 workgroups per group), above it k_fc_cols (4 lean ones)
     int fc_quad_max = 4;             // DNE_FC_QUAD_MAX: up to this many groups per window the 64-workgroups-per-group fc (k_fc_quad); above it k_fc_tail
@@ -930,6 +932,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipFuncSetAttribute((const void *)k_out<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     CH(hipFuncSetAttribute((const void *)k_out<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
+    env_int("DNE_NSUB_FULL", 1, 4, &h->nsub_full);
     env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
     env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
     env_int("DNE_FC_TAILK_MAX", 0, 1 << 20, &h->fc_tailk_max);
@@ -953,6 +956,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_DUO_LAG", 0, 64, &h->duo_lag);
     env_int("DNE_FC_PRIO", 0, 3, &h->fc_prio);
     env_int("DNE_DUO_SWEEP", 0, 2, &h->duo_sweep);
+    env_int("DNE_DUO_SYNC", 1, 8, &h->duo_sync);
     env_int("DNE_FCREF_MT8", 0, 1, &h->fcref_mt8);
     env_int("DNE_CONV2_REF_FPW", 1, 8, &h->conv2_ref_fpw);
     env_int("DNE_DUO_SOLO_BELOW", 0, 1 << 30, &h->duo_solo_below);
@@ -1543,10 +1547,10 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 3) / 4, blocks = std::min(items, h->fc_grid);
         const size_t out_lds = (size_t)h->out_lds_kb * 1024;   // an LDS reservation nobody uses: it only bounds k_out's workgroups per CU next to the streaming fc
         const bool sweep = h->duo_sweep && (!solo || h->duo_sweep > 1);
-        if (es && sweep) hipLaunchKernelGGL((k_fc_duo<2, true, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9));
-        else if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9));
-        else if (sweep) hipLaunchKernelGGL((k_fc_duo<1, false, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9));
-        else hipLaunchKernelGGL((k_fc_duo<1, false>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9));
+        if (es && sweep) hipLaunchKernelGGL((k_fc_duo<2, true, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11));
+        else if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11));
+        else if (sweep) hipLaunchKernelGGL((k_fc_duo<1, false, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11));
+        else hipLaunchKernelGGL((k_fc_duo<1, false>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11));
         if (after_stream_kernel) hipEventRecord(after_stream_kernel, st);
         if (out_fused) return;   // the caller runs k_tail_step: policy head + emulator step in one launch
         if (es) hipLaunchKernelGGL((k_out<2, true>), dim3(count), dim3(256), out_lds, st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
@@ -1648,7 +1652,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     auto pick_nsub = [&](int total) {
         // measured (tools/kbench.py sweeps): k_fc2 wants 3 windows at full width and 4 in the upper mid range; below
         // ~400 groups the windows are sized to fit the column-split tail kernels (<= fc_tail_max groups each)
-        int k = total >= 1900 ? 3 : total >= h->fc2_min_total ? 4 : total > 4 * h->fc_tail_max ? 3
+        int k = total >= 1900 ? h->nsub_full : total >= h->fc2_min_total ? 4 : total > 4 * h->fc_tail_max ? 3
               : total >= 48 ? std::max(2, (total + h->fc_tail_max - 1) / h->fc_tail_max) : 1;
         if (h->nsub_fixed > 0) k = h->nsub_fixed;
         k = std::min(k, (int)h->sub_streams.size());

@@ -1576,6 +1576,12 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
         else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     }
     const bool solo = (lag & 256) != 0;   // sparse windows: one unit per wave (twice the waves, nothing to share anyway)
+    const int sw_sync = ((lag >> 11) & 7) + 1;   // SWEEP: one s_barrier every sw_sync row blocks of the workgroup's timeline
+    int sw_t = 0;                                // SWEEP: the workgroup's time in row blocks (the same sequence in every wave)
+    auto sw_tick = [&]() {
+        sw_t++;
+        if (sw_sync == 1 || sw_t % sw_sync == 0) __builtin_amdgcn_s_barrier();
+    };
     lag &= 255;
     const int n_duos = solo ? n_units : (n_units + 1) >> 1, n_items = (n_duos + 3) >> 2;
     typedef DuoSide<NV> Side;
@@ -1665,10 +1671,10 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
             }
             mine = uni(mine); tmax = uni(tmax);
             if (!has) {
-                for (int i = 0; i < tmax; i++) __builtin_amdgcn_s_barrier();
+                for (int i = 0; i < tmax; i++) sw_tick();
                 continue;
             }
-            for (int i = 0; i < mine; i++) __builtin_amdgcn_s_barrier();
+            for (int i = 0; i < mine; i++) sw_tick();
             sw_tail = tmax - mine - len;
         }
 
@@ -1797,7 +1803,7 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
                 one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
                 if (DA) end_block(SA);
                 if (DB) end_block(SB);
-                if constexpr (SWEEP) __builtin_amdgcn_s_barrier();   // the workgroup's four waves advance one row block at a time
+                if constexpr (SWEEP) sw_tick();   // the workgroup's four waves advance one row block at a time
             }
         };
         request_x(SA, 0);
@@ -1825,7 +1831,7 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
         store(SA);
         if (b_on) store(SB);
         if constexpr (SWEEP)
-            for (int i = 0; i < sw_tail; i++) __builtin_amdgcn_s_barrier();
+            for (int i = 0; i < sw_tail; i++) sw_tick();
     }
 }
 
