@@ -1564,6 +1564,7 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
     constexpr int W = 8;                          // rows in flight per stream
     __shared__ long long sw_key[2][4];            // SWEEP: the waves' first table addresses / row-block counts, double-buffered by item parity
     __shared__ int sw_len[2][4];
+    __shared__ int sw_plan[2][4][4][2];           // SWEEP: [parity][wave][round] -> the duo's units (A, B or -1)
     int sw_par = 0;
     constexpr int NBLK = 968 / W, BPC = 64 / W;   // row blocks per unit, per 64-row activation chunk
     const int tid = threadIdx.x, wv = uni(tid >> 6), lane = tid & 63;
@@ -1582,14 +1583,15 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
         sw_t++;
         if (sw_sync == 1 || sw_t % sw_sync == 0) __builtin_amdgcn_s_barrier();
     };
+    const int rounds = SWEEP ? ((lag >> 14) & 3) + 1 : 1;   // SWEEP: duos a wave takes one after the other on the workgroup's timeline
     lag &= 255;
-    const int n_duos = solo ? n_units : (n_units + 1) >> 1, n_items = (n_duos + 3) >> 2;
+    const int n_duos = solo ? n_units : (n_units + 1) >> 1, n_items = (n_duos + 4 * rounds - 1) / (4 * rounds);
     typedef DuoSide<NV> Side;
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const int d = item * 4 + wv;
-        if (!SWEEP && d >= n_duos) continue;
+    // the units of duo d: finished groups dropped, a lone survivor runs as side A; false when there is nothing to do
+    auto select = [&](int d, int &uA, int &uB) {
         const bool in_range = d < n_duos;
-        int uA = in_range ? uni(order[solo ? d : 2 * d]) : -1, uB = in_range && !solo && 2 * d + 1 < n_units ? uni(order[2 * d + 1]) : -1;
+        uA = in_range ? uni(order[solo ? d : 2 * d]) : -1;
+        uB = in_range && !solo && 2 * d + 1 < n_units ? uni(order[2 * d + 1]) : -1;
         if (A.done && in_range) {
             auto finished = [&](int uu) {
                 int all_done = 1;
@@ -1601,11 +1603,68 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
             if (uB >= 0 && finished(uB)) uB = -1;
         }
         if (uA < 0) { uA = uB; uB = -1; }
-        bool has = true;
-        if (uA < 0) {
-            if (!SWEEP) continue;
-            has = false;      // SWEEP: a wave without work still takes part in the workgroup's barriers
-            uA = uni(order[0]);
+        return uA >= 0;
+    };
+    auto unit_key = [&](int uu) { return uni64(A.m_off[(size_t)(uu >> 2) * NV]) + (long long)(uu & 3) * SLICE_FLOATS; };
+    auto duo_gb = [&](int uA, int uB) {   // B trails A by gb row blocks: its row (blk - gb) * W + i then sits within W rows of A's row blk * W + i in the table
+        if (uB < 0) return NBLK;
+        const long long delta = unit_key(uB) - unit_key(uA);
+        return delta < 0 ? 0 : (int)min((long long)NBLK, delta / (256 * W) + lag);
+    };
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        int sw_tail = 0;
+        if constexpr (SWEEP) {
+            // plan: the wave's duos of this item (round r: duo (item * rounds + r) * 4 + wave), their lengths in row blocks, the table
+            // address the wave starts at
+            const int par = sw_par;
+            sw_par ^= 1;
+            int total = 0;
+            long long first_key = 0;
+            for (int r = 0; r < rounds; r++) {
+                int pa, pb;
+                const bool ok = select((item * rounds + r) * 4 + wv, pa, pb);
+                const int len = !ok ? 0 : pb >= 0 ? NBLK + duo_gb(pa, pb) : NBLK;
+                if (ok && total == 0) first_key = unit_key(pa);
+                total += len;
+                if (lane == 0) { sw_plan[par][wv][r][0] = ok ? pa : -1; sw_plan[par][wv][r][1] = pb; }
+            }
+            if (lane == 0) { sw_key[par][wv] = first_key; sw_len[par][wv] = total; }
+            __syncthreads();
+            // the waves' keys ascend with the wave index (table order); a wave starts when the front reaches its first row, unless its
+            // predecessor is a whole unit away (nothing to share: no point in waiting)
+            int delay = 0, mine = 0, tmax = 0;
+            long long prev = 0;
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const long long kj = sw_key[par][j];
+                const int lj = sw_len[par][j];
+                if (lj == 0) continue;
+                if (any) {
+                    const long long gap = (kj - prev) / (256 * W);
+                    delay += gap > 0 && gap < NBLK ? (int)gap : 0;
+                }
+                any = true;
+                prev = kj;
+                if (j == wv) mine = delay;
+                tmax = max(tmax, delay + lj);
+            }
+            mine = uni(mine); tmax = uni(tmax);
+            if (total == 0) {      // a wave without work still takes part in the workgroup's barriers
+                for (int i = 0; i < tmax; i++) sw_tick();
+                continue;
+            }
+            for (int i = 0; i < mine; i++) sw_tick();
+            sw_tail = tmax - mine - total;
+        }
+        for (int rnd = 0; rnd < rounds; rnd++) {
+        int uA, uB;
+        if constexpr (SWEEP) {
+            uA = uni(sw_plan[(sw_par ^ 1)][wv][rnd][0]);
+            uB = uni(sw_plan[(sw_par ^ 1)][wv][rnd][1]);
+            if (uA < 0) continue;
+        } else {
+            if (!select(item * 4 + wv, uA, uB)) continue;
         }
         const bool b_on = uB >= 0;
         if (!b_on) uB = uA;   // valid addresses for the side that is never computed or stored
@@ -1636,47 +1695,7 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
         };
         init(SA, uA);
         init(SB, uB);
-        // B trails A by gb row blocks: its row (blk - gb) * W + i then sits within W rows of A's row blk * W + i in the table
-        int gb = NBLK;
-        if (b_on) {
-            const long long delta = SB.key - SA.key;
-            gb = delta < 0 ? 0 : (int)min((long long)NBLK, delta / (256 * W) + lag);
-        }
-
-        int sw_tail = 0;
-        if constexpr (SWEEP) {
-            const int par = sw_par;
-            sw_par ^= 1;
-            const int len = !has ? 0 : b_on ? NBLK + gb : NBLK;
-            if (lane == 0) { sw_key[par][wv] = SA.key; sw_len[par][wv] = len; }
-            __syncthreads();
-            // the waves' keys ascend with the wave index (table order); a wave starts when the front reaches its first row, unless its
-            // predecessor is a whole unit away (nothing to share: no point in waiting)
-            int delay = 0, mine = 0, tmax = 0;
-            long long prev = 0;
-            bool any = false;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const long long kj = sw_key[par][j];
-                const int lj = sw_len[par][j];
-                if (lj == 0) continue;
-                if (any) {
-                    const long long gap = (kj - prev) / (256 * W);
-                    delay += gap > 0 && gap < NBLK ? (int)gap : 0;
-                }
-                any = true;
-                prev = kj;
-                if (j == wv) mine = delay;
-                tmax = max(tmax, delay + lj);
-            }
-            mine = uni(mine); tmax = uni(tmax);
-            if (!has) {
-                for (int i = 0; i < tmax; i++) sw_tick();
-                continue;
-            }
-            for (int i = 0; i < mine; i++) sw_tick();
-            sw_tail = tmax - mine - len;
-        }
+        const int gb = duo_gb(uA, b_on ? uB : -1);
 
         // activations: chunk c = rows 64c .. 64c+63 of the unit's slice, one row per lane.  The raw values of chunk c + 1 are
         // requested (asm, like the weight rows) when chunk c starts and turned into relu(bn2(.)) eight row blocks later, long
@@ -1830,6 +1849,7 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
         };
         store(SA);
         if (b_on) store(SB);
+        }   // rounds
         if constexpr (SWEEP)
             for (int i = 0; i < sw_tail; i++) sw_tick();
     }
