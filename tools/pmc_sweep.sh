@@ -1,3 +1,6 @@
+#!/bin/bash
+# FETCH_SIZE of k_fc_duo at full width (2500 pairs; 1 and 3 windows) with and without the workgroup's table timeline
+# (DNE_DUO_SWEEP): one rocprofv3 --pmc pass each, kernel trace only.   gpurun -- 'bash tools/pmc_sweep.sh'
 R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 for m in 0 1; do for ns in 1 3; do
 DNE_DUO_SWEEP=$m DNE_NSUB=$ns rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/ps_$m_$ns -o kb -- python $R/tools/kbench.py --pairs 2500 --reps 1 --tslimit 6 > /dev/null 2>&1

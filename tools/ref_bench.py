@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""The reference pass of 5000 members (virtual batch norm: 128 reference frames through every member's perturbed network)
+alone: ms per pass, mean of three.  REF_CHUNK=5000 runs it as ONE chunk (the kernels then do not overlap: under rocprofv3 their
+durations are their own); default = the product path (chunks of 512 members alternating between two streams).
+    python tools/ref_bench.py;  REF_CHUNK=5000 rocprofv3 --kernel-trace --stats -- python tools/ref_bench.py"""
 import json, os, sys, time
 import numpy as np
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
