@@ -4,7 +4,8 @@
 # nobody dies within 6 steps).  Counter collection serialises the dispatches: a launch is measured with the chip to itself.
 #   regime               pairs  windows   units per launch (member-steps)
 #   full_1window          2500     1       5000    two units per wave (table-ordered duos)
-#   full_3windows         2500     3       1667    the bench's first lock-steps (>= 1900 active pairs)
+#   full_3windows         2500     3       1667    round 2's shape of the first lock-steps
+#   full_4windows         2500     4       1250    the bench's first lock-steps (>= 1900 active pairs) since the sweep
 #   half_4windows         1250     4        625    one unit per wave (below 1500 active pairs)
 #   third_4windows         800     4        400    the lower end of the streaming regime
 # tools/summarize_pmc_regimes.py gpurun_out/<tag>/pmc_regimes rNN  ->  profiles/rNN_pmc.json
@@ -34,6 +35,7 @@ PY
 }
 run full_1window 2500 1
 run full_3windows 2500 3
+run full_4windows 2500 4
 run half_4windows 1250 4
 run third_4windows 800 4
 ls "$O"

@@ -9,7 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "deep-neuroevolution_amd"))
 D, PFX = sys.argv[1], sys.argv[2]
-REGIMES = [("full_1window", 2500, 1), ("full_3windows", 2500, 3), ("half_4windows", 1250, 4), ("third_4windows", 800, 4)]
+REGIMES = [("full_1window", 2500, 1), ("full_3windows", 2500, 3), ("full_4windows", 2500, 4), ("half_4windows", 1250, 4), ("third_4windows", 800, 4)]
 P, FCW, FC_FLOATS, NOISE = 1009058, 12432, 3872 * 256, 250_000_000
 
 
