@@ -582,6 +582,7 @@ struct dne_handle {
     int render_bands = 8, band_threads = 512;   // tail: workgroups per frame (DNE_RENDER_BANDS, 1 = render inside k_tail_step) and their size
     int render_wg_max = 512;         // ... halved until members x bands fits this many workgroups (DNE_RENDER_WG_MAX)
     int tail_fused_max = 200;        // up to this many active groups (all windows) k_out + k_env_logic + k_env_render run as one kernel (DNE_TAIL_FUSED_MAX)
+    int nsub_mid = 4;                // DNE_NSUB_MID: windows between 800 and 1899 active groups
     int nsub_full = 4;               // DNE_NSUB_FULL: windows at full width (>= 1900 active groups)
     int nsub_fixed = 0, fc_grid = 512, fc_tail_max = 96, fc_rb = 4, fc_chain_min = 1 << 30;
     int fc_tailk_max = 32;           // DNE_FC_TAILK_MAX: up to this many groups per window k_fc_tail (16 workgroups per group), above it k_fc_cols (4 lean ones)
@@ -934,6 +935,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipFuncSetAttribute((const void *)k_out<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
     env_int("DNE_NSUB_FULL", 1, 4, &h->nsub_full);
+    env_int("DNE_NSUB_MID", 1, 4, &h->nsub_mid);
     env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
     env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
     env_int("DNE_FC_TAILK_MAX", 0, 1 << 20, &h->fc_tailk_max);
@@ -971,7 +973,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_CHAIN_MIN", 1, 1 << 30, &h->fc_chain_min);
     env_int("DNE_FC_RB", 2, 8, &h->fc_rb);
     env_int("DNE_FC_GRID", 1, 1 << 16, &h->fc_grid);
-    for (int s = 1; s < 4; s++) { hipStream_t st; CH(hipStreamCreate(&st)); h->sub_streams.push_back(st); }
+    for (int s = 1; s < 4; s++) { hipStream_t st; CH(hipStreamCreate(&st)); h->sub_streams.push_back(st); }   // more than four windows measured slower (5 / 6 / 8 at full width: +7.5 / +5.4 / +7.2 %)
     make_layout(cfg->policy_kind, cfg->n_actions, &h->L);
     h->M = cfg->max_members;
     h->F = cfg->policy_kind == DNE_KIND_ES ? (cfg->ref_count > 0 ? cfg->ref_count : 128) : 0;
@@ -1655,7 +1657,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     auto pick_nsub = [&](int total) {
         // measured (tools/kbench.py sweeps): k_fc2 wants 3 windows at full width and 4 in the upper mid range; below
         // ~400 groups the windows are sized to fit the column-split tail kernels (<= fc_tail_max groups each)
-        int k = total >= 1900 ? h->nsub_full : total >= h->fc2_min_total ? 4 : total > 4 * h->fc_tail_max ? 3
+        int k = total >= 1900 ? h->nsub_full : total >= h->fc2_min_total ? h->nsub_mid : total > 4 * h->fc_tail_max ? 3
               : total >= 48 ? std::max(2, (total + h->fc_tail_max - 1) / h->fc_tail_max) : 1;
         if (h->nsub_fixed > 0) k = h->nsub_fixed;
         k = std::min(k, (int)h->sub_streams.size());
