@@ -1530,21 +1530,28 @@ __device__ __forceinline__ long long uni64(long long v) {
 // 16 bytes per lane from (uniform base + per-lane byte offset + OFF); the result lands asynchronously: read it only through
 // wait_rows.  Written as asm so that the load is issued exactly here, into the registers of the row just consumed -- the
 // compiler's own schedule hoists the loads of a row block to its top, which costs a second register set and a copy per row.
+// cache-policy experiments (same-box A/B through DNE_LIB_PATH; the product library leaves both empty): -DDNE_EPS_MOD='" nt"' etc.
+#ifndef DNE_EPS_MOD
+#define DNE_EPS_MOD ""
+#endif
+#ifndef DNE_THETA_MOD
+#define DNE_THETA_MOD ""
+#endif
 template <int OFF>
 __device__ __forceinline__ void gload4(f32x4 &dst, unsigned voff, const float *sbase) {
     // "+v": the registers of the row just consumed are the destination (its readers come first; nothing is kept alive or copied)
-    asm volatile("global_load_dwordx4 %[d], %[vo], %[sb] offset:%[of]" : [d] "+v"(dst) : [vo] "v"(voff), [sb] "s"(sbase), [of] "n"(OFF));
+    asm volatile("global_load_dwordx4 %[d], %[vo], %[sb] offset:%[of]" DNE_THETA_MOD : [d] "+v"(dst) : [vo] "v"(voff), [sb] "s"(sbase), [of] "n"(OFF));
 }
 // the same load, pinned behind the accumulator updates of the row it replaces: without the (untouched) accumulators as
 // operands the compiler sinks a whole block's arithmetic below all of its loads and keeps the old rows alive in copies
 template <int OFF>
 __device__ __forceinline__ void gload4_after(f32x4 &dst, unsigned voff, const float *sbase, f32x2 &a0, f32x2 &a1, f32x2 &a2, f32x2 &a3) {
-    asm volatile("global_load_dwordx4 %[d], %[vo], %[sb] offset:%[of]"
+    asm volatile("global_load_dwordx4 %[d], %[vo], %[sb] offset:%[of]" DNE_EPS_MOD
                  : [d] "+v"(dst), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : [vo] "v"(voff), [sb] "s"(sbase), [of] "n"(OFF));
 }
 template <int OFF>
 __device__ __forceinline__ void gload4_after(f32x4 &dst, unsigned voff, const float *sbase, f32x2 &a0, f32x2 &a1) {
-    asm volatile("global_load_dwordx4 %[d], %[vo], %[sb] offset:%[of]"
+    asm volatile("global_load_dwordx4 %[d], %[vo], %[sb] offset:%[of]" DNE_EPS_MOD
                  : [d] "+v"(dst), "+v"(a0), "+v"(a1) : [vo] "v"(voff), [sb] "s"(sbase), [of] "n"(OFF));
 }
 template <int N>
