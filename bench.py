@@ -19,14 +19,15 @@ value = sum of episode lengths over all ranks and timed generations / max-over-r
 
 After the headline region the same command times BASELINE.json's other configurations (tools/workloads.py: Deep GA on both
 networks, the NS-ES meta-population loop, the six-game loop, the 2-worker CPU reference path) and reports them under "extra",
-each with its own roofline / CPU baseline.  Default: on at N = 1, off at N > 1 (--extra all turns them on there; they then run
-sharded over the same ranks and borrow the headline engine's communicator).
+each with its own roofline / CPU baseline.  Default: all of them at N = 1; at N > 1 the sharded ones (ga, nses, sweep: BASELINE
+configs 4 and 5 are defined on 4 and 8 GPUs), run over the same ranks on the headline engine's communicator.
 
 The ranks never import torch on the RCCL path: the engine is reached through ctypes, device synchronisation is
 hipDeviceSynchronize inside the C ABI, and the exchange, the barrier and the max / sum over ranks are RCCL calls behind
 dne_comm_*.  So the HIP runtime in the process is the one libdne_hip.so was built against (/opt/rocm), the same one the GPU
-tests run on.  If the ranks cannot build an RCCL communicator they agree -- all of them, explicitly -- on carrying the same
-32-byte records over gloo instead; the JSON line says which carrier ran ("comm").
+tests run on.  If the ranks cannot build an RCCL communicator the launch FAILS (exit 3) -- unless --allow-gloo-fallback is given,
+in which case they agree, all of them and explicitly, on carrying the same 32-byte records over gloo; the JSON line says which
+carrier ran ("comm").
 
 Environment: ALE and ROMs do not exist in this image, so the emulator under wrap_deepmind is the
 Frostbite-shaped SynthAtari fixture -- stated in "data".
@@ -62,8 +63,10 @@ FC_KERNELS = {   # the kernel behind the profiled ("full") fc launches of one ev
     1: "dne::k_fc<2, false, true, 4> (streaming fc + bn + out + argmax, one pair per work item: every window with > 96 active "
        "pairs; the rank's share is too small for k_fc2)",
 }
-PMC_PROFILES = (os.path.join("profiles", "r03_pmc.json"), os.path.join("profiles", "r02_pmc.json"), os.path.join("profiles", "r01_pmc.json"))
+PMC_PROFILES = tuple(os.path.join("profiles", "r0%d_pmc.json" % r) for r in (4, 3, 2, 1))
 EXTRAS = ("ga", "ga_large", "nses", "sweep", "config1")
+EXTRAS_MULTI = ("ga", "nses", "sweep")         # default at N > 1: BASELINE configs 4 / 5 are DEFINED on 4 / 8 GPUs (ga_large, config1: one rank)
+SIMDS, SHADER_HZ = 1024, 2.4e9                 # MI355X: 256 CUs x 4 SIMDs; nominal shader clock
 
 EXP = {
     "config": {"calc_obstat_prob": 0.0, "episodes_per_batch": 5000, "eval_prob": 0.0, "l2coeff": 0.005,
@@ -96,30 +99,73 @@ def cpu_baseline(noise, theta, ref, sigma, tslimit, n_actions):
 FC_KERNEL_TAG = {3: "k_fc_duo", 2: "k_fc2", 1: "k_fc<"}
 
 
-def _pmc_traffic(kind, units_per_launch):
-    """HBM bytes per env-step of the streaming fc kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled for the
-    16-byte streaming loads as MI355X_MICROARCH.md prescribes, plus WRITE_SIZE; collected by tools/collect_profiles.sh in
-    separate --pmc runs).  Round 3's file holds several regimes (window sizes): the one whose units per launch is closest to
-    this run's is used.  It is a property of the kernel measured under the profiler, NOT a measurement of this run: bench.py
-    cannot read hardware counters in-process.  (None, None, None) if no profile is committed."""
+def _pmc_profile(kind):
+    """the newest committed PMC summary (profiles/rNN_pmc.json) that measured this run's streaming kernel, or (None, None)"""
     for rel in PMC_PROFILES:
         p = os.path.join(ROOT, rel)
         if not os.path.exists(p):
             continue
         try:
             d = json.load(open(p))
-            regimes = d.get("regimes")
-            if regimes:
-                ok = [r for r in regimes if FC_KERNEL_TAG.get(kind, "?") in r["kernel"]]
-                if ok:
-                    best = min(ok, key=lambda r: abs(np.log(max(r["units_per_launch"], 1.0) / max(units_per_launch, 1.0))))
-                    return float(best["hbm_bytes_per_unit"]), rel, best.get("regime")
-            k = d["k_fc_step"]
-            if FC_KERNEL_TAG.get(kind, "?") in k["kernel"]:   # counters of another kernel say nothing about this one
-                return float(k["hbm_bytes_per_unit"]), rel, "one full-width window (DNE_NSUB=1, 2500 pairs)"
         except Exception:
-            pass
-    return None, None, None
+            continue
+        tag = FC_KERNEL_TAG.get(kind, "?")
+        if any(tag in r.get("kernel", "") for r in d.get("regimes", [])) or tag in d.get("k_fc_step", {}).get("kernel", ""):
+            return d, rel
+    return None, None
+
+
+def _pmc_traffic(kind, units_per_launch):
+    """HBM-side bytes per env-step of the streaming fc kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled for the
+    16-byte streaming loads as MI355X_MICROARCH.md prescribes, plus WRITE_SIZE; separate --pmc runs).  Preferred: the regime
+    `bench_mix` -- the counters summed over EVERY dispatch of the kernel in a run of this very command (tools/collect_pmc_bench_mix.sh:
+    bench.py's own launch mix, divided by the units those launches processed).  Otherwise the fixed-width regime (tools/kbench.py)
+    whose units per launch is closest to this run's.  A property of the kernel measured under the profiler, NOT a measurement of
+    this run: bench.py cannot read hardware counters in-process.  (None, None, None) if no profile is committed."""
+    d, rel = _pmc_profile(kind)
+    if d is None:
+        return None, None, None
+    tag = FC_KERNEL_TAG.get(kind, "?")
+    regimes = [r for r in d.get("regimes", []) if tag in r["kernel"]]
+    mix = [r for r in regimes if r["regime"].startswith("bench_mix")]
+    if mix:
+        return float(mix[0]["hbm_bytes_per_unit"]), rel, mix[0]["regime"]
+    if regimes:
+        best = min(regimes, key=lambda r: abs(np.log(max(r["units_per_launch"], 1.0) / max(units_per_launch, 1.0))))
+        return float(best["hbm_bytes_per_unit"]), rel, best.get("regime")
+    k = d["k_fc_step"]
+    return float(k["hbm_bytes_per_unit"]), rel, "one full-width window (DNE_NSUB=1, 2500 pairs)"
+
+
+def _floors(kind, units_per_launch, avg_ms):
+    """What really bounds the streaming kernel: it is neither at the algorithmic-bytes roofline nor anywhere near
+    it by choice -- pairs and table neighbours share rows.  Two floors per launch, from the committed profile: every DISTINCT
+    table row under the launch's slices once at 8 TB/s, and the kernel's own VALU issue time (SQ_ACTIVE_INST_VALU quad-cycles x 4
+    over 1024 SIMDs at the nominal clock: what its instruction stream costs with every wave always ready)."""
+    d, rel = _pmc_profile(kind)
+    if d is None:
+        return None
+    tag = FC_KERNEL_TAG.get(kind, "?")
+    regimes = [r for r in d.get("regimes", []) if tag in r["kernel"] and "floor_unique_rows_bytes_per_unit" in r]
+    mix = [r for r in regimes if r["regime"].startswith("bench_mix")]
+    r = mix[0] if mix else (min(regimes, key=lambda r: abs(np.log(max(r["units_per_launch"], 1.0) / max(units_per_launch, 1.0)))) if regimes else None)
+    out = {"source": rel}
+    if r is not None:
+        out["hbm_distinct_rows_bytes_per_unit"] = r["floor_unique_rows_bytes_per_unit"]
+        out["hbm_distinct_rows_ms"] = r["floor_unique_rows_bytes_per_unit"] * units_per_launch / HBM_PEAK * 1e3
+    sq = d.get("sq", {}).get(tag)
+    if sq:
+        out["valu_insts_per_unit"] = sq["SQ_INSTS_VALU_per_unit"]
+        out["valu_issue_ms"] = sq["SQ_ACTIVE_INST_VALU_per_unit"] * 4.0 * units_per_launch / SIMDS / SHADER_HZ * 1e3
+        out["valu_source"] = sq.get("regime")
+        for k in ("wave_cycles_split", "waves_per_simd"):
+            if k in sq:
+                out[k] = sq[k]
+    bind = max(out.get("hbm_distinct_rows_ms", 0.0), out.get("valu_issue_ms", 0.0))
+    if bind > 0:
+        out["binding"] = "valu" if out.get("valu_issue_ms", 0.0) >= out.get("hbm_distinct_rows_ms", 0.0) else "hbm"
+        out["frac_of_binding_floor"] = bind / avg_ms
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ rendezvous of the ranks
@@ -158,10 +204,19 @@ class FileRendezvous:
     MASTER_PORT and its run id -- and only this user can read.  Files older than this launch are ignored."""
 
     def __init__(self, world):
-        key = "%s.%s.%d" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
+        # one directory per LAUNCH: the launcher's pid alone can recur, its start time (field 22 of /proc/<pid>/stat) cannot, and an
+        # elastic restart inside one launcher bumps TORCHELASTIC_RESTART_COUNT -- a crashed launch's files are never in this one's way
+        ppid = os.getppid()
+        try:
+            started = open("/proc/%d/stat" % ppid).read().rsplit(")", 1)[1].split()[19]
+        except (OSError, IndexError):
+            started = "0"
+        key = "%s.%s.%s.%d.%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                                  os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), ppid, started)
         self.dir = os.environ.get("DNE_RDV_DIR") or os.path.join("/tmp", "dne_rdv.%d.%s" % (os.getuid(), key))
         os.makedirs(self.dir, mode=0o700, exist_ok=True)
         self.fresh = _T0 - 300
+        self.token = None           # rank 0's nonce, published with the id and echoed by every vote: a vote without it is not of this launch
 
     def _put(self, name, obj):
         p = os.path.join(self.dir, name)
@@ -169,12 +224,14 @@ class FileRendezvous:
             json.dump(obj, f)
         os.replace(p + ".tmp", p)
 
-    def _get(self, name, timeout, what):
+    def _get(self, name, timeout, what, token=None):
         p, deadline = os.path.join(self.dir, name), time.time() + timeout
         while True:
             try:
                 if os.path.getmtime(p) >= self.fresh:
-                    return json.load(open(p))
+                    m = json.load(open(p))
+                    if token is None or m.get("token") == token:
+                        return m
             except (OSError, ValueError):
                 pass
             if time.time() > deadline:
@@ -188,21 +245,34 @@ class FileRendezvous:
                     os.unlink(os.path.join(self.dir, f))
                 except OSError:
                     pass
-            self._put("uid", {"uid": uid.hex() if uid else None, "err": err})
+            self._put("uid", {"uid": uid.hex() if uid else None, "err": err, "token": os.urandom(8).hex()})
         m = self._get("uid", 600, "the RCCL id")
         if m is None:
             return None, "rank %d: no RCCL id from rank 0 after 600 s" % rank
+        self.token = m.get("token")
         return (bytes.fromhex(m["uid"]) if m.get("uid") else None), m.get("err")
 
     def vote(self, rank, world, ok, err):
-        self._put("vote.%d" % rank, {"ok": bool(ok), "err": err})
-        votes = [self._get("vote.%d" % r, 400, "rank %d's vote" % r) for r in range(world)]
+        self._put("vote.%d" % rank, {"ok": bool(ok), "err": err, "token": self.token})
+        votes = [self._get("vote.%d" % r, 400, "rank %d's vote" % r, token=self.token) for r in range(world)]
         errors = ["rank %d: %s" % (r, (v or {}).get("err") or "no answer") for r, v in enumerate(votes) if not (v and v["ok"])]
         return {"carrier": "gloo" if errors else "rccl", "errors": errors}
 
     def done(self, rank):
         if rank == 0:
             shutil.rmtree(self.dir, ignore_errors=True)
+
+
+EXIT_NO_RCCL = 3
+
+
+def gloo_fallback_refusal(decision, allowed):
+    """--transport rccl (the default): a vote that ends on gloo is a FAILED launch unless --allow-gloo-fallback was given, so that
+    no N > 1 run can report a scaling number that never touched RCCL.  Returns the message to leave with, or None to carry on."""
+    if decision.get("carrier") == "rccl" or allowed:
+        return None
+    return ("no RCCL communicator on every rank (%s) and --allow-gloo-fallback not given: refusing to run the exchange over gloo "
+            "(exit %d)" % ("; ".join(decision.get("errors") or ["no reason reported"]), EXIT_NO_RCCL))
 
 
 def comm_init_bounded(engine, rank, world, uid, timeout):
@@ -445,9 +515,22 @@ def run_rank(args):
             if uid is not None:
                 ok, err, hung_init = comm_init_bounded(engine, rank, world, uid, args.rccl_init_timeout)
             decision = rdv.vote(rank, world, ok, err)
+            refusal = gloo_fallback_refusal(decision, args.allow_gloo_fallback)
+            if refusal:
+                # the default carrier is RCCL and a scaling run must not "pass" on the host path: every rank got the same decision
+                # and every rank leaves with the same code
+                crumb(refusal)
+                engine.comm_abort()
+                if rdv is not None:
+                    rdv.done(rank)
+                sys.stdout.flush(); sys.stderr.flush()
+                os._exit(EXIT_NO_RCCL)      # a thread may still sit inside ncclCommInitRank
             if decision["carrier"] == "rccl":
                 engine.barrier()
                 r_, n_, is_ = engine.comm_info()
+                if n_ != world or r_ != rank:
+                    raise SystemExit("rank %d: the RCCL communicator reports ncclCommCount %d / ncclCommUserRank %d, the launch has %d ranks"
+                                     % (rank, n_, r_, world))
                 comm.update({"carrier": "rccl", "nccl_comm_count": n_, "nccl_user_rank": r_})
                 crumb("RCCL communicator ready: ncclCommCount %d, ncclCommUserRank %d" % (n_, r_))
             else:
@@ -483,9 +566,12 @@ def run_rank(args):
         engine.barrier()    # RCCL all-reduce when a communicator exists, then hipDeviceSynchronize
 
     gen = 0
+    all_units = all_launches = 0      # streaming-kernel units / launches of EVERY generation incl. warm-up: the denominator of a PMC pass
     for _ in range(args.warmup):
         crumb("generation %d (warmup) eval" % gen)
         es.es_generation(engine, noise.noise.size, config, n_pairs, gen, args.tslimit, EXP["optimizer"], rank, world, transport)
+        p = engine.profile()
+        all_units += p["fc_full_units"]; all_launches += p["fc_full_launches"]
         gen += 1
     barrier()
     t0 = time.time()
@@ -503,6 +589,7 @@ def run_rank(args):
         steps_local += p["env_steps"]
         # roofline kernel = the full-width streaming launches only (mid-range and tail lock-steps run other fc kernels)
         fc_ms += p["fc_full_ms"]; fc_launches += p["fc_full_launches"]; fc_units += p["fc_full_units"]
+        all_units += p["fc_full_units"]; all_launches += p["fc_full_launches"]
         fc_all_ms += p["fc_ms"]; fc_kind = int(p["fc_full_kind"]); fc_union_ms += p["fc_full_union_ms"]
         for k in stage:
             stage[k] += p[k]
@@ -527,7 +614,8 @@ def run_rank(args):
     crumb("red zones intact")
 
     which = [x for x in (args.extra.split(",") if args.extra not in ("", "none", "all", "default") else
-                         (EXTRAS if args.extra == "all" or (args.extra == "default" and world == 1) else ())) if x]
+                         (EXTRAS if args.extra == "all" or (args.extra == "default" and world == 1) else
+                          EXTRAS_MULTI if args.extra == "default" else ())) if x]
     for x in which:
         if x not in EXTRAS:
             raise SystemExit("--extra: unknown workload %r (choose from %s)" % (x, ", ".join(EXTRAS)))
@@ -558,8 +646,9 @@ def run_rank(args):
             per_unit, src, regime = _pmc_traffic(fc_kind, units_per_launch)
             achieved = units_per_launch * ALG_BYTES_PER_ENV_STEP / (avg_ms * 1e-3)
             traffic = per_unit * units_per_launch if per_unit else None
+            floors = _floors(fc_kind, units_per_launch, avg_ms)
             out["roofline"] = {
-                "bound": "hbm", "kernel": FC_KERNELS[fc_kind],
+                "bound": "valu+hbm" if floors and "valu_issue_ms" in floors else "hbm", "kernel": FC_KERNELS[fc_kind],
                 "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                 "frac_algorithmic": achieved / HBM_PEAK,
                 "frac_counter": (traffic / (avg_ms * 1e-3) / HBM_PEAK) if traffic else None,
@@ -569,10 +658,13 @@ def run_rank(args):
                                    "measured in this run" % src) if src else None,
                 "algorithmic_bytes_per_unit": ALG_BYTES_PER_ENV_STEP, "unit_def": "one env-step of one member",
                 "units_per_launch": units_per_launch, "avg_launch_ms": avg_ms, "launches": int(fc_launches),
+                "all_generations": {"units": int(all_units), "launches": int(all_launches)},
+                "floors": floors,
                 "note": "frac = frac_algorithmic = SURVEY 8d bytes (every member's weights once per env-step) / launch time / 8 TB/s; "
                         "an antithetic pair shares one read of its noise slice and (k_fc_duo) neighbouring units share table rows, so "
                         "the bytes the memory system actually moves (frac_counter) are well below that -- frac_counter is the honest "
-                        "distance to the HBM roofline, and it falls when the kernel avoids traffic",
+                        "distance to the HBM roofline, and it falls when the kernel avoids traffic; floors = what bounds the kernel "
+                        "now: its distinct table rows once at 8 TB/s and its own VALU issue time (SQ counters), per launch",
             }
             # SURVEY 8d also asks for the whole-job figure: every env-step of the generation (reference pass, tail and
             # update included in the time) priced at the same algorithmic bytes
@@ -640,12 +732,15 @@ def main():
     ap.add_argument("--no-profile-events", action="store_true")
     ap.add_argument("--extra", default="default",
                     help="BASELINE configs timed after the headline region: comma list of %s, or all / none; default = all at N = 1, "
-                         "none at N > 1" % ", ".join(EXTRAS))
+                         "%s at N > 1 (configs 4 / 5 are defined on 4 / 8 GPUs)" % (", ".join(EXTRAS), ",".join(EXTRAS_MULTI)))
     ap.add_argument("--extra-small", action="store_true", help="testing aid: the extra workloads at a population of 96")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "gloo"],
                     help="exchange for N > 1: rccl = dne_comm_* (RCCL over xGMI behind the C ABI); gloo = torch.distributed on the "
                          "host, only to exercise the multi-rank path on a box with fewer GPUs than ranks")
     ap.add_argument("--single-device", action="store_true", help="testing aid: every rank uses GPU 0 (needs --transport gloo)")
+    ap.add_argument("--allow-gloo-fallback", action="store_true",
+                    help="--transport rccl: if any rank cannot build the RCCL communicator, carry the records over gloo instead of "
+                         "exiting with code %d (the JSON line's comm.carrier then says gloo)" % EXIT_NO_RCCL)
     ap.add_argument("--rccl-init-timeout", type=int, default=int(os.environ.get("DNE_RCCL_INIT_TIMEOUT", "180")))
     ap.add_argument("--no-supervisor", action="store_true", help="N = 1: run in this process (no child, no retry)")
     args = ap.parse_args()

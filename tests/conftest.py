@@ -31,3 +31,28 @@ def oracle():
     import oracle as O
     O.build()
     return O
+
+
+@pytest.fixture(scope="session")
+def noise_table():
+    """The reference's 250M-entry table (es.py:51-61), sampled once per test session (2.5 s, 1 GB); engines attach() to it."""
+    from dne_hip import es
+    return es.SharedNoiseTable()
+
+
+ES_FULL = dict(n_pairs=2500, nact=18, sigma=0.02, tslimit=5000)   # BASELINE.json configs[1]
+
+
+@pytest.fixture(scope="session")
+def oracle_es_gen0(oracle, noise_table):
+    """Generation 0 of config 2 (= the rollouts of config 4's first iteration: same theta, reference batch, indices and seeds)
+    on the CPU oracle over every usable host core, ONCE per session: all 2500 x 2 returns, sign-returns, lengths and RAM
+    trajectories.  About a minute on the GPU box's host."""
+    import oracle_pool
+    from dne_hip import es, policies
+    c = ES_FULL
+    th = policies.xavier_flat(c["nact"], 0)
+    ref = oracle.get_ref_batch(seed=0, batch_size=128, nact=c["nact"])
+    _, idx, seeds = es.generation_inputs(noise_table.noise.size, th.size, c["n_pairs"], 0, 0, 1)
+    ret, sg, ln, bcs = oracle_pool.es_generation(noise_table.noise, th, ref, idx, seeds, c["sigma"], c["tslimit"], c["nact"], want_bc=True)
+    return dict(theta=th, ref=ref, idx=idx, seeds=seeds, ret=ret, sg=sg, ln=ln, bcs=bcs)

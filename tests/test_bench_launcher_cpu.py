@@ -111,3 +111,34 @@ def test_file_rendezvous_of_an_external_launcher(tmp_path, monkeypatch):
         assert all(res[r][0] == bytes(range(128)) for r in range(world))
         want = {"carrier": "gloo", "errors": ["rank 2: boom"]} if fail else {"carrier": "rccl", "errors": []}
         assert all(res[r][1] == want for r in range(world))
+
+
+def test_rccl_is_not_optional_by_default():
+    """--transport rccl: a vote that ends on gloo fails the launch (exit 3) unless --allow-gloo-fallback was given"""
+    sys.path.insert(0, ROOT)
+    import bench
+    lost = {"carrier": "gloo", "errors": ["rank 1: ncclCommInitRank: unhandled system error"]}
+    msg = bench.gloo_fallback_refusal(lost, allowed=False)
+    assert msg and "rank 1: ncclCommInitRank" in msg and "--allow-gloo-fallback" in msg and bench.EXIT_NO_RCCL == 3
+    assert bench.gloo_fallback_refusal(lost, allowed=True) is None
+    assert bench.gloo_fallback_refusal({"carrier": "rccl", "errors": []}, allowed=False) is None
+
+
+def test_file_rendezvous_ignores_votes_of_another_launch(tmp_path, monkeypatch):
+    """a vote file without this launch's token (rank 0's nonce, published with the id) is not read as a vote"""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("DNE_RDV_DIR", str(tmp_path / "rdv"))
+    os.makedirs(tmp_path / "rdv")
+    r0, r1 = bench.FileRendezvous(2), bench.FileRendezvous(2)
+    (tmp_path / "rdv" / "vote.1").write_text(json.dumps({"ok": True, "err": None, "token": "feedfacefeedface"}))   # fresh, but foreign
+    uid0, _ = r0.exchange_uid(0, bytes(range(128)), None)        # rank 0 clears leftovers, then publishes id + token
+    uid1, _ = r1.exchange_uid(1, None, None)
+    assert uid0 == uid1 == bytes(range(128)) and r0.token == r1.token and len(r0.token) == 16
+    (tmp_path / "rdv" / "vote.1").write_text(json.dumps({"ok": True, "err": None, "token": "feedfacefeedface"}))
+    assert r0._get("vote.1", 0.2, "rank 1's vote", token=r0.token) is None
+    res = {}
+    ts = [threading.Thread(target=lambda r=r, v=v: res.update({r: v.vote(r, 2, True, None)})) for r, v in ((0, r0), (1, r1))]
+    [t.start() for t in ts]
+    [t.join(30) for t in ts]
+    assert res[0] == res[1] == {"carrier": "rccl", "errors": []}

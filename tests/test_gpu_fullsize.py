@@ -12,9 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
-def full(oracle):
+def full(oracle, noise_table):
     from dne_hip import _lib, es, policies
-    noise = es.SharedNoiseTable()                                    # es.py:51-61, 250M entries
+    noise = noise_table                                              # es.py:51-61, 250M entries
     e = _lib.Engine(_lib.KIND_ES, NACT, max_members=2 * N_PAIRS, ref_count=128)
     noise.attach(e)
     th = policies.xavier_flat(NACT, 0)
@@ -151,23 +151,17 @@ def test_bench_config_soak(full):
         e.close()
 
 
-def _oracle_pair(i):
-    import oracle as O
-    noise, th, ref, idx, seeds = _ORACLE_BASE
-    L = O.layout(O.KIND_ES, NACT)
-    return O.es_eval(L, th, noise, idx[i:i + 1], 0.02, 5000, ref, seeds[2 * i:2 * i + 2])
-
-
 @pytest.mark.slow
 @pytest.mark.timeout(1500)
-def test_full_generation_bit_exact(full, oracle):
+def test_full_generation_bit_exact(full, oracle, oracle_es_gen0):
     """Generation 0 of config 2 in full -- all 2500 x 2 returns, sign-returns and lengths, and theta after the update --
-    against the CPU oracle run over every host core (about a minute on the GPU box's 256 cores; es.py:246-248, 297)."""
-    import multiprocessing as mp
+    against the CPU oracle run over every usable host core (conftest.oracle_es_gen0, shared with the NS-ES test;
+    es.py:246-248, 297)."""
     from dne_hip import es
-    global _ORACLE_BASE
     e, noise, th, ref = full
     _, idx, seeds = es.generation_inputs(noise.noise.size, e.P, N_PAIRS, 0, 0, 1)
+    o = oracle_es_gen0
+    assert np.array_equal(o["idx"], idx) and np.array_equal(o["seeds"], seeds) and np.array_equal(o["ref"], ref)
     e.set_theta(th); e.optimizer_reset()
     ret, sg, ln = e.es_eval(idx, 0.02, 5000, seeds)
     rec = e.allgather_results(N_PAIRS, N_PAIRS)
@@ -175,31 +169,23 @@ def test_full_generation_bit_exact(full, oracle):
     e.es_update_gathered("centered_rank", "adam", 0.005, 0.01)
     theta_gpu = e.get_theta()
     e.set_theta(th); e.optimizer_reset()
-    _ORACLE_BASE = (noise.noise, th, ref, idx, seeds)
-    cores = min(os.cpu_count() or 1, 256)
-    budget = 40 * cores            # pairs the oracle can do in roughly ten minutes at one pair per ~15 core-seconds
-    sel = np.arange(N_PAIRS) if budget >= N_PAIRS else np.random.RandomState(9).choice(N_PAIRS, budget, replace=False)
-    with mp.get_context("fork").Pool(cores) as pool:
-        out = pool.map(_oracle_pair, [int(i) for i in sel], chunksize=1)
-    oret = np.concatenate([o[0] for o in out]); osg = np.concatenate([o[1] for o in out]); oln = np.concatenate([o[2] for o in out])
-    assert np.array_equal(ln[sel], oln)
-    assert np.array_equal(ret[sel], oret) and np.array_equal(sg[sel], osg)
+    assert np.array_equal(ln, o["ln"]), np.flatnonzero((ln != o["ln"]).any(axis=1))[:8]
+    assert np.array_equal(ret, o["ret"]) and np.array_equal(sg, o["sg"])
     assert ret.shape == ln.shape == (N_PAIRS, 2) and ret.dtype == np.float32                      # es.py:246-248
-    if len(sel) == N_PAIRS:        # the whole population was checked: the update must match too
-        g = oracle.es_gradient(noise.noise, idx, oret, e.P)
-        assert g.shape == (e.P,) and g.dtype == np.float32                                          # es.py:297
-        _, oth = oracle.Adam(th, 0.01).update(g, 0.005)
-        assert np.array_equal(theta_gpu, oth)
+    g = oracle.es_gradient(noise.noise, idx, o["ret"], e.P)
+    assert g.shape == (e.P,) and g.dtype == np.float32                                              # es.py:297
+    _, oth = oracle.Adam(th, 0.01).update(g, 0.005)
+    assert np.array_equal(theta_gpu, oth)
 
 
-def test_ga_full_size_properties(oracle):
+def test_ga_full_size_properties(oracle, noise_table):
     """Config 3 at full size: 1000 children, top-20 truncation, 250M table (ga.py:136-149, 251-271).  Generation 0 (every
     child its own normc genome) and a generation of children of 20 cached parents: idempotent, independent of the slot a
     child is evaluated in, spot-checked against the oracle; selection equals the oracle's on the full return vector; the
     parent cache rebuilds nothing it already holds."""
     from dne_hip import _lib, es, ga
     n, T, sigma, tslimit = 1000, 20, 0.005, 60
-    noise = es.SharedNoiseTable()
+    noise = noise_table
     e = _lib.Engine(_lib.KIND_GA, NACT, max_members=n)
     try:
         noise.attach(e)
@@ -237,19 +223,20 @@ def _oracle_child(i):
 
 @pytest.mark.slow
 @pytest.mark.timeout(1800)
-def test_ga_full_generation_bit_exact(oracle):
+def test_ga_full_generation_bit_exact(oracle, noise_table):
     """Config 3 in full: generations 0 and 1 of the Deep GA at 1000 children, tslimit 5000, 250M table -- every child's
     return, sign-return and length, and the 20 survivors of the truncation with their scores, against the CPU oracle run over
-    every host core (ga.py:136-149, 251-271; about a minute per generation on the GPU box's 256 cores)."""
+    every host core (ga.py:136-149, 251-271; about half a minute per generation on the GPU box's host)."""
     import multiprocessing as mp
     from dne_hip import _lib, es, ga
     global _ORACLE_GA
     n, T, sigma = 1000, 20, 0.005
-    noise = es.SharedNoiseTable()
+    noise = noise_table
     e = _lib.Engine(_lib.KIND_GA, NACT, max_members=n)
     try:
         noise.attach(e)
-        cores = min(os.cpu_count() or 1, 256)
+        import oracle_pool
+        cores = oracle_pool.workers()
         pop, score = [], np.array([], np.float32)
         for gen in range(2):
             mine, parent, fresh, env_seeds = ga.ga_generation_inputs(noise.noise.size, e.P, n, len(pop), gen, 0, 1)

@@ -59,6 +59,23 @@ def test_cpu_legs_time_the_oracle_like_reference_workers(W, oracle):
     assert r["cores"] == 2 and r["kind"] == "port" and r["value"] > 0 and "2 CPU worker processes" in r["workload"]
     g = W.cpu_ga(noise, 0.005, 6, 18, children=4, procs=2, sample=2)
     assert g["cores"] == 2 and g["value"] > 0
+    # the sweep: every leg reports wall AND consumed CPU seconds; the value is the best wall-clock rate; the host is described
+    from dne_hip import policies
+    th, ref = policies.xavier_flat(18, 0), oracle.get_ref_batch(seed=0, batch_size=4)
+    s = W.cpu_es(noise, th, ref, 0.02, 6, 18, n_pairs_total=8, sample_pairs=2)
+    assert len(s["sweep"]) >= 2 and s["sweep"][0]["workers"] == 2 and all(r["cpu_s"] > 0 and r["wall_s"] > 0 for r in s["sweep"])
+    assert s["value"] == max(r["rate_wall"] for r in s["sweep"]) and s["cores"] in [r["workers"] for r in s["sweep"]]
+    h = s["host"]
+    assert h["usable_cpus"] <= h["os_cpu_count"] and h["sched_getaffinity"] >= 1 and "cgroup_cpu_max" in h and h["model"]
+
+
+def test_usable_cpus_honours_the_cgroup_quota(monkeypatch):
+    import hostinfo
+    monkeypatch.setattr(hostinfo, "affinity_cpus", lambda: 64)
+    monkeypatch.setattr(hostinfo, "_read", lambda p: "1050000 100000" if p == "/sys/fs/cgroup/cpu.max" else None)
+    assert hostinfo.cgroup_cpu_limit() == 10.5 and hostinfo.usable_cpus() == 11
+    monkeypatch.setattr(hostinfo, "_read", lambda p: "max 100000" if p == "/sys/fs/cgroup/cpu.max" else None)
+    assert hostinfo.cgroup_cpu_limit() is None and hostinfo.usable_cpus() == 64
 
 
 @pytest.mark.timeout(900)

@@ -20,7 +20,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for _p in (ROOT, os.path.join(ROOT, "deep-neuroevolution_amd")):
+for _p in (ROOT, os.path.join(ROOT, "deep-neuroevolution_amd"), os.path.join(ROOT, "tools")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
@@ -240,9 +240,9 @@ def _cpu_es_pair(i):
     import oracle as O
     noise, theta, ref, sigma, tslimit, nact, idx, seeds = _BASE
     L = O.layout(O.KIND_ES, nact)
-    t0 = time.time()
+    t0, c0 = time.time(), time.process_time()
     _, _, ln = O.es_eval(L, theta, noise, idx[i:i + 1], sigma, tslimit, ref, seeds[2 * i:2 * i + 2])
-    return int(ln.sum()), time.time() - t0
+    return int(ln.sum()), time.time() - t0, time.process_time() - c0
 
 
 def _cpu_ga_child(i):
@@ -250,12 +250,14 @@ def _cpu_ga_child(i):
     import oracle as O
     noise, sigma, tslimit, nact, fresh, seeds = _BASE
     L = O.layout(O.KIND_GA, nact)
-    t0 = time.time()
+    t0, c0 = time.time(), time.process_time()
     r = O.rollout(L, O.ga_rebuild(L, noise, [int(fresh[i])], sigma), None, seeds[i], tslimit)
-    return int(r[2]), time.time() - t0
+    return int(r[2]), time.time() - t0, time.process_time() - c0
 
 
 def _pool_rate(fn, n, procs):
+    """n work items over `procs` forked single-threaded workers -> (env-steps, CPU seconds the workers consumed
+    [time.process_time inside each item: what the cores really delivered], wall seconds incl. start-up and stragglers)"""
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
@@ -264,38 +266,67 @@ def _pool_rate(fn, n, procs):
     with mp.get_context("fork").Pool(procs) as pool:
         res = pool.map(fn, range(n), chunksize=1)
     wall = time.time() - t0
-    return int(sum(r[0] for r in res)), float(sum(r[1] for r in res)), wall
+    return int(sum(r[0] for r in res)), float(sum(r[2] for r in res)), wall
+
+
+def _sweep_counts(procs):
+    """worker counts to try: the reference runs one worker per core it is given (launch.py:117), so which count is best is a
+    property of the host -- 2 (config 1), 16, 64, 128, 256, what the cgroup / affinity mask admits, and os.cpu_count()"""
+    from hostinfo import usable_cpus
+    if procs:
+        return [int(procs)]
+    top = os.cpu_count() or 1
+    return sorted({w for w in (2, 16, 64, 128, 256, usable_cpus(), top) if 1 <= w <= top})
+
+
+def _cpu_sweep(fn, counts, n_total, items_for):
+    """time `fn` at every worker count; the baseline is the BEST wall-clock rate (the reference's operator would pick that count)"""
+    rows = []
+    for w in counts:
+        n = min(items_for(w), n_total)
+        steps, cpu_s, wall = _pool_rate(fn, n, w)
+        rows.append({"workers": w, "items": n, "env_steps": steps, "wall_s": round(wall, 2), "cpu_s": round(cpu_s, 2),
+                     "rate_wall": steps / wall, "rate_per_cpu_second": steps / max(cpu_s, 1e-9),
+                     "cpus_delivered": round(cpu_s / wall, 1)})
+    return rows, max(rows, key=lambda r: r["rate_wall"])
 
 
 def cpu_es(noise, theta, ref, sigma, tslimit, nact, n_pairs_total=2500, procs=None, sample_pairs=None, generation=0):
     """The CPU oracle structured like the reference workers (one single-threaded process per worker, one antithetic pair at a
-    time, batch-1 forwards, a reference pass per episode: es.py:366-439, launch.py:117) on the first `sample_pairs` pairs of a
-    generation.  The reference's workers never idle, so the rate is steps per busy worker-second times the worker count."""
+    time, batch-1 forwards, a reference pass per episode: es.py:366-439, launch.py:117) on the first pairs of a generation, at a
+    sweep of worker counts.  `value` is the best WALL-CLOCK rate of the sweep (process start-up and stragglers included) and
+    `cores` the worker count that gave it; `host` says what the box really offers (affinity mask, cgroup quota, CPU model),
+    `cpus_delivered` = CPU seconds consumed / wall seconds of that leg."""
     global _BASE
     from dne_hip import es
-    procs = procs or os.cpu_count() or 1
+    from hostinfo import host_facts
     _, idx, seeds = es.generation_inputs(noise.size, theta.size, n_pairs_total, generation, 0, 1)
-    n = min(sample_pairs or 2 * procs, n_pairs_total)
     _BASE = (noise, theta, ref, sigma, tslimit, nact, idx, seeds)
-    steps, busy, wall = _pool_rate(_cpu_es_pair, n, procs)
-    return {"value": steps / (busy / procs), "unit": "env-steps/s", "cores": procs, "kind": "port",
+    items = (lambda w: sample_pairs) if sample_pairs else (lambda w: min(max(2 * w, 16), 256))
+    rows, best = _cpu_sweep(_cpu_es_pair, _sweep_counts(procs), n_pairs_total, items)
+    return {"value": best["rate_wall"], "unit": "env-steps/s", "cores": best["workers"], "kind": "port",
+            "cpus_delivered": best["cpus_delivered"], "rate_per_cpu_second": best["rate_per_cpu_second"],
             "sample": "first %d antithetic pairs of generation %d (%d full episodes, %d env-steps) over %d single-threaded worker "
-                      "processes; %.1f busy worker-seconds, %.1f s wall (wall-clock rate incl. stragglers and process start-up: "
-                      "%.0f steps/s)" % (n, generation, 2 * n, steps, procs, busy, wall, steps / wall)}
+                      "processes: %.1f s wall, %.1f CPU-seconds; value = env-steps / wall of the best worker count of the sweep"
+                      % (best["items"], generation, 2 * best["items"], best["env_steps"], best["workers"], best["wall_s"], best["cpu_s"]),
+            "sweep": rows, "host": host_facts()}
 
 
 def cpu_ga(noise, sigma, tslimit, nact, children=1000, procs=None, sample=None):
-    """ga.py:209-271's worker on the oracle: rebuild a root genome (normc), one episode; the first `sample` children of generation 0"""
+    """ga.py:209-271's worker on the oracle: rebuild a root genome (normc), one episode; the first children of generation 0,
+    at the same sweep of worker counts as cpu_es"""
     global _BASE
     from dne_hip import _lib, ga
-    procs = procs or os.cpu_count() or 1
     _, _, fresh, seeds = ga.ga_generation_inputs(noise.size, _lib.num_params(_lib.KIND_GA, nact), children, 0, 0, 0, 1)
-    n = min(sample or procs, children)
     _BASE = (noise, sigma, tslimit, nact, fresh, seeds)
-    steps, busy, wall = _pool_rate(_cpu_ga_child, n, procs)
-    return {"value": steps / (busy / procs), "unit": "env-steps/s", "cores": procs, "kind": "port",
-            "sample": "first %d children of generation 0 (%d env-steps) over %d single-threaded worker processes; %.1f busy "
-                      "worker-seconds, %.1f s wall" % (n, steps, procs, busy, wall)}
+    items = (lambda w: sample) if sample else (lambda w: min(max(w, 16), 256))
+    rows, best = _cpu_sweep(_cpu_ga_child, _sweep_counts(procs), children, items)
+    return {"value": best["rate_wall"], "unit": "env-steps/s", "cores": best["workers"], "kind": "port",
+            "cpus_delivered": best["cpus_delivered"],
+            "sample": "first %d children of generation 0 (%d env-steps) over %d single-threaded worker processes: %.1f s wall, "
+                      "%.1f CPU-seconds; best worker count of the sweep" % (best["items"], best["env_steps"], best["workers"],
+                                                                            best["wall_s"], best["cpu_s"]),
+            "sweep": rows}
 
 
 def config1_cpu(noise, nact=18, pop=256, sigma=0.02, tslimit=5000, sample_pairs=8):
