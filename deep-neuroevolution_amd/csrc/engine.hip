@@ -566,6 +566,8 @@ struct dne_handle {
     int conv2_ref_fpw = 8;           // DNE_CONV2_REF_FPW: reference frames per conv2 workgroup (8, 4, or 1 = the lock-step kernel)
     int duo_rounds = 1;              // DNE_DUO_ROUNDS: duos per wave and work item of the sweep (1-4)
     int duo_sync = 1;                // DNE_DUO_SYNC: row blocks per barrier of the sweep (1-8)
+    int duo_w = 8;                   // DNE_DUO_W: rows in flight per stream of k_fc_duo (8: two waves per SIMD; 4: four)
+    int duo_grid = 0;                // DNE_DUO_GRID: persistent grid of k_fc_duo (0 = fc_grid, doubled for DNE_DUO_W=4)
     int duo_sweep = 2;               // DNE_DUO_SWEEP (0 = off): the four waves of a k_fc_duo workgroup walk one table timeline (1: two units per wave only, 2: also one unit per wave)
     int fc_prio = 3;                 // DNE_FC_PRIO: s_setprio of k_fc_duo's waves (0-3)
     int duo_lag = 0;                 // DNE_DUO_LAG: extra row batches by which the second unit of a duo trails the first
@@ -961,6 +963,9 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_DUO_SWEEP", 0, 2, &h->duo_sweep);
     env_int("DNE_DUO_SYNC", 1, 8, &h->duo_sync);
     env_int("DNE_DUO_ROUNDS", 1, 4, &h->duo_rounds);
+    env_int("DNE_DUO_W", 4, 8, &h->duo_w);
+    if (h->duo_w != 4) h->duo_w = 8;
+    env_int("DNE_DUO_GRID", 0, 1 << 16, &h->duo_grid);
     env_int("DNE_FCREF_MT8", 0, 1, &h->fcref_mt8);
     env_int("DNE_CONV2_REF_FPW", 1, 8, &h->conv2_ref_fpw);
     env_int("DNE_DUO_SOLO_BELOW", 0, 1 << 30, &h->duo_solo_below);
@@ -1550,9 +1555,12 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         const bool solo = h->duo_solo_now;
         const bool sweep = h->duo_sweep && (!solo || h->duo_sweep > 1);
         const int rounds = sweep ? h->duo_rounds : 1;   // duos a wave takes one after the other within a work item (sweep only)
-        const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 4 * rounds - 1) / (4 * rounds), blocks = std::min(items, h->fc_grid);
+        const bool w4 = h->duo_w == 4 && es && sweep;
+        const int duo_grid = h->duo_grid ? h->duo_grid : (w4 ? 2 * h->fc_grid : h->fc_grid);
+        const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 4 * rounds - 1) / (4 * rounds), blocks = std::min(items, duo_grid);
         const size_t out_lds = (size_t)h->out_lds_kb * 1024;   // an LDS reservation nobody uses: it only bounds k_out's workgroups per CU next to the streaming fc
-        if (es && sweep) hipLaunchKernelGGL((k_fc_duo<2, true, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
+        if (w4) hipLaunchKernelGGL((k_fc_duo<2, true, true, 4>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
+        else if (es && sweep) hipLaunchKernelGGL((k_fc_duo<2, true, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
         else if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
         else if (sweep) hipLaunchKernelGGL((k_fc_duo<1, false, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
         else hipLaunchKernelGGL((k_fc_duo<1, false>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));

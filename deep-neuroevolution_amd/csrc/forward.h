@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <utility>
 
 namespace dne {
 
@@ -1565,13 +1566,25 @@ __device__ __forceinline__ void wait_rows(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d
 // when the front reaches their unit's first row (a wave-uniform count of s_barrier, no fence: the rolling loads stay in flight), and
 // one s_barrier per row block keeps the four in table lock-step, so that all eight units ask for a table row within the same few
 // loads and HBM delivers it once.  A schedule, not arithmetic: same chains, same bits.
-template <int NV, bool HAS_BN, bool SWEEP = false>
-__global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict__ order, int n_units,
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// W = rows in flight per stream.  W = 8: 198 registers, two waves per SIMD.  W = 4 (round 4): the same bytes in flight per SIMD from
+// twice the waves (<= 128 registers, four waves per SIMD) -- the SQ counters of the W = 8 kernel alone show its waves issuing 17 % of
+// their cycles, stalled on instruction dependencies 41 % and parked (timeline start-up, barriers, loads) 41 %: more waves fill those.
+template <int NV, bool HAS_BN, bool SWEEP = false, int W = 8>
+__global__ __launch_bounds__(256, W == 8 ? 2 : 4) void k_fc_duo(FwdArgs A, const int *__restrict__ order, int n_units,
                                                 const float *__restrict__ y2, float *__restrict__ y3t, int lag) {
-    constexpr int W = 8;                          // rows in flight per stream
+    static_assert(W == 8 || W == 4, "sub-slice boundaries are multiples of 8 rows");
     __shared__ long long sw_key[2][4];            // SWEEP: the waves' first table addresses / row-block counts, double-buffered by item parity
     __shared__ int sw_len[2][4];
     __shared__ int sw_plan[2][4][4][2];           // SWEEP: [parity][wave][round] -> the duo's units (A, B or -1)
+    // W = 4: the quarter's running fold lives in LDS (touched once per sub-slice, every 30 row blocks) instead of 16 registers -- with
+    // them the build spills bn2's scale / shift, and every reload drains the rows in flight (s_waitcnt vmcnt(0) inside the row loop)
+    constexpr bool FOLD_LDS = W == 4;
+    __shared__ f32x4 sw_fold[FOLD_LDS ? 4 : 1][2][NV][FOLD_LDS ? 64 : 1];
     int sw_par = 0;
     constexpr int NBLK = 968 / W, BPC = 64 / W;   // row blocks per unit, per 64-row activation chunk
     const int tid = threadIdx.x, wv = uni(tid >> 6), lane = tid & 63;
@@ -1709,7 +1722,11 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
         // after every load issued before the row loads of those blocks has landed (loads complete in order).
         auto request_x = [&](Side &Z, int c) {
             if (c >= 16) return;
-            const unsigned xoff = (c < 15 ? lane : min(lane, 7)) * 4;
+            // derived from voff at the point of use: kept live across the row loop these two offsets are what the W = 4 build spills
+            // (and a reload brings an s_waitcnt vmcnt(0) -- every row in flight drained -- into the loop)
+            unsigned vo = voff;
+            asm volatile("" : "+v"(vo));
+            const unsigned xoff = c < 15 ? vo >> 2 : min(vo >> 2, 28u);
 #pragma unroll
             for (int v = 0; v < NV; v++)   // xv as an operand: behind take_x's arithmetic, when the old raw values are dead (no copy of a register in flight)
                 asm volatile("global_load_dword %[d], %[vo], %[sb]" : [d] "=v"(Z.xn[v]), "+v"(Z.xv[v]) : [vo] "v"(xoff), [sb] "s"(Z.xs[v] + 64 * c));
@@ -1780,6 +1797,19 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
             Z.lb++;
             if (Z.lb == Z.nb) {   // end of a sub-slice (oracle fc_raw): the chain joins the quarter's fold and starts again from 0
                 const bool first = Z.nb == FC_SUB0 / W;
+                if constexpr (FOLD_LDS) {
+                    const int side = &Z == &SB ? 1 : 0;
+#pragma unroll
+                    for (int v = 0; v < NV; v++) {
+                        f32x4 a4 = {Z.acc[v][0][0], Z.acc[v][0][1], Z.acc[v][1][0], Z.acc[v][1][1]};
+                        if (!first) {
+                            const f32x4 f4 = sw_fold[wv][side][v][lane];
+                            a4 = f32x4{f4[0] + a4[0], f4[1] + a4[1], f4[2] + a4[2], f4[3] + a4[3]};
+                        }
+                        sw_fold[wv][side][v][lane] = a4;
+                        Z.acc[v][0] = Z.acc[v][1] = f32x2{0.0f, 0.0f};
+                    }
+                } else {
 #pragma unroll
                 for (int v = 0; v < NV; v++)
 #pragma unroll
@@ -1787,6 +1817,7 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
                         Z.fold[v][hf] = first ? Z.acc[v][hf] : Z.fold[v][hf] + Z.acc[v][hf];
                         Z.acc[v][hf] = f32x2{0.0f, 0.0f};
                     }
+                }
                 Z.nb += FC_SUBN / W;
             }
         };
@@ -1797,9 +1828,7 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
                 if (DA) refill(SA, eA[I], tA[I], ii);
                 if (DB) refill(SB, eB[I], tB[I], ii);
             };
-            one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
-            one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
-            one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+            static_for<W>(one);
             if (DA) next_block(SA);
             if (DB) next_block(SB);
 #pragma unroll
@@ -1824,9 +1853,7 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
                     if (DB) refill(SB, eB[I], tB[I], ii);
                     __builtin_amdgcn_sched_barrier(0);
                 };
-                one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
-                one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
-                one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{});
+                static_for<W>(one);
                 if (DA) end_block(SA);
                 if (DB) end_block(SB);
                 if constexpr (SWEEP) sw_tick();   // the workgroup's four waves advance one row block at a time
@@ -1851,6 +1878,10 @@ __global__ __launch_bounds__(256) void k_fc_duo(FwdArgs A, const int *__restrict
 #pragma unroll
             for (int v = 0; v < NV; v++) {
                 f4a o = {Z.fold[v][0][0], Z.fold[v][0][1], Z.fold[v][1][0], Z.fold[v][1][1]};
+                if constexpr (FOLD_LDS) {
+                    const f32x4 f4 = sw_fold[wv][&Z == &SB ? 1 : 0][v][lane];
+                    o = f4a{f4[0], f4[1], f4[2], f4[3]};
+                }
                 *(f4a *)(y3t + ((size_t)Z.mem[v] * 4 + Z.sl) * 256 + lane * 4) = o;
             }
         };

@@ -153,6 +153,10 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_SWEEP": "1"},   # ... the timeline only for two units per wave (default 2: also for one)
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_ROUNDS": "2"},   # ... every wave takes two duos one after the other on the workgroup's timeline
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_ROUNDS": "3", "DNE_DUO_SYNC": "2"},   # ... three single units, a barrier every second row block
+    {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_W": "4"},   # ... four rows in flight per stream instead of eight (four waves per SIMD; the fold in LDS), two units per wave
+    {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_W": "4"},   # ... one unit per wave
+    {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_W": "4", "DNE_DUO_SYNC": "2", "DNE_NSUB": "2"},   # ... a barrier every second row block, two windows
+    {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_W": "8"},   # ... and the eight-row form by name
     {"DNE_FC_DUO": "0", "DNE_FC2_MIN": "2", "DNE_FC_TAIL_MAX": "1"},    # the duo path switched off: k_fc2
     {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1"},                      # k_fc<2> streaming kernel
     {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1", "DNE_FC_RB": "2"},    # ... with 2-row batches
