@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <cstdlib>
 #include <cmath>
@@ -567,6 +568,13 @@ struct dne_handle {
     int duo_rounds = 1;              // DNE_DUO_ROUNDS: duos per wave and work item of the sweep (1-4)
     int duo_sync = 1;                // DNE_DUO_SYNC: row blocks per barrier of the sweep (1-8)
     int duo_w = 8;                   // DNE_DUO_W: rows in flight per stream of k_fc_duo (8: two waves per SIMD; 4: four)
+    int fc_sub = 1;                  // DNE_FC_SUB: the sub-slice fc (k_fc_sub: one wave per 128 / 120-row chain) in the mid range -- 0 off, 1 GA children (materialised), 2 also ES pairs
+    int fc_sub_min = 97, fc_sub_max = 1100;   // DNE_FC_SUB_MIN / _MAX: active groups (all windows) between which it runs
+    int fc_sub_nsub = 2;             // DNE_FC_SUB_NSUB: windows of that regime
+    int fc_sub_spw = 0;              // DNE_FC_SUB_SPW: sub-slices per wave (1, 2, 4, 8; 0 = by width)
+    bool sub_now = false;            // decided per burst by eval_core
+    float *y3s = nullptr;            // [member][32][256]: the chain sums k_fc_sub leaves for k_out<.., SUB>
+    int duo_xcd = 0;                 // DNE_DUO_XCD: k_fc_duo's work items dealt to the XCDs in contiguous ranges (one table range per L2)
     int duo_grid = 0;                // DNE_DUO_GRID: persistent grid of k_fc_duo (0 = fc_grid, doubled for DNE_DUO_W=4)
     int duo_sweep = 2;               // DNE_DUO_SWEEP (0 = off): the four waves of a k_fc_duo workgroup walk one table timeline (1: two units per wave only, 2: also one unit per wave)
     int fc_prio = 3;                 // DNE_FC_PRIO: s_setprio of k_fc_duo's waves (0-3)
@@ -660,7 +668,7 @@ struct dne_handle {
     // RCCL communicator (dne_comm_init); the library is opened on demand
     void *rccl_lib = nullptr; void *comm = nullptr; int comm_rank = 0, comm_size = 1;
     bool comm_borrowed = false;      // dne_comm_share: the communicator belongs to another handle of this process
-    bool comm_off = false;           // dne_comm_abort: this handle takes no part in RCCL any more (a late dne_comm_init result is dropped)
+    std::atomic<bool> comm_off{false};   // dne_comm_abort (possibly from another host thread than a dne_comm_init still in flight): this handle takes no part in RCCL any more, a late result is dropped
     double *comm_scratch = nullptr;
 
     template <typename T>
@@ -966,6 +974,13 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_DUO_W", 4, 8, &h->duo_w);
     if (h->duo_w != 4) h->duo_w = 8;
     env_int("DNE_DUO_GRID", 0, 1 << 16, &h->duo_grid);
+    env_int("DNE_DUO_XCD", 0, 1, &h->duo_xcd);
+    env_int("DNE_FC_SUB", 0, 2, &h->fc_sub);
+    env_int("DNE_FC_SUB_MIN", 1, 1 << 30, &h->fc_sub_min);
+    env_int("DNE_FC_SUB_MAX", 1, 1 << 30, &h->fc_sub_max);
+    env_int("DNE_FC_SUB_NSUB", 1, 4, &h->fc_sub_nsub);
+    env_int("DNE_FC_SUB_SPW", 0, 8, &h->fc_sub_spw);
+    if (h->fc_sub_spw != 1 && h->fc_sub_spw != 2 && h->fc_sub_spw != 4 && h->fc_sub_spw != 8) h->fc_sub_spw = 0;
     env_int("DNE_FCREF_MT8", 0, 1, &h->fcref_mt8);
     env_int("DNE_CONV2_REF_FPW", 1, 8, &h->conv2_ref_fpw);
     env_int("DNE_DUO_SOLO_BELOW", 0, 1 << 30, &h->duo_solo_below);
@@ -1023,6 +1038,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     if (h->large) { CH(h->alloc(&h->y1, M * 14112, "y1")); CH(h->alloc(&h->y2, M * 7744, "y2")); CH(h->alloc(&h->y3, M * 7744, "y3")); CH(h->alloc(&h->y3t, M * 512, "y3t")); }
     else { CH(h->alloc(&h->y1, M * 7056, "y1")); CH(h->alloc(&h->y2, M * 3872, "y2")); CH(h->alloc(&h->y3, M * 256, "y3")); CH(h->alloc(&h->y3t, M * 4 * 256, "y3t")); }
     CH(h->alloc(&h->unit_order, M * 4, "unit_order"));
+    if (!h->large && h->fc_sub) CH(h->alloc(&h->y3s, M * 32 * 256, "y3s"));
     if (cfg->n_actions > SPEC_ACTIONS - 2) h->spec_max = 0;
     if (h->spec_max > 0) {   // candidate outcomes of the speculative tail: [list position][action]
         const size_t rows = (size_t)h->spec_max * SPEC_ACTIONS;
@@ -1535,6 +1551,18 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         hipLaunchKernelGGL(k_lout, dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->action, logits);
         return;
     }
+    if (h->sub_now && !logits && !out_fused && h->y3s) {   // mid range: one wave per sub-slice chain, folded by the head
+        const int total_waves_at_1 = 32 * count;
+        // sub-slices per wave: about 8000 waves (one round of the whole machine) whatever the width
+        const int spw = h->fc_sub_spw ? h->fc_sub_spw : count * h->fc_sub_nsub <= 320 ? 1 : count * h->fc_sub_nsub <= 640 ? 2 : count * h->fc_sub_nsub <= 1280 ? 4 : 8;
+        const int waves = total_waves_at_1 / spw, blocks = (waves + 3) / 4;
+        // eval_core's sub_regime admits exactly two populations: ES pairs and GA children written out
+        if (es) hipLaunchKernelGGL((k_fc_sub<2, true, true>), dim3(blocks), dim3(256), 0, st, A, list, count, spw, (const float *)h->y2, h->y3s);
+        else hipLaunchKernelGGL((k_fc_sub<1, false, false>), dim3(blocks), dim3(256), 0, st, A, list, count, spw, (const float *)h->y2, h->y3s);
+        if (es) hipLaunchKernelGGL((k_out<2, true, true>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3s, h->y3, h->action, (float *)nullptr);
+        else hipLaunchKernelGGL((k_out<1, false, true>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3s, h->y3, h->action, (float *)nullptr);
+        return;
+    }
     if (count <= h->fc_tail_max) {   // latency-bound regime: 4 workgroups per group + a separate output-layer kernel
 #define FCT(NV, BN)                                                                                                          \
     do {                                                                                                                     \
@@ -1559,11 +1587,11 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         const int duo_grid = h->duo_grid ? h->duo_grid : (w4 ? 2 * h->fc_grid : h->fc_grid);
         const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 4 * rounds - 1) / (4 * rounds), blocks = std::min(items, duo_grid);
         const size_t out_lds = (size_t)h->out_lds_kb * 1024;   // an LDS reservation nobody uses: it only bounds k_out's workgroups per CU next to the streaming fc
-        if (w4) hipLaunchKernelGGL((k_fc_duo<2, true, true, 4>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
-        else if (es && sweep) hipLaunchKernelGGL((k_fc_duo<2, true, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
-        else if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
-        else if (sweep) hipLaunchKernelGGL((k_fc_duo<1, false, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
-        else hipLaunchKernelGGL((k_fc_duo<1, false>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
+        if (w4) hipLaunchKernelGGL((k_fc_duo<2, true, true, 4>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14) | (h->duo_xcd << 16));
+        else if (es && sweep) hipLaunchKernelGGL((k_fc_duo<2, true, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14) | (h->duo_xcd << 16));
+        else if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14) | (h->duo_xcd << 16));
+        else if (sweep) hipLaunchKernelGGL((k_fc_duo<1, false, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14) | (h->duo_xcd << 16));
+        else hipLaunchKernelGGL((k_fc_duo<1, false>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14) | (h->duo_xcd << 16));
         if (after_stream_kernel) hipEventRecord(after_stream_kernel, st);
         if (out_fused) return;   // the caller runs k_tail_step: policy head + emulator step in one launch
         if (es) hipLaunchKernelGGL((k_out<2, true>), dim3(count), dim3(256), out_lds, st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
@@ -1633,6 +1661,9 @@ extern "C" int dne_debug_activations_large(dne_handle *h, int member, float *y1,
 static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_t *env_seed, float *returns,
                      float *signreturns, int32_t *lengths, uint8_t *bc_out) {
     h->tt_on = false;
+    // per-evaluation launch state (tail table in the kernel arguments, the regime flags) never outlives this call, whichever
+    // return is taken: a later dne_act / dne_debug_activations must not decode members from a stale table
+    struct ClearOnExit { dne_handle *h; ~ClearOnExit() { h->tt_on = false; h->sub_now = false; } } clear_on_exit{h};
     if (n % gsize) return h->fail("member count %d not a multiple of the group size %d", n, gsize);
     if (tslimit <= 0) return h->fail("timestep limit must be positive");
     if (bc_out && !h->bc) return h->fail("behaviour characterisations requested but the engine was created with record_bc = 0");
@@ -1662,11 +1693,18 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     // (HBM) the others run their MFMA convolutions and emulator frames.  nsub follows the active count:
     // two free-running streams at full width, three in the mid range (where no single kernel fills the chip),
     // one when only a handful of episodes are left (measured: tools/kbench.py sweeps).
+    // the sub-slice fc's range: GA children written out (plain rows), optionally ES pairs (DNE_FC_SUB=2); never the LargeModel
+    auto sub_regime = [&](int total) {
+        if (h->large || !h->y3s || total < h->fc_sub_min || total > h->fc_sub_max) return false;
+        if (h->L.kind == DNE_KIND_ES) return h->fc_sub >= 2 && gsize == 2 && total < h->fc_duo_min;
+        return h->fc_sub >= 1 && gsize == 1 && h->members_materialized;
+    };
     auto pick_nsub = [&](int total) {
         // measured (tools/kbench.py sweeps): k_fc2 wants 3 windows at full width and 4 in the upper mid range; below
         // ~400 groups the windows are sized to fit the column-split tail kernels (<= fc_tail_max groups each)
         int k = total >= 1900 ? h->nsub_full : total >= h->fc2_min_total ? h->nsub_mid : total > 4 * h->fc_tail_max ? 3
               : total >= 48 ? std::max(2, (total + h->fc_tail_max - 1) / h->fc_tail_max) : 1;
+        if (sub_regime(total)) k = h->fc_sub_nsub;
         if (h->nsub_fixed > 0) k = h->nsub_fixed;
         k = std::min(k, (int)h->sub_streams.size());
         return std::max(1, std::min(k, total));
@@ -1713,6 +1751,8 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
         h->duo_now = !h->large && h->fc_duo && (h->L.kind == DNE_KIND_ES ? gsize == 2 : (gsize == 1 && h->fc_duo_ga)) && total >= h->fc_duo_min &&
                      (size_t)4 * ((total + nsub - 1) / nsub) * sizeof(long long) <= 160 * 1024;   // k_unit_order ranks a window's keys in LDS
         h->duo_solo_now = total < h->duo_solo_below;
+        h->sub_now = sub_regime(total);
+        if (h->sub_now) h->duo_now = h->fc2_now = false;
         if (h->duo_now)   // the list only changes at a compaction: rank each window's units by table address once per burst
             for (int s = 0; s < nsub; s++) {
                 const int lo = (int)((long long)total * s / nsub), cnt = (int)((long long)total * (s + 1) / nsub) - lo;
@@ -1733,7 +1773,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 const bool pe = prof && (duo_eval ? duo_win : fc2_eval ? h->fc2_now : cnt > h->fc_tail_max);
                 if (pe) { e[0] = ne++; HCHECK(h, hipEventRecord(h->event(e[0]), sst)); }
                 // fused policy head + emulator (+ render): while all windows together still fit the chip one workgroup per member
-                const bool tail = !h->large && cnt <= h->fc_tail_max && total <= h->tail_fused_max;   // (the fused tail kernels are the small networks')
+                const bool tail = !h->large && !h->sub_now && cnt <= h->fc_tail_max && total <= h->tail_fused_max;   // (the fused tail kernels are the small networks')
                 // speculative tail: the emulator + renderer outcome of every action, inside the launches of this step's forward pass
                 const bool spec = tail && nsub == 1 && h->spec_max > 0 && cnt * gsize <= h->spec_max &&
                                   cnt * gsize <= h->conv_split_max && !h->dbg_skip;
@@ -1826,6 +1866,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
         h->trace("eval: lock-step %d, %d active groups", t, total);
     }
     h->tt_on = false;
+    h->sub_now = false;
     HCHECK(h, hipGetLastError());
     HCHECK(h, hipEventRecord(h->ev_b, h->stream));
     HCHECK(h, hipMemcpyAsync(returns, h->ret, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -2347,11 +2388,16 @@ extern "C" int dne_comm_init(dne_handle *h, int rank, int nranks, const void *un
     memcpy(&id, unique_id128, sizeof(id));
     ncclComm_t c = nullptr;
     h->trace("comm init: rank %d of %d", rank, nranks);
-    NCHECK(h, g_rccl.CommInitRank(&c, nranks, id, rank));
-    if (h->comm_off) {   // the caller gave up on this initialisation (dne_comm_abort from another thread) while it was in flight
-        g_rccl.CommAbort(c);
-        return h->fail("dne_comm_init: communicator dropped, dne_comm_abort was called meanwhile");
+    // the one call that can block for long (a peer that never arrives).  If the caller has meanwhile given up (dne_comm_abort from
+    // the thread that owns the handle), that thread is using the handle: from here on this late path touches NOTHING of it but the
+    // atomic flag -- no error text (h->fail writes the shared buffer), no trace -- and returns a code.  The handle must not be
+    // destroyed while an initialisation is still in flight (bench.py leaves through os._exit in that case).
+    const ncclResult_t init_rc = g_rccl.CommInitRank(&c, nranks, id, rank);
+    if (h->comm_off.load(std::memory_order_acquire)) {
+        if (init_rc == ncclSuccess && c) g_rccl.CommAbort(c);
+        return -2;   // DNE_COMM_DROPPED
     }
+    if (init_rc != ncclSuccess) return h->fail("ncclCommInitRank -> %s", g_rccl.GetErrorString(init_rc));
     h->comm = c; h->comm_rank = rank; h->comm_size = nranks;
     HCHECK(h, h->alloc(&h->comm_scratch, 64, "comm_scratch"));
     h->trace("comm ready");
@@ -2399,7 +2445,7 @@ extern "C" int dne_comm_share(dne_handle *h, dne_handle *owner) {
 // Give up on RCCL for this handle (the ranks agreed on another carrier): an existing communicator is aborted, one that a
 // still-running dne_comm_init on another thread produces later is dropped.  Afterwards the handle behaves like a single rank.
 extern "C" int dne_comm_abort(dne_handle *h) {
-    h->comm_off = true;
+    h->comm_off.store(true, std::memory_order_release);
     if (h->comm && !h->comm_borrowed && g_rccl.lib) g_rccl.CommAbort((ncclComm_t)h->comm);
     h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1;
     return 0;

@@ -1604,6 +1604,7 @@ __global__ __launch_bounds__(256, W == 8 ? 2 : 4) void k_fc_duo(FwdArgs A, const
         if (sw_sync == 1 || sw_t % sw_sync == 0) __builtin_amdgcn_s_barrier();
     };
     const int rounds = SWEEP ? ((lag >> 14) & 3) + 1 : 1;   // SWEEP: duos a wave takes one after the other on the workgroup's timeline
+    const bool xcd_map = (lag >> 16) & 1;   // DNE_DUO_XCD: workgroups of one XCD (blockIdx % 8) take a contiguous range of work items = one table range per L2
     lag &= 255;
     const int n_duos = solo ? n_units : (n_units + 1) >> 1, n_items = (n_duos + 4 * rounds - 1) / (4 * rounds);
     typedef DuoSide<NV> Side;
@@ -1631,7 +1632,10 @@ __global__ __launch_bounds__(256, W == 8 ? 2 : 4) void k_fc_duo(FwdArgs A, const
         const long long delta = unit_key(uB) - unit_key(uA);
         return delta < 0 ? 0 : (int)min((long long)NBLK, delta / (256 * W) + lag);
     };
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int xcd_chunk = (n_items + 7) >> 3;
+    for (int it = blockIdx.x; it < (xcd_map ? 8 * xcd_chunk : n_items); it += gridDim.x) {
+        const int item = xcd_map ? (it & 7) * xcd_chunk + (it >> 3) : it;
+        if (item >= n_items) continue;
         int sw_tail = 0;
         if constexpr (SWEEP) {
             // plan: the wave's duos of this item (round r: duo (item * rounds + r) * 4 + wave), their lengths in row blocks, the table
@@ -2539,7 +2543,114 @@ __global__ __launch_bounds__(256) void k_fc_cols(FwdArgs A, const int *__restric
 
 // fc slice combine + bias, bn3 + relu, output layer (out_products / out_wave_sums: thread = input k) + first-max argmax from the
 // fc partial sums, one workgroup per group.  The members of a group share base vector and noise slice (antithetic pair).
-template <int NV, bool HAS_BN>
+// ------------------------------------------------------- sub-slice fc: one wave per (group, sub-slice chain), nothing shared, nothing waited for
+// The mid range (about 100 .. 1000 groups alive): too many groups for the latency kernels, too few for one workgroup per group to
+// fill 256 CUs (k_fc<1>: 250 members = 250 workgroups, 4 KB in flight per wave: 3.9 TB/s at best).  The numerics contract already cuts
+// every output's k-sum into 32 independent chains (4 quarters x 8 sub-slices of 128 / 120 rows, oracle fc_raw), so the chain IS the
+// unit of work here: a wave walks the 128 / 120 rows of ONE sub-slice (or of `spw` consecutive ones) with whole 1 KB rows per load
+// instruction (lane = 4 columns), RB rows in flight, no LDS, no barrier, and stores the chain's 256 sums to y3s[member][32][256];
+// the head (k_out<.., SUB>) folds them in the oracle's order.  250 members = 8000 waves: the whole machine streams.
+template <int NV, bool HAS_BN, bool NOISE>
+__global__ __launch_bounds__(256) void k_fc_sub(FwdArgs A, const int *__restrict__ list, int n_groups, int spw /* sub-slices per wave: 1, 2, 4, 8 */,
+                                                const float *__restrict__ y2, float *__restrict__ y3s /*[member][32][256]*/) {
+    constexpr int RB = 8;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const Layout &L = A.L;
+    const int upg = 32 / spw;   // waves per group
+    const int w = uni(blockIdx.x * 4 + wv);
+    if (w >= n_groups * upg) return;
+    const int gi = w / upg, j = w - gi * upg;
+    const int g = uni(list ? list[gi] : gi);
+    if (A.done) {   // finished group still in the list: nobody reads its sums
+        int all_done = 1;
+#pragma unroll
+        for (int v = 0; v < NV; v++) all_done &= uni(A.done[g * NV + v]) != 0;
+        if (all_done) return;
+    }
+    const int m0 = g * NV;
+    const long long off = uni64(A.m_off[m0]);
+    const float *base = A.bases + (size_t)uni(A.m_slot[m0]) * A.base_stride + L.fcw + lane * 4;
+    const float *eps = A.noise + off + L.fcw + lane * 4;
+    float scale[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) scale[v] = A.m_scale[m0 + v];
+    __builtin_amdgcn_s_setprio(3);
+    for (int s = 0; s < spw; s++) {
+        const int u = j * spw + s, q = u >> 3, i = u & 7;
+        const int nrows = i == 0 ? FC_SUB0 : FC_SUBN;
+        const int R0 = 968 * q + (i == 0 ? 0 : FC_SUB0 + FC_SUBN * (i - 1));   // first row of the chain within the 3872
+        // activations relu(bn2(y2)) of the chain's rows: two chunks of 64, one row per lane (bn2 channel = row mod 32)
+        float xa[NV], xb[NV];
+        {
+            const int ra = R0 + lane, rb = R0 + min(64 + lane, nrows - 1);
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                float a = y2[(size_t)(m0 + v) * 3872 + ra], b = y2[(size_t)(m0 + v) * 3872 + rb];
+                if (HAS_BN) {
+                    const float *bn = A.bn + (size_t)(m0 + v) * 608;
+                    a = a * bn[32 + (ra & 31)]; a = a + bn[64 + (ra & 31)];
+                    b = b * bn[32 + (rb & 31)]; b = b + bn[64 + (rb & 31)];
+                }
+                xa[v] = a > 0.0f ? a : 0.0f;
+                xb[v] = b > 0.0f ? b : 0.0f;
+            }
+        }
+        const float *th = base + (size_t)R0 * 256;
+        const float *ep = eps + (size_t)R0 * 256;
+        float acc[NV][4];
+#pragma unroll
+        for (int v = 0; v < NV; v++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[v][c] = 0.0f;
+        f4a t_cur[RB], t_nxt[RB];
+        f4u e_cur[NOISE ? RB : 1], e_nxt[NOISE ? RB : 1];
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            t_cur[r] = *(const f4a *)(th + r * 256);
+            if (NOISE) e_cur[r] = *(const f4u *)(ep + r * 256);
+        }
+        const int nb = nrows / RB;   // 16 or 15 row blocks
+        for (int b = 0; b < nb; b++) {
+            if (b + 1 < nb) {
+#pragma unroll
+                for (int r = 0; r < RB; r++) {
+                    t_nxt[r] = *(const f4a *)(th + ((b + 1) * RB + r) * 256);
+                    if (NOISE) e_nxt[r] = *(const f4u *)(ep + ((b + 1) * RB + r) * 256);
+                }
+            }
+            const bool first = b < 8;   // rows 0 .. 63 of the chain come from xa
+            const int li = (b & 7) * RB;
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    const float x = lane_bcast(first ? xa[v] : xb[v], li + r);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        float wgt = t_cur[r][c];
+                        if (NOISE) {
+                            const float pv = scale[v] * e_cur[r][c];   // fl(theta + fl(scale * eps)): es.py:412-419's two roundings
+                            wgt = wgt + pv;
+                        }
+                        acc[v][c] = __builtin_fmaf(x, wgt, acc[v][c]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                t_cur[r] = t_nxt[r];
+                if (NOISE) e_cur[r] = e_nxt[r];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const f4a o = {acc[v][0], acc[v][1], acc[v][2], acc[v][3]};
+            *(f4a *)(y3s + ((size_t)(m0 + v) * 32 + u) * 256 + lane * 4) = o;
+        }
+    }
+}
+
+template <int NV, bool HAS_BN, bool SUB = false>
 __global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y3t,
                                             float *__restrict__ y3, int32_t *__restrict__ actions,
                                             float *__restrict__ logits_out) {
@@ -2566,10 +2677,26 @@ __global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ 
 #pragma unroll
     for (int v = 0; v < NV; v++) {
         const int m = m0 + v;
-        const float *p = y3t + (size_t)m * 4 * 256 + tid;
-        const float s01 = p[0] + p[256];
-        const float s23 = p[512] + p[768];
-        float t = s01 + s23;
+        float t;
+        if constexpr (SUB) {   // behind k_fc_sub: the 32 chain sums of the column; a quarter = the left fold of its 8 (oracle fc_raw)
+            const float *p = y3t + (size_t)m * 32 * 256 + tid;
+            float qs[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float f = p[(8 * q) * 256];
+#pragma unroll
+                for (int i = 1; i < 8; i++) f = f + p[(8 * q + i) * 256];
+                qs[q] = f;
+            }
+            const float s01 = qs[0] + qs[1];
+            const float s23 = qs[2] + qs[3];
+            t = s01 + s23;
+        } else {
+            const float *p = y3t + (size_t)m * 4 * 256 + tid;
+            const float s01 = p[0] + p[256];
+            const float s23 = p[512] + p[768];
+            t = s01 + s23;
+        }
         float pvb = sc[v] * fb_e;
         const float fb = fb_t + pvb;
         t = t + fb;

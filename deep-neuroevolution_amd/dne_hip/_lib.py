@@ -71,6 +71,12 @@ def build(force=False):
     """Compile libdne_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(_CSRC, f) for f in ("engine.hip", "forward.h", "forward_large.h", "reduce.h", "env_synth.h")]
     srcs.append(os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include", "dne_hip.h"))
+    if os.environ.get("DNE_LIB_PATH"):
+        # another build of the same ABI was asked for by name: `make` only knows the in-tree library, so running it here would
+        # rebuild THAT one in the middle of an A/B and still not produce the file named -- check the file and leave it alone
+        if not os.path.exists(LIB_PATH):
+            raise DneError("DNE_LIB_PATH=%s does not exist (it names a prebuilt library; nothing is built for it)" % LIB_PATH)
+        return LIB_PATH
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
         subprocess.check_call(["make", "-C", _CSRC, "-s"])
     return LIB_PATH
@@ -380,7 +386,10 @@ class Engine:
     def comm_init(self, rank, nranks, unique_id):
         assert len(unique_id) == 128
         buf = (C.c_char * 128).from_buffer_copy(unique_id)
-        self._ck(self.lib.dne_comm_init(self.h, int(rank), int(nranks), buf))
+        rc = self.lib.dne_comm_init(self.h, int(rank), int(nranks), buf)
+        if rc == -2:   # DNE_COMM_DROPPED: the late path must not touch the handle's error text (another thread owns the handle by now)
+            raise DneError("dne_comm_init: communicator dropped, dne_comm_abort was called while ncclCommInitRank was in flight")
+        self._ck(rc)
         self.comm_size = int(nranks)
 
     def comm_share(self, owner):

@@ -51,41 +51,62 @@ def _server_cfg(redis_cfg):
     return {k: v for k, v in redis_cfg.items() if k != 'transport'}
 
 
+class _Pending(Exception):
+    """raised by an attempt that should be made again"""
+
+
+def _bounded_retry(attempt, what, tries, base_delay):
+    """Call attempt() until it returns; an attempt that raises _Pending is repeated after a pause, at most `tries` attempts in
+    all.  The pause is per process -- between 1x and 2x base_delay, spread by pid -- so that a fleet of workers started
+    together does not knock on the server in step (the behaviour, not the code, of dist.py:27-64).  -> attempt()'s value,
+    or None when every attempt was pending."""
+    pause = base_delay * (9 + os.getpid() % 10) / 9.0
+    for n in range(1, tries + 1):
+        try:
+            return attempt()
+        except _Pending as why:
+            if n == tries:
+                return None
+            logger.warning('%s: %s; attempt %d of %d in %.2f s', what, why, n + 1, tries, pause)
+            time.sleep(pause)
+
+
 def retry_connect(redis_cfg, tries=300, base_delay=4., connect_timeout=None):
-    """dist.py:27-43"""
-    cls, conn_err = _redis_module()
+    """A connection that answered PING, or the carrier's ConnectionError after `tries` refusals (dist.py:27-43)."""
+    client, refused = _redis_module()
     kw = _server_cfg(redis_cfg)
     if connect_timeout is not None:
         kw['socket_connect_timeout'] = connect_timeout
-    for i in range(tries):
+    last = []
+
+    def attempt():
         try:
-            r = cls(**kw)
-            r.ping()
-            return r
-        except conn_err as e:
-            if i == tries - 1:
-                raise
-            delay = base_delay * (1 + (os.getpid() % 10) / 9)
-            logger.warning('Could not connect to {}. Retrying after {:.2f} sec ({}/{}). Error: {}'.format(redis_cfg, delay, i + 2, tries, e))
-            time.sleep(delay)
+            conn = client(**kw)
+            conn.ping()
+            return conn
+        except refused as e:
+            last[:] = [e]
+            raise _Pending('no answer from {} ({})'.format(redis_cfg, e))
+    conn = _bounded_retry(attempt, 'connect', tries, base_delay)
+    if conn is None:
+        raise last[0]
+    return conn
 
 
 def retry_get(r, key, tries=300, base_delay=4.):
-    """dist.py:46-64"""
-    for i in range(tries):
-        if isinstance(key, (list, tuple)):
-            vals = r.mget(key)
-            if all(v is not None for v in vals):
-                return vals
-        else:
-            val = r.get(key)
-            if val is not None:
-                return val
-        if i != tries - 1:
-            delay = base_delay * (1 + (os.getpid() % 10) / 9)
-            logger.warning('{} not set. Retrying after {:.2f} sec ({}/{})'.format(key, delay, i + 2, tries))
-            time.sleep(delay)
-    raise RuntimeError('{} not set'.format(key))
+    """The value of `key` (GET), or of every key of a list / tuple (MGET), once all of them are set; RuntimeError after `tries`
+    looks (dist.py:46-64)."""
+    many = isinstance(key, (list, tuple))
+
+    def attempt():
+        got = r.mget(key) if many else [r.get(key)]
+        if any(v is None for v in got):
+            raise _Pending('{} not set'.format(key))
+        return got if many else got[0]
+    val = _bounded_retry(attempt, 'get', tries, base_delay)
+    if val is None:
+        raise RuntimeError('{} not set'.format(key))
+    return val
 
 
 def _carrier(redis_cfg):

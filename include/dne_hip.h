@@ -176,6 +176,10 @@ int dne_es_update(dne_handle *h, const int64_t *idx, const float *returns_n2, co
  * librccl.so.1 is opened on demand, single-GPU use never touches it. */
 int dne_comm_unique_id(void *out128);
 int dne_comm_init(dne_handle *h, int rank, int nranks, const void *unique_id128);
+/* ncclCommInitRank blocks until every rank arrives: a caller that bounds it runs dne_comm_init on a second host thread and, on
+ * time-out, calls dne_comm_abort from the first.  The late dne_comm_init then returns DNE_COMM_DROPPED (-2) WITHOUT touching the
+ * handle (no error text: dne_last_error is not meaningful for that code); the handle must not be destroyed while it is in flight. */
+#define DNE_COMM_DROPPED (-2)
 /* what the communicator itself reports (ncclCommUserRank / ncclCommCount); without a communicator: rank 0 of 1, *is_rccl = 0.
  * The launcher side of gpu_implementation/neuroevolution/concurrent_worker.py:129-142 (one worker per visible device) asks
  * dne_device_count for the number of HIP devices this process can see. */

@@ -157,6 +157,9 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_W": "4"},   # ... one unit per wave
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_W": "4", "DNE_DUO_SYNC": "2", "DNE_NSUB": "2"},   # ... a barrier every second row block, two windows
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_W": "8"},   # ... and the eight-row form by name
+    {"DNE_FC_SUB": "2", "DNE_FC_SUB_MIN": "2"},                         # the sub-slice fc (k_fc_sub: one wave per 128 / 120-row chain, folded by k_out<.., SUB>) for pairs, two windows
+    {"DNE_FC_SUB": "2", "DNE_FC_SUB_MIN": "2", "DNE_FC_SUB_NSUB": "1", "DNE_FC_SUB_SPW": "2"},   # ... one window, two chains per wave
+    {"DNE_FC_SUB": "2", "DNE_FC_SUB_MIN": "2", "DNE_FC_SUB_SPW": "8"},   # ... a whole quarter per wave
     {"DNE_FC_DUO": "0", "DNE_FC2_MIN": "2", "DNE_FC_TAIL_MAX": "1"},    # the duo path switched off: k_fc2
     {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1"},                      # k_fc<2> streaming kernel
     {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1", "DNE_FC_RB": "2"},    # ... with 2-row batches
@@ -339,6 +342,9 @@ def test_reference_batch_sizes(nref, members, oracle, small_noise):
     {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "0"},                                                    # k_fc_tail<1> (noise-free form: children written out)
     {"DNE_SPEC_MAX": "0", "DNE_FC_QUAD_MAX": "64"},                                                   # k_fc_quad<1>
     {"DNE_SPEC_MAX": "0", "DNE_CONV12T_MAX": "0"},                                                    # k_conv1 + k_conv2 in the tail instead of k_conv12t<false>
+    {"DNE_FC_SUB_MIN": "2"},                                                                          # the mid range's sub-slice fc (k_fc_sub<1, false, false> on written-out children) at every count
+    {"DNE_FC_SUB_MIN": "2", "DNE_FC_SUB_SPW": "4", "DNE_FC_SUB_NSUB": "3"},                           # ... four chains per wave, three windows
+    {"DNE_FC_SUB": "0"},                                                                              # ... and switched off
 ])
 def test_ga_step_kernel_variants_are_bit_exact(knobs, oracle, small_noise, monkeypatch):
     """the GA evaluation (single members, one base vector per parent, final-RAM behaviour characterisation) through the kernel
