@@ -271,10 +271,7 @@ __device__ __forceinline__ void head_body(HeadLds<RENDER> &H, const FwdArgs &A, 
     if (!wait()) return;
     DNE_PHASE(3, 1);
     if (tid < 256) {
-        const float *p = y3t + (size_t)m * 4 * 256 + tid;
-        const float s01 = p[0] + p[256];
-        const float s23 = p[512] + p[768];
-        float t = s01 + s23;
+        float t = fc_combine(y3t, m, tid, A.sub_sums != 0);
         float pvb = sc * fbe;
         const float fb = fbt + pvb;
         t = t + fb;
@@ -572,9 +569,10 @@ struct dne_handle {
     int fc_sub_min = 97, fc_sub_max = 1100;   // DNE_FC_SUB_MIN / _MAX: active groups (all windows) between which it runs
     int fc_sub_nsub = 2;             // DNE_FC_SUB_NSUB: windows of that regime
     int fc_sub_spw = 0;              // DNE_FC_SUB_SPW: sub-slices per wave (1, 2, 4, 8; 0 = by width)
+    int fc_sub_prio = 0;             // DNE_FC_SUB_PRIO: s_setprio of k_fc_sub's waves (the regime is bound by a window's chain of small kernels: they must not starve)
+    int fc_sub_head = 1;             // DNE_FC_SUB_HEAD: policy head + emulator step in one launch (k_tail_step) behind k_fc_sub instead of k_out + k_env_logic
     bool sub_now = false;            // decided per burst by eval_core
     float *y3s = nullptr;            // [member][32][256]: the chain sums k_fc_sub leaves for k_out<.., SUB>
-    int duo_xcd = 0;                 // DNE_DUO_XCD: k_fc_duo's work items dealt to the XCDs in contiguous ranges (one table range per L2)
     int duo_grid = 0;                // DNE_DUO_GRID: persistent grid of k_fc_duo (0 = fc_grid, doubled for DNE_DUO_W=4)
     int duo_sweep = 2;               // DNE_DUO_SWEEP (0 = off): the four waves of a k_fc_duo workgroup walk one table timeline (1: two units per wave only, 2: also one unit per wave)
     int fc_prio = 3;                 // DNE_FC_PRIO: s_setprio of k_fc_duo's waves (0-3)
@@ -720,6 +718,7 @@ struct dne_handle {
         A.noise = noise; A.bases = bases; A.base_stride = base_stride;
         A.m_slot = m_slot; A.m_off = m_off; A.m_scale = m_scale; A.bn = bn; A.bn_mom = bn_mom;
         A.done = use_done ? done : nullptr; A.L = L;
+        A.sub_sums = sub_now ? 1 : 0;
         if (tt_on) A.tt = tt; else A.tt.n = 0;
         return A;
     }
@@ -974,12 +973,13 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_DUO_W", 4, 8, &h->duo_w);
     if (h->duo_w != 4) h->duo_w = 8;
     env_int("DNE_DUO_GRID", 0, 1 << 16, &h->duo_grid);
-    env_int("DNE_DUO_XCD", 0, 1, &h->duo_xcd);
     env_int("DNE_FC_SUB", 0, 2, &h->fc_sub);
     env_int("DNE_FC_SUB_MIN", 1, 1 << 30, &h->fc_sub_min);
     env_int("DNE_FC_SUB_MAX", 1, 1 << 30, &h->fc_sub_max);
     env_int("DNE_FC_SUB_NSUB", 1, 4, &h->fc_sub_nsub);
     env_int("DNE_FC_SUB_SPW", 0, 8, &h->fc_sub_spw);
+    env_int("DNE_FC_SUB_PRIO", 0, 3, &h->fc_sub_prio);
+    env_int("DNE_FC_SUB_HEAD", 0, 1, &h->fc_sub_head);
     if (h->fc_sub_spw != 1 && h->fc_sub_spw != 2 && h->fc_sub_spw != 4 && h->fc_sub_spw != 8) h->fc_sub_spw = 0;
     env_int("DNE_FCREF_MT8", 0, 1, &h->fcref_mt8);
     env_int("DNE_CONV2_REF_FPW", 1, 8, &h->conv2_ref_fpw);
@@ -1551,16 +1551,17 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         hipLaunchKernelGGL(k_lout, dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->action, logits);
         return;
     }
-    if (h->sub_now && !logits && !out_fused && h->y3s) {   // mid range: one wave per sub-slice chain, folded by the head
+    if (h->sub_now && !logits && h->y3s) {   // mid range: one wave per sub-slice chain, folded by the head
         const int total_waves_at_1 = 32 * count;
         // sub-slices per wave: about 8000 waves (one round of the whole machine) whatever the width
         const int spw = h->fc_sub_spw ? h->fc_sub_spw : count * h->fc_sub_nsub <= 320 ? 1 : count * h->fc_sub_nsub <= 640 ? 2 : count * h->fc_sub_nsub <= 1280 ? 4 : 8;
         const int waves = total_waves_at_1 / spw, blocks = (waves + 3) / 4;
         // eval_core's sub_regime admits exactly two populations: ES pairs and GA children written out
-        if (es) hipLaunchKernelGGL((k_fc_sub<2, true, true>), dim3(blocks), dim3(256), 0, st, A, list, count, spw, (const float *)h->y2, h->y3s);
-        else hipLaunchKernelGGL((k_fc_sub<1, false, false>), dim3(blocks), dim3(256), 0, st, A, list, count, spw, (const float *)h->y2, h->y3s);
-        if (es) hipLaunchKernelGGL((k_out<2, true, true>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3s, h->y3, h->action, (float *)nullptr);
-        else hipLaunchKernelGGL((k_out<1, false, true>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3s, h->y3, h->action, (float *)nullptr);
+        if (es) hipLaunchKernelGGL((k_fc_sub<2, true, true>), dim3(blocks), dim3(256), 0, st, A, list, count, spw, h->fc_sub_prio, (const float *)h->y2, h->y3s);
+        else hipLaunchKernelGGL((k_fc_sub<1, false, false>), dim3(blocks), dim3(256), 0, st, A, list, count, spw, h->fc_sub_prio, (const float *)h->y2, h->y3s);
+        if (out_fused) return;   // the caller runs k_tail_step (FwdArgs::sub_sums tells it to fold the chain sums)
+        if (es) hipLaunchKernelGGL((k_out<2, true>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3s, h->y3, h->action, (float *)nullptr);
+        else hipLaunchKernelGGL((k_out<1, false>), dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3s, h->y3, h->action, (float *)nullptr);
         return;
     }
     if (count <= h->fc_tail_max) {   // latency-bound regime: 4 workgroups per group + a separate output-layer kernel
@@ -1587,11 +1588,11 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         const int duo_grid = h->duo_grid ? h->duo_grid : (w4 ? 2 * h->fc_grid : h->fc_grid);
         const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 4 * rounds - 1) / (4 * rounds), blocks = std::min(items, duo_grid);
         const size_t out_lds = (size_t)h->out_lds_kb * 1024;   // an LDS reservation nobody uses: it only bounds k_out's workgroups per CU next to the streaming fc
-        if (w4) hipLaunchKernelGGL((k_fc_duo<2, true, true, 4>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14) | (h->duo_xcd << 16));
-        else if (es && sweep) hipLaunchKernelGGL((k_fc_duo<2, true, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14) | (h->duo_xcd << 16));
-        else if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14) | (h->duo_xcd << 16));
-        else if (sweep) hipLaunchKernelGGL((k_fc_duo<1, false, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14) | (h->duo_xcd << 16));
-        else hipLaunchKernelGGL((k_fc_duo<1, false>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14) | (h->duo_xcd << 16));
+        if (w4) hipLaunchKernelGGL((k_fc_duo<2, true, true, 4>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
+        else if (es && sweep) hipLaunchKernelGGL((k_fc_duo<2, true, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
+        else if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
+        else if (sweep) hipLaunchKernelGGL((k_fc_duo<1, false, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
+        else hipLaunchKernelGGL((k_fc_duo<1, false>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
         if (after_stream_kernel) hipEventRecord(after_stream_kernel, st);
         if (out_fused) return;   // the caller runs k_tail_step: policy head + emulator step in one launch
         if (es) hipLaunchKernelGGL((k_out<2, true>), dim3(count), dim3(256), out_lds, st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
@@ -1815,7 +1816,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 if (chain && last_fc) HCHECK(h, hipStreamWaitEvent(sst, last_fc, 0));
                 if (pe) { e[1] = ne++; HCHECK(h, hipEventRecord(h->event(e[1]), sst)); }   // after the wait: brackets fc only
                 if (pe) e[2] = ne++;
-                const bool duo_head = duo_win && h->duo_head_fused;   // the table-ordered fc leaves partial sums: head + emulator in one launch
+                const bool duo_head = (duo_win && h->duo_head_fused) || (h->sub_now && h->fc_sub_head);   // the fc leaves partial sums: head + emulator in one launch
                 launch_fc(h, lst, cnt, gsize, nullptr, sst, tail || duo_head, h->duo_now ? h->unit_order + 4 * lo : nullptr,
                           pe && duo_win ? h->event(e[2]) : nullptr);   // duo: the bracket ends behind k_fc_duo, before k_out
                 if (chain) { last_fc = h->fc_ring[fc_ring_pos++ % h->fc_ring.size()]; HCHECK(h, hipEventRecord(last_fc, sst)); }
@@ -1836,8 +1837,9 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 } else if (duo_head) {
                     const FwdArgs A = h->fwd(false);
                     const int items = cnt * gsize;
-                    if (h->L.kind == DNE_KIND_ES) hipLaunchKernelGGL((k_tail_step<true, false>), dim3(items), dim3(h->head_threads), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
-                    else hipLaunchKernelGGL((k_tail_step<false, false>), dim3(items), dim3(h->head_threads), 0, sst, A, E, lst, gsize, tslimit, (const float *)h->y3t, h->y3, h->action);
+                    const float *sums = h->sub_now ? h->y3s : h->y3t;
+                    if (h->L.kind == DNE_KIND_ES) hipLaunchKernelGGL((k_tail_step<true, false>), dim3(items), dim3(h->head_threads), 0, sst, A, E, lst, gsize, tslimit, sums, h->y3, h->action);
+                    else hipLaunchKernelGGL((k_tail_step<false, false>), dim3(items), dim3(h->head_threads), 0, sst, A, E, lst, gsize, tslimit, sums, h->y3, h->action);
                     if (!(h->dbg_skip & 4))
                         hipLaunchKernelGGL(k_env_render, dim3(items), dim3(items <= 192 ? 1024 : h->render_threads), 0, sst, E, lst, gsize, 0, 1);
                 } else launch_env_step(h, E, lst, cnt, gsize, tslimit, sst);

@@ -52,6 +52,7 @@ struct FwdArgs {
     float *bn;               // [members][608]: s1[16] h1[16] s2[32] h2[32] s3[256] h3[256]
     float *bn_mom;           // [members][608]: the batch moments behind them, mean / variance in the same layout (snapshots)
     const int32_t *done;     // per member, step mode only
+    int sub_sums;            // the fc left 32 chain sums per column (k_fc_sub: y3s[member][32][256]) instead of 4 quarter sums: the head folds them
     Layout L;
     TailTable tt;
 };
@@ -60,6 +61,28 @@ constexpr int OB_BYTES = 84 * 84 * 4;
 // fc sub-slices within a quarter of 968 rows (oracle ORC_FC_SUB): the first has 128 rows, the other seven 120 -- every boundary is
 // a multiple of 8 rows.  A kernel that walks a quarter row by row keeps the running left fold T: at a boundary T (+)= chain, chain = 0.
 constexpr int FC_SUB0 = 128, FC_SUBN = 120;
+// the fc output of column `col` before the bias, from what the fc kernels leave behind: 4 quarter sums [member][4][256], or -- behind
+// k_fc_sub -- the 32 chain sums [member][32][256], a quarter being the LEFT FOLD of its 8 (oracle fc_raw); then (q0 + q1) + (q2 + q3)
+__device__ __forceinline__ float fc_combine(const float *__restrict__ sums, int member, int col, bool sub) {
+    float q[4];
+    if (sub) {
+        const float *p = sums + (size_t)member * 32 * 256 + col;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float f = p[(8 * k) * 256];
+#pragma unroll
+            for (int i = 1; i < 8; i++) f = f + p[(8 * k + i) * 256];
+            q[k] = f;
+        }
+    } else {
+        const float *p = sums + (size_t)member * 4 * 256 + col;
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[k] = p[k * 256];
+    }
+    const float s01 = q[0] + q[1];
+    const float s23 = q[2] + q[3];
+    return s01 + s23;
+}
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment
 typedef float f4a __attribute__((ext_vector_type(4)));
 
@@ -1556,6 +1579,10 @@ __device__ __forceinline__ void gload4_after(f32x4 &dst, unsigned voff, const fl
                  : [d] "+v"(dst), "+v"(a0), "+v"(a1) : [vo] "v"(voff), [sb] "s"(sbase), [of] "n"(OFF));
 }
 template <int N>
+__device__ __forceinline__ void wait_rows(f32x4 &a, f32x4 &b) {
+    asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(a), "+v"(b) : [n] "n"(N));
+}
+template <int N>
 __device__ __forceinline__ void wait_rows(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d) {   // at most N loads still in flight afterwards
     asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : [n] "n"(N));
 }
@@ -1604,7 +1631,6 @@ __global__ __launch_bounds__(256, W == 8 ? 2 : 4) void k_fc_duo(FwdArgs A, const
         if (sw_sync == 1 || sw_t % sw_sync == 0) __builtin_amdgcn_s_barrier();
     };
     const int rounds = SWEEP ? ((lag >> 14) & 3) + 1 : 1;   // SWEEP: duos a wave takes one after the other on the workgroup's timeline
-    const bool xcd_map = (lag >> 16) & 1;   // DNE_DUO_XCD: workgroups of one XCD (blockIdx % 8) take a contiguous range of work items = one table range per L2
     lag &= 255;
     const int n_duos = solo ? n_units : (n_units + 1) >> 1, n_items = (n_duos + 4 * rounds - 1) / (4 * rounds);
     typedef DuoSide<NV> Side;
@@ -1632,10 +1658,9 @@ __global__ __launch_bounds__(256, W == 8 ? 2 : 4) void k_fc_duo(FwdArgs A, const
         const long long delta = unit_key(uB) - unit_key(uA);
         return delta < 0 ? 0 : (int)min((long long)NBLK, delta / (256 * W) + lag);
     };
-    const int xcd_chunk = (n_items + 7) >> 3;
-    for (int it = blockIdx.x; it < (xcd_map ? 8 * xcd_chunk : n_items); it += gridDim.x) {
-        const int item = xcd_map ? (it & 7) * xcd_chunk + (it >> 3) : it;
-        if (item >= n_items) continue;
+    // (work items dealt to the XCDs in contiguous ranges -- one table range per L2 -- measured slower: 273.8 vs 264.5 ms per generation;
+    //  a neighbour's rows are read ~100 row blocks apart, long after any cache has dropped them)
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         int sw_tail = 0;
         if constexpr (SWEEP) {
             // plan: the wave's duos of this item (round r: duo (item * rounds + r) * 4 + wave), their lengths in row blocks, the table
@@ -2544,17 +2569,20 @@ __global__ __launch_bounds__(256) void k_fc_cols(FwdArgs A, const int *__restric
 // fc slice combine + bias, bn3 + relu, output layer (out_products / out_wave_sums: thread = input k) + first-max argmax from the
 // fc partial sums, one workgroup per group.  The members of a group share base vector and noise slice (antithetic pair).
 // ------------------------------------------------------- sub-slice fc: one wave per (group, sub-slice chain), nothing shared, nothing waited for
-// The mid range (about 100 .. 1000 groups alive): too many groups for the latency kernels, too few for one workgroup per group to
-// fill 256 CUs (k_fc<1>: 250 members = 250 workgroups, 4 KB in flight per wave: 3.9 TB/s at best).  The numerics contract already cuts
-// every output's k-sum into 32 independent chains (4 quarters x 8 sub-slices of 128 / 120 rows, oracle fc_raw), so the chain IS the
-// unit of work here: a wave walks the 128 / 120 rows of ONE sub-slice (or of `spw` consecutive ones) with whole 1 KB rows per load
-// instruction (lane = 4 columns), RB rows in flight, no LDS, no barrier, and stores the chain's 256 sums to y3s[member][32][256];
-// the head (k_out<.., SUB>) folds them in the oracle's order.  250 members = 8000 waves: the whole machine streams.
+// The mid range (about 100 .. 800 groups alive): too many groups for the latency kernels, too few for one workgroup per group to
+// fill 256 CUs (k_fc<1>: 250 members = 250 workgroups, 4 KB in flight per wave).  The numerics contract already cuts every output's
+// k-sum into 32 independent chains (4 quarters x 8 sub-slices of 128 / 120 rows, oracle fc_raw), so the chain IS the unit of work
+// here: a wave walks the rows of ONE sub-slice (or of `spw` consecutive ones) with whole 1 KB rows per load instruction (lane = 4
+// columns) through k_fc_duo's rolling window -- W rows per stream always in flight, each row's registers refilled the moment it is
+// consumed, no LDS, no barrier -- and stores the chain's 256 sums to y3s[member][32][256]; the head (FwdArgs::sub_sums) folds them in
+// the oracle's order.  250 members = 8000 waves: the whole machine streams.  The block behind a chain's last one is fetched and never
+// used: it lies inside the member's own parameter slice (the next sub-slice, or fc bias / bn3 / output layer behind the fc matrix).
 template <int NV, bool HAS_BN, bool NOISE>
 __global__ __launch_bounds__(256) void k_fc_sub(FwdArgs A, const int *__restrict__ list, int n_groups, int spw /* sub-slices per wave: 1, 2, 4, 8 */,
-                                                const float *__restrict__ y2, float *__restrict__ y3s /*[member][32][256]*/) {
-    constexpr int RB = 8;
+                                                int prio, const float *__restrict__ y2, float *__restrict__ y3s /*[member][32][256]*/) {
+    constexpr int W = 8;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const unsigned voff = lane * 16;
     const Layout &L = A.L;
     const int upg = 32 / spw;   // waves per group
     const int w = uni(blockIdx.x * 4 + wv);
@@ -2567,14 +2595,16 @@ __global__ __launch_bounds__(256) void k_fc_sub(FwdArgs A, const int *__restrict
         for (int v = 0; v < NV; v++) all_done &= uni(A.done[g * NV + v]) != 0;
         if (all_done) return;
     }
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     const int m0 = g * NV;
     const long long off = uni64(A.m_off[m0]);
-    const float *base = A.bases + (size_t)uni(A.m_slot[m0]) * A.base_stride + L.fcw + lane * 4;
-    const float *eps = A.noise + off + L.fcw + lane * 4;
+    const float *base = A.bases + (size_t)uni(A.m_slot[m0]) * A.base_stride + L.fcw;
+    const float *eps = A.noise + off + L.fcw;
     float scale[NV];
 #pragma unroll
     for (int v = 0; v < NV; v++) scale[v] = A.m_scale[m0 + v];
-    __builtin_amdgcn_s_setprio(3);
     for (int s = 0; s < spw; s++) {
         const int u = j * spw + s, q = u >> 3, i = u & 7;
         const int nrows = i == 0 ? FC_SUB0 : FC_SUBN;
@@ -2593,64 +2623,76 @@ __global__ __launch_bounds__(256) void k_fc_sub(FwdArgs A, const int *__restrict
                 }
                 xa[v] = a > 0.0f ? a : 0.0f;
                 xb[v] = b > 0.0f ? b : 0.0f;
+                // finished BEFORE the first row load is issued: left to itself the compiler finishes them in the middle of the
+                // window's first fill and drains the rows already requested (s_waitcnt vmcnt(0)) to do so
+                asm volatile("" : "+v"(xa[v]), "+v"(xb[v]));
             }
         }
-        const float *th = base + (size_t)R0 * 256;
-        const float *ep = eps + (size_t)R0 * 256;
-        float acc[NV][4];
+        const float *tnext = base + (size_t)R0 * 256;   // wave-uniform: the chain's next row block
+        const float *enext = eps + (size_t)R0 * 256;
+        f32x2 acc[NV][2];
 #pragma unroll
-        for (int v = 0; v < NV; v++)
+        for (int v = 0; v < NV; v++) acc[v][0] = acc[v][1] = f32x2{0.0f, 0.0f};
+        f32x4 t[W], e[NOISE ? W : 1];
 #pragma unroll
-            for (int c = 0; c < 4; c++) acc[v][c] = 0.0f;
-        f4a t_cur[RB], t_nxt[RB];
-        f4u e_cur[NOISE ? RB : 1], e_nxt[NOISE ? RB : 1];
+        for (int r = 0; r < W; r++) t[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < RB; r++) {
-            t_cur[r] = *(const f4a *)(th + r * 256);
-            if (NOISE) e_cur[r] = *(const f4u *)(ep + r * 256);
-        }
-        const int nb = nrows / RB;   // 16 or 15 row blocks
+        for (int r = 0; r < (NOISE ? W : 1); r++) e[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int PENDING = (W - 1) * (NOISE ? 2 : 1);
+        auto refill = [&](auto ii) {
+            constexpr int I = decltype(ii)::value;
+            if constexpr (NOISE) {
+                if constexpr (NV == 2) gload4_after<(I % 4) * 1024>(e[I], voff, enext + (I / 4) * 1024, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+                else gload4_after<(I % 4) * 1024>(e[I], voff, enext + (I / 4) * 1024, acc[0][0], acc[0][1]);
+                gload4<(I % 4) * 1024>(t[I], voff, tnext + (I / 4) * 1024);
+            } else {
+                if constexpr (NV == 2) gload4_after<(I % 4) * 1024>(t[I], voff, tnext + (I / 4) * 1024, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+                else gload4_after<(I % 4) * 1024>(t[I], voff, tnext + (I / 4) * 1024, acc[0][0], acc[0][1]);
+            }
+        };
+        static_for<W>(refill);
+        tnext += W * 256; enext += W * 256;
+        const int nb = nrows / W;   // 16 or 15 row blocks
         for (int b = 0; b < nb; b++) {
-            if (b + 1 < nb) {
+            const int li = (b & 7) * W;
+            float xs[NV];   // rows 0 .. 63 of the chain come from xa, the rest from xb
 #pragma unroll
-                for (int r = 0; r < RB; r++) {
-                    t_nxt[r] = *(const f4a *)(th + ((b + 1) * RB + r) * 256);
-                    if (NOISE) e_nxt[r] = *(const f4u *)(ep + ((b + 1) * RB + r) * 256);
-                }
-            }
-            const bool first = b < 8;   // rows 0 .. 63 of the chain come from xa
-            const int li = (b & 7) * RB;
-#pragma unroll
-            for (int r = 0; r < RB; r++) {
+            for (int v = 0; v < NV; v++) xs[v] = b < 8 ? xa[v] : xb[v];
+            auto one = [&](auto ii) {
+                constexpr int I = decltype(ii)::value;
+                wait_rows<PENDING>(t[I], e[NOISE ? I : 0]);
+                const f32x2 tlo = {t[I][0], t[I][1]}, thi = {t[I][2], t[I][3]};
 #pragma unroll
                 for (int v = 0; v < NV; v++) {
-                    const float x = lane_bcast(first ? xa[v] : xb[v], li + r);
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        float wgt = t_cur[r][c];
-                        if (NOISE) {
-                            const float pv = scale[v] * e_cur[r][c];   // fl(theta + fl(scale * eps)): es.py:412-419's two roundings
-                            wgt = wgt + pv;
-                        }
-                        acc[v][c] = __builtin_fmaf(x, wgt, acc[v][c]);
+                    const float x = lane_bcast(xs[v], li + I);
+                    const f32x2 xx = {x, x};
+                    f32x2 wl = tlo, wh = thi;
+                    if constexpr (NOISE) {   // fl(theta + fl(scale * eps)): es.py:412-419's two roundings
+                        const f32x2 sc = {scale[v], scale[v]}, elo = {e[I][0], e[I][1]}, ehi = {e[I][2], e[I][3]};
+                        const f32x2 pl = sc * elo, ph = sc * ehi;
+                        wl = tlo + pl; wh = thi + ph;
                     }
+                    acc[v][0] = __builtin_elementwise_fma(xx, wl, acc[v][0]);
+                    acc[v][1] = __builtin_elementwise_fma(xx, wh, acc[v][1]);
                 }
-            }
-#pragma unroll
-            for (int r = 0; r < RB; r++) {
-                t_cur[r] = t_nxt[r];
-                if (NOISE) e_cur[r] = e_nxt[r];
-            }
+                __builtin_amdgcn_sched_barrier(0);
+                refill(ii);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            static_for<W>(one);
+            tnext += W * 256; enext += W * 256;
         }
 #pragma unroll
+        for (int r = 0; r < W; r++) wait_rows<0>(t[r], e[NOISE ? r : 0]);   // the over-fetched block: nothing in flight into dead registers
+#pragma unroll
         for (int v = 0; v < NV; v++) {
-            const f4a o = {acc[v][0], acc[v][1], acc[v][2], acc[v][3]};
+            const f4a o = {acc[v][0][0], acc[v][0][1], acc[v][1][0], acc[v][1][1]};
             *(f4a *)(y3s + ((size_t)(m0 + v) * 32 + u) * 256 + lane * 4) = o;
         }
     }
 }
 
-template <int NV, bool HAS_BN, bool SUB = false>
+template <int NV, bool HAS_BN>
 __global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ list, const float *__restrict__ y3t,
                                             float *__restrict__ y3, int32_t *__restrict__ actions,
                                             float *__restrict__ logits_out) {
@@ -2677,26 +2719,7 @@ __global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ 
 #pragma unroll
     for (int v = 0; v < NV; v++) {
         const int m = m0 + v;
-        float t;
-        if constexpr (SUB) {   // behind k_fc_sub: the 32 chain sums of the column; a quarter = the left fold of its 8 (oracle fc_raw)
-            const float *p = y3t + (size_t)m * 32 * 256 + tid;
-            float qs[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                float f = p[(8 * q) * 256];
-#pragma unroll
-                for (int i = 1; i < 8; i++) f = f + p[(8 * q + i) * 256];
-                qs[q] = f;
-            }
-            const float s01 = qs[0] + qs[1];
-            const float s23 = qs[2] + qs[3];
-            t = s01 + s23;
-        } else {
-            const float *p = y3t + (size_t)m * 4 * 256 + tid;
-            const float s01 = p[0] + p[256];
-            const float s23 = p[512] + p[768];
-            t = s01 + s23;
-        }
+        float t = fc_combine(y3t, m, tid, A.sub_sums != 0);
         float pvb = sc[v] * fb_e;
         const float fb = fb_t + pvb;
         t = t + fb;

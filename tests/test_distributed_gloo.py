@@ -227,3 +227,79 @@ def test_nses_two_ranks_gloo_bit_identical():
     assert eng.get_theta().tobytes() == out[0][1]
     rec = np.frombuffer(out[0][2][1], es.RECORD)
     assert (rec["aux"] > 0).all()                      # novelty, not sign-returns
+
+
+# ------------------------------------------------------------------------------------------------ bench.py's own launcher, 4 and 8 ranks
+def _launch_oracle_ranks(tmp_path, world, mode, n_pairs, tsl, nref):
+    """bench.launch_ranks (the pipes, RANK / WORLD_SIZE / MASTER_* of the ranks) with tests/rank_stub_oracle.py as the rank"""
+    import argparse
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ["STUB_OUT"] = str(tmp_path)
+    try:
+        args = argparse.Namespace(gpus=world, single_device=True, transport="gloo")
+        rc = bench.launch_ranks(args, child_argv=[sys.executable, os.path.join(ROOT, "tests", "rank_stub_oracle.py"), mode, str(n_pairs), str(tsl),
+                                                  str(nref)], check_devices=False)
+    finally:
+        del os.environ["STUB_OUT"]
+    assert rc == 0
+    return [json.load(open(tmp_path / ("r%d.json" % r))) for r in range(world)]
+
+
+@pytest.mark.timeout(900)
+def test_eight_ranks_full_population_shards(tmp_path):
+    """SURVEY 8e at the driver's width: 2500 pairs over 8 ranks = shards of 313 / 312 (round-robin), one all-gather of 32-byte
+    records (gloo here), the redundant update -- every rank ends with the same records and the same theta; the gathered array is in
+    global pair order whatever rank produced an entry (spot-checked against a one-rank evaluation of those pairs)."""
+    from dne_hip import es
+    n_pairs, tsl, nref = 2500, 3, 4
+    out = _launch_oracle_ranks(tmp_path, 8, "es", n_pairs, tsl, nref)
+    assert [o["mine"] for o in out] == [313] * 4 + [312] * 4 and [o["evaluated"] for o in out] == [o["mine"] for o in out]
+    assert all(o["n_records"] == n_pairs for o in out)
+    assert len({o["records"] for o in out}) == 1 and len({o["theta"] for o in out}) == 1
+    # pairs 0, 1, 2 belong to ranks 0, 1, 2; the last two to ranks (2498 % 8, 2499 % 8) = (2, 3): re-derive them on one engine
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    from oracle_engine import OracleEngine
+    from dne_hip import policies
+    eng = OracleEngine(0, ref_count=nref)
+    eng.noise_upload(np.random.RandomState(123).randn(2_500_000).astype(np.float32))
+    eng.set_theta(policies.xavier_flat(18, 0)); eng.set_ref_batch(O.get_ref_batch(seed=0, batch_size=nref))
+    want = np.zeros(n_pairs, es.RECORD)
+    for r in (0, 1, 2, 3):
+        mine, idx, seeds = es.generation_inputs(2_500_000, eng.P, n_pairs, 0, r, 8)
+        sel = [k for k, g in enumerate(mine) if g in (0, 1, 2, 2498, 2499)]
+        for k in sel:
+            ret, sg, ln = eng.es_eval(idx[k:k + 1], 0.02, tsl, seeds[2 * k:2 * k + 2])
+            want[mine[k]] = es.pack_records(idx[k:k + 1], ret, ln, sg)[0]
+    assert want[:3].tobytes().hex() == out[0]["first"] and want[-2:].tobytes().hex() == out[0]["last"]
+
+
+@pytest.mark.timeout(900)
+def test_four_ranks_nses_through_the_launcher(tmp_path):
+    """BASELINE config 4 is defined on 4 GPUs: NSR-ES with the population sharded 4 ways (novelty in the records' aux slot,
+    nses.py:384; blend + update on every rank, nses.py:217-228) through bench.py's launcher -- identical records and theta on the
+    four ranks, equal to a one-rank run of the same generation."""
+    from dne_hip import es, nses
+    n_pairs, tsl, nref = 22, 8, 8                     # shards of 6, 6, 5, 5
+    out = _launch_oracle_ranks(tmp_path, 4, "nses", n_pairs, tsl, nref)
+    assert [o["mine"] for o in out] == [6, 6, 5, 5] and len({o["records"] for o in out}) == 1 and len({o["theta"] for o in out}) == 1
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import hashlib
+    import oracle as O
+    from oracle_engine import OracleEngine
+    from dne_hip import policies
+    eng = OracleEngine(0, ref_count=nref, bc_max_steps=tsl)
+    eng.noise_upload(np.random.RandomState(123).randn(2_500_000).astype(np.float32))
+    eng.set_theta(policies.xavier_flat(18, 0)); eng.set_ref_batch(O.get_ref_batch(seed=0, batch_size=nref))
+    rs = np.random.RandomState(77)
+    archive = [rs.randint(0, 256, (n, 128)).astype(np.uint8) for n in (9, 4, 10)]
+    full = np.zeros(n_pairs, es.RECORD)
+    for r in range(4):
+        mine, idx, seeds = es.generation_inputs(2_500_000, eng.P, n_pairs, 0, r, 4)
+        ret, _, ln = eng.es_eval(idx, 0.02, tsl, seeds)
+        full[mine] = es.pack_records(idx, ret, ln, eng.novelty_batch(archive, ln, 2).astype(np.float32).reshape(-1, 2))
+    assert hashlib.sha256(full.tobytes()).hexdigest() == out[0]["records"]
+    nses.blend_and_update(eng, full, "nsr", "centered_sign_rank", 0.005, OPT)
+    assert hashlib.sha256(eng.get_theta().tobytes()).hexdigest() == out[0]["theta"]
