@@ -426,7 +426,7 @@ def launch_ranks(args, child_argv=None, check_devices=True):
 
 
 # ------------------------------------------------------------------------------------------------ the extra workloads
-def run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, transport_records, tslimit, want_cpu, small):
+def run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, transport_records, tslimit, want_cpu, small, cpu_ref=None):
     """BASELINE configs 1, 3, 4, 5 (tools/workloads.py), each timed on its own; a failure of one is reported in its slot.
     small (--extra-small, the tests): the same code paths at a population of 96 / 48 children / two games."""
     import workloads as W
@@ -451,10 +451,20 @@ def run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, t
         leg("ga_large", lambda: W.ga_large(noise, device_id=local_rank, tslimit=tslimit, **ga_kw))
     leg("nses", lambda: W.nses(noise, transport=transport_bytes, **shared, **ns_kw))
     leg("sweep", lambda: W.six_games(noise, transport=transport_records, **shared, **sw_kw))
+    ns_in = out.get("nses", {}).pop("_cpu_inputs", None)      # arrays for the CPU leg, not part of the report
     if rank == 0 and want_cpu:
+        # the CPU legs of the extras run at the worker count the headline sweep found best (cpu_ref), on bounded samples
+        procs = (cpu_ref or {}).get("cores") or None
         if "ga" in out and "error" not in out["ga"]:
             crumb("extra: ga cpu baseline")
-            out["ga"]["cpu_baseline"] = W.cpu_ga(noise.noise, 0.005, tslimit, 18, children=ga_kw.get("children", 1000))
+            out["ga"]["cpu_baseline"] = W.cpu_ga(noise.noise, 0.005, tslimit, 18, children=ga_kw.get("children", 1000), procs=procs)
+        if ns_in is not None and "error" not in out["nses"]:
+            crumb("extra: nses cpu baseline")
+            out["nses"]["cpu_baseline"] = W.cpu_nses(noise.noise, ns_in["theta"], ns_in["ref"], ns_in["archive"], ns_in["k"], 0.02, tslimit, 18,
+                                                     n_pairs_total=ns_kw.get("pop", 5000) // 2, procs=procs, sample_pairs=4 if small else None)
+        if "sweep" in out and "error" not in out["sweep"]:
+            crumb("extra: sweep cpu baseline")
+            out["sweep"]["cpu_baseline"] = W.cpu_sweep(noise.noise, out["sweep"]["games"], cpu_ref, tslimit, procs, sample_pairs=4 if small else None)
         leg("config1", lambda: W.config1_cpu(noise.noise, tslimit=tslimit, sample_pairs=2 if small else 8))
     return out
 
@@ -619,10 +629,14 @@ def run_rank(args):
     for x in which:
         if x not in EXTRAS:
             raise SystemExit("--extra: unknown workload %r (choose from %s)" % (x, ", ".join(EXTRAS)))
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # before the extras: their CPU legs reuse the worker count it finds
+        crumb("cpu baseline")
+        cpu = cpu_baseline(noise.noise, theta0, ref, config.noise_stdev, args.tslimit, 18)
     extra = None
     if which:
         extra = run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, transport, args.tslimit,
-                           not args.no_cpu_baseline, args.extra_small)
+                           not args.no_cpu_baseline, args.extra_small, cpu_ref=cpu)
 
     if rank == 0:
         value = total_steps / wall
@@ -702,9 +716,14 @@ def run_rank(args):
         out["theta_abs_sum_after"] = theta_sum
         if extra is not None:
             out["extra"] = extra
-        if world == 1 and not args.no_cpu_baseline:
-            crumb("cpu baseline")
-            out["cpu_baseline"] = cpu_baseline(noise.noise, theta0, ref, config.noise_stdev, args.tslimit, 18)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["cpu_baseline"]["gpu_over_cpu"] = value / cpu["value"]
+            out["cpu_baseline"]["note"] = ("the GPU box grants this container %s CPUs of its %s (cgroup cpu.max / affinity: host); the ratio is against "
+                                           "THAT host share -- per CPU-second the oracle makes %.0f env-steps, so a whole host of %s cores at the "
+                                           "same per-core rate would be about %.0f env-steps/s (memory bandwidth permitting)"
+                                           % (cpu["host"].get("usable_cpus"), cpu["host"].get("os_cpu_count"), cpu["rate_per_cpu_second"],
+                                              cpu["host"].get("physical_cores"), cpu["rate_per_cpu_second"] * (cpu["host"].get("physical_cores") or 0)))
         print(json.dumps(out), flush=True)
     if transport is not None:
         dist.barrier()

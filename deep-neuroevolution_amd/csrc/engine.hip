@@ -569,6 +569,7 @@ struct dne_handle {
     int fc_sub_min = 97, fc_sub_max = 1100;   // DNE_FC_SUB_MIN / _MAX: active groups (all windows) between which it runs
     int fc_sub_nsub = 2;             // DNE_FC_SUB_NSUB: windows of that regime
     int fc_sub_spw = 0;              // DNE_FC_SUB_SPW: sub-slices per wave (1, 2, 4, 8; 0 = by width)
+    int fc_sub_grid = 1024;          // DNE_FC_SUB_GRID: workgroups of k_fc_sub at most (4 waves each; 1024 = four waves per SIMD)
     int fc_sub_prio = 0;             // DNE_FC_SUB_PRIO: s_setprio of k_fc_sub's waves (the regime is bound by a window's chain of small kernels: they must not starve)
     int fc_sub_head = 1;             // DNE_FC_SUB_HEAD: policy head + emulator step in one launch (k_tail_step) behind k_fc_sub instead of k_out + k_env_logic
     bool sub_now = false;            // decided per burst by eval_core
@@ -979,6 +980,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_SUB_NSUB", 1, 4, &h->fc_sub_nsub);
     env_int("DNE_FC_SUB_SPW", 0, 8, &h->fc_sub_spw);
     env_int("DNE_FC_SUB_PRIO", 0, 3, &h->fc_sub_prio);
+    env_int("DNE_FC_SUB_GRID", 1, 1 << 20, &h->fc_sub_grid);
     env_int("DNE_FC_SUB_HEAD", 0, 1, &h->fc_sub_head);
     if (h->fc_sub_spw != 1 && h->fc_sub_spw != 2 && h->fc_sub_spw != 4 && h->fc_sub_spw != 8) h->fc_sub_spw = 0;
     env_int("DNE_FCREF_MT8", 0, 1, &h->fcref_mt8);
@@ -1555,7 +1557,7 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         const int total_waves_at_1 = 32 * count;
         // sub-slices per wave: about 8000 waves (one round of the whole machine) whatever the width
         const int spw = h->fc_sub_spw ? h->fc_sub_spw : count * h->fc_sub_nsub <= 320 ? 1 : count * h->fc_sub_nsub <= 640 ? 2 : count * h->fc_sub_nsub <= 1280 ? 4 : 8;
-        const int waves = total_waves_at_1 / spw, blocks = (waves + 3) / 4;
+        const int waves = total_waves_at_1 / spw, blocks = std::min((waves + 3) / 4, h->fc_sub_grid);
         // eval_core's sub_regime admits exactly two populations: ES pairs and GA children written out
         if (es) hipLaunchKernelGGL((k_fc_sub<2, true, true>), dim3(blocks), dim3(256), 0, st, A, list, count, spw, h->fc_sub_prio, (const float *)h->y2, h->y3s);
         else hipLaunchKernelGGL((k_fc_sub<1, false, false>), dim3(blocks), dim3(256), 0, st, A, list, count, spw, h->fc_sub_prio, (const float *)h->y2, h->y3s);

@@ -2585,19 +2585,20 @@ __global__ __launch_bounds__(256) void k_fc_sub(FwdArgs A, const int *__restrict
     const unsigned voff = lane * 16;
     const Layout &L = A.L;
     const int upg = 32 / spw;   // waves per group
-    const int w = uni(blockIdx.x * 4 + wv);
-    if (w >= n_groups * upg) return;
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    // a bounded grid walks the work (DNE_FC_SUB_GRID): at 54 registers the whole launch would otherwise sit on every wave slot of the
+    // chip and the other window's convolutions / renderer / head -- the links of ITS lock-step chain -- wait for a slot behind it
+    for (int w = uni(blockIdx.x * 4 + wv); w < n_groups * upg; w += gridDim.x * 4) {
     const int gi = w / upg, j = w - gi * upg;
     const int g = uni(list ? list[gi] : gi);
     if (A.done) {   // finished group still in the list: nobody reads its sums
         int all_done = 1;
 #pragma unroll
         for (int v = 0; v < NV; v++) all_done &= uni(A.done[g * NV + v]) != 0;
-        if (all_done) return;
+        if (all_done) continue;
     }
-    if (prio == 3) __builtin_amdgcn_s_setprio(3);
-    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     const int m0 = g * NV;
     const long long off = uni64(A.m_off[m0]);
     const float *base = A.bases + (size_t)uni(A.m_slot[m0]) * A.base_stride + L.fcw;
@@ -2690,6 +2691,7 @@ __global__ __launch_bounds__(256) void k_fc_sub(FwdArgs A, const int *__restrict
             *(f4a *)(y3s + ((size_t)(m0 + v) * 32 + u) * 256 + lane * 4) = o;
         }
     }
+    }   // persistent loop over the launch's waves' worth of work
 }
 
 template <int NV, bool HAS_BN>

@@ -4,8 +4,9 @@ and the master's reduce/update block (es.py:274-301) replaced by whole-populatio
 
 One GPU worker evaluates its whole shard of antithetic pairs in a single dne_es_eval and pushes ONE Result
 holding n pairs (legal: the master concatenates Results, es.py:274-277).  With several GPUs the shards are
-exchanged as fixed 32-byte records by one all-gather (RCCL through torch.distributed) and every rank runs
-the identical reduce + optimizer step, so theta stays bit-identical without a gradient all-reduce.
+exchanged as fixed 32-byte records by one all-gather (RCCL behind the C ABI: dne_allgather_results; torch.distributed
+only as the gloo carrier of the CPU tests) and every rank runs the identical reduce + optimizer step, so theta stays
+bit-identical without a gradient all-reduce.
 """
 import logging
 import time

@@ -64,6 +64,41 @@ class Schedule(object):
 make_schedule = Schedule.from_config
 
 
+class _LegacySchedule(Schedule):
+    """snapshot.pkl files written before the three schedule classes became one hold TrainingState.mutation_power as an instance of
+    dne_hip.ga_gpu.ConstantSchedule / LinearSchedule / ExponentialSchedule with those classes' own attributes (helper.py:46-82's:
+    _value -- or schedule, field, initial_p, final_p).  These names keep such files loadable: unpickling hands the old attribute
+    dict to __setstate__, which maps it onto Schedule's."""
+    KIND = None
+
+    def __init__(self, *args, **kw):
+        spec = dict(kw, type=type(self).__name__)
+        if args:                                   # the old positional forms: (value) / keyword-only otherwise
+            spec['value'] = args[0]
+        fresh = Schedule.from_config(spec)
+        self.__dict__.update(fresh.__dict__)
+
+    def __setstate__(self, state):
+        if 'kind' in state:                        # written after the merge
+            self.__dict__.update(state)
+        elif self.KIND == 'constant':
+            Schedule.__init__(self, 'constant', state['_value'])
+        else:                                      # the old ExponentialSchedule also carried a helper object (`linear`): not needed
+            Schedule.__init__(self, self.KIND, state['initial_p'], state['final_p'], state['schedule'], state['field'])
+
+
+class ConstantSchedule(_LegacySchedule):
+    KIND = 'constant'
+
+
+class LinearSchedule(_LegacySchedule):
+    KIND = 'linear'
+
+
+class ExponentialSchedule(_LegacySchedule):
+    KIND = 'exponential'
+
+
 # ---------------------------------------------------------------------------------------------- run state (what snapshot.pkl holds)
 class Offspring(object):
     """One evaluated genome (ga.py:88-106): seeds = (idx0, (idx1, power1), ...), the rewards / lengths of its training

@@ -182,3 +182,30 @@ def test_gpu_tree_ga_large_model_on_the_engine_surface(oracle, tmp_path):
     for idx, power in st.elite.seeds[1:]:
         ref = ref + np.float32(power) * noise.noise[idx:idx + P]
     assert np.array_equal(th, ref.astype(np.float32))
+
+
+def test_snapshots_with_the_old_schedule_classes_still_load():
+    """snapshot.pkl of a run made before ga_gpu's three schedule classes became one: TrainingState.mutation_power unpickles from
+    the old class names / attribute dicts into an equivalent Schedule (resume and load_population keep working)"""
+    import math
+    import pickle
+    from dne_hip import ga_gpu
+
+    def old(cls, **attrs):                       # an instance as the old code pickled it: the class by name + its own __dict__
+        o = cls.__new__(cls)
+        o.__dict__.update(attrs)
+        return pickle.loads(pickle.dumps(o))
+    c = old(ga_gpu.ConstantSchedule, _value=0.002)
+    assert c.value(iteration=5) == 0.002 and c.kind == 'constant'
+    lin = old(ga_gpu.LinearSchedule, schedule=100, field='iteration', final_p=0.001, initial_p=0.005)
+    assert lin.value(iteration=50, timesteps_so_far=0) == pytest.approx(0.003) and lin.value(iteration=500) == pytest.approx(0.001)
+    ex = old(ga_gpu.ExponentialSchedule, initial_p=0.01, final_p=0.0001, schedule=10, field='iteration', linear=object.__new__(object))
+    assert ex.value(iteration=5) == pytest.approx(math.exp((math.log(0.01) + math.log(0.0001)) / 2))
+    # a whole state: what main() loads on resume
+    st = ga_gpu.TrainingState({'mutation_power': 0.002, 'episode_cutoff_mode': 5000})
+    st.mutation_power = lin
+    st2 = pickle.loads(pickle.dumps(st))
+    assert st2.sample(st2.mutation_power) == pytest.approx(0.005) and isinstance(st2.mutation_power, ga_gpu.Schedule)
+    # constructing by the old names still works too (experiment files name them)
+    assert ga_gpu.LinearSchedule(schedule=10, field='iteration', final_p=1.0, initial_p=0.0).value(iteration=5) == pytest.approx(0.5)
+    assert ga_gpu.ConstantSchedule(0.5).value() == 0.5

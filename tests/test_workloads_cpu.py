@@ -43,6 +43,9 @@ def test_ga_generations_and_roofline(W):
     assert [g["gen"] for g in r["generations"]] == [0, 1] and all(g["env_steps"] > 0 and g["max_len"] <= 8 for g in r["generations"])
     assert r["value"] == pytest.approx(r["generations"][1]["steps_per_s"])          # generation 0 (root genomes) is not the value
     assert r["roofline"]["achieved"] == pytest.approx(r["value"] * (4 * 1008450 + 28224) / 1e9) and r["roofline"]["traffic"] is None
+    # generations 10 / 100 and the chain of 259 -- synthetic deep genomes, cold and warm parent cache
+    assert [d["chain"] for d in r["deep_chains"]] == [10, 100, 259]
+    assert all(d["cold"]["env_steps"] == d["warm"]["env_steps"] > 0 for d in r["deep_chains"])
 
 
 @pytest.mark.timeout(900)

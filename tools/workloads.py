@@ -59,13 +59,14 @@ def _es_engine(noise, nact, n_pairs, rank, world, device_id, theta_seed, env_see
     env = policies.HipAtariEnv(e, seed=env_seed)
     ref = np.rint(np.stack(es.get_ref_batch(env, 128, np.random.RandomState(ref_seed))) * 255.0).astype(np.uint8)
     e.set_ref_batch(ref)
+    e._bench_ref = ref          # the CPU legs time the oracle on the same reference batch
     e.optimizer_reset()
     return e
 
 
 # ------------------------------------------------------------------------------------------------ config 3
 def ga_small(noise, generations=4, children=1000, parents=20, sigma=0.005, tslimit=5000, nact=18, device_id=0, rank=0, world=1,
-             comm_from=None, transport=None):
+             comm_from=None, transport=None, deep_chains=(10, 100, 259)):
     """es_distributed's Deep GA (ga.py:136-149, 251-271) through dne_hip.ga.ga_generation: generation 0 evaluates 1000 root
     genomes (normc init), the later ones children of the 20 cached parents."""
     from dne_hip import _lib, ga
@@ -85,6 +86,26 @@ def ga_small(noise, generations=4, children=1000, parents=20, sigma=0.005, tslim
             rows.append({"gen": gen, "wall_s": wall, "env_steps": int(ln.sum()), "steps_per_s": float(ln.sum() / wall),
                          "mean_len": float(ln.mean()), "max_len": int(ln.max()), "best": float(score[0]),
                          "rank0_ms": {k: round(p[k], 2) for k in ("eval_ms", "fc_ms", "conv_ms", "env_ms")}})
+        # "measure at generations 1, 10, 100 (chain 258 per display.py:31 as stress)".  A run only reaches such
+        # chains after that many generations, so: a synthetic population of `parents` genomes carrying 10 / 100 / 259 seeds
+        # (RandomState(3)), one generation each on a COLD parent cache (the 20 chains are rebuilt inside the timed call: one streaming
+        # pass per chain) and once more warm.  tests/test_gpu_fullsize_configs.py checks the same form against the oracle.
+        deep = []
+        hi = noise.noise.size - e.P + 1
+        for L in deep_chains:
+            rs = np.random.RandomState(3 + L)
+            popL = [[int(x) for x in rs.randint(0, hi, size=L)] for _ in range(parents)]
+            scL = np.zeros(parents, np.float32)
+            row = {"chain": L}
+            for label in ("cold", "warm"):
+                e.barrier()
+                t0 = time.time()
+                _, _, ln = ga.ga_generation(e, noise.noise.size, sigma, popL, scL, children, parents, 1, 1000 + L, tslimit, rank, world, transport)
+                e.barrier()
+                wall = time.time() - t0
+                row[label] = {"wall_s": wall, "env_steps": int(ln.sum()), "steps_per_s": float(ln.sum() / wall)}
+            row["rebuild_ms"] = 1e3 * (row["cold"]["wall_s"] - row["warm"]["wall_s"])
+            deep.append(row)
         e.check_redzones()
     finally:
         e.close()
@@ -95,7 +116,7 @@ def ga_small(noise, generations=4, children=1000, parents=20, sigma=0.005, tslim
                         "GAAtariPolicy (P=1008450), seed-chain genomes rebuilt on the device" % (children, parents, sigma, tslimit),
             "metric": "env-steps/sec/generation", "value": sps, "unit": "env-steps/s", "n_gpus": world,
             "value_basis": "generations 1..%d (children of cached parents); generation 0 = %d root genomes" % (generations - 1, children),
-            "generations": rows, "roofline": whole_job_roofline(sps, "ga", world)}
+            "generations": rows, "deep_chains": deep, "roofline": whole_job_roofline(sps, "ga", world)}
 
 
 def ga_large(noise, generations=3, children=1000, parents=20, power=0.002, tslimit=5000, nact=18, device_id=0):
@@ -146,6 +167,8 @@ def nses(noise, iterations=2, pop=5000, meta_pop=3, archive_extra=29, k=10, tsli
     cfg = es.Config(**dict(ES_CONFIG, episodes_per_batch=pop, return_proc_mode="centered_sign_rank"))   # configurations/frostbite_nses.json:10
     n_pairs = pop // 2
     e = _es_engine(noise, nact, n_pairs, rank, world, device_id, 0, 0, 0, comm_from, transport, record_bc=True, bc_max_steps=tslimit)
+    ref_batch = e._bench_ref
+    first_theta = None
     try:
         rs = np.random.RandomState(7)
         thetas, opt_state, archive = {}, {}, []
@@ -154,6 +177,8 @@ def nses(noise, iterations=2, pop=5000, meta_pop=3, archive_extra=29, k=10, tsli
             th = policies.xavier_flat(nact, seed=100 + p)
             e.set_theta(th)
             archive.append(N.get_mean_bc(e, tslimit, rs.randint(2 ** 31)))
+            if p == 0:
+                first_theta = th
             if p < meta_pop:
                 thetas[p] = th
                 opt_state[p] = (np.zeros(e.P, np.float32), np.zeros(e.P, np.float32), 0)
@@ -190,7 +215,8 @@ def nses(noise, iterations=2, pop=5000, meta_pop=3, archive_extra=29, k=10, tsli
                                                                                          meta_pop + archive_extra + iterations, tslimit),
             "metric": "env-steps/sec/iteration (rollouts + novelty + exchange + blend + update + parent selection)", "value": sps,
             "unit": "env-steps/s", "n_gpus": world, "iterations": rows, "archive_setup_s": t_setup,
-            "roofline": whole_job_roofline(sps, "es", world)}
+            "roofline": whole_job_roofline(sps, "es", world),
+            "_cpu_inputs": {"theta": first_theta, "ref": ref_batch, "archive": [a.copy() for a in archive[:meta_pop + archive_extra]], "k": k}}
 
 
 # ------------------------------------------------------------------------------------------------ config 5
@@ -312,6 +338,36 @@ def cpu_es(noise, theta, ref, sigma, tslimit, nact, n_pairs_total=2500, procs=No
             "sweep": rows, "host": host_facts()}
 
 
+def _cpu_nses_pair(i):
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import oracle as O
+    noise, theta, ref, sigma, tslimit, nact, idx, seeds, archive, k = _BASE
+    L = O.layout(O.KIND_ES, nact)
+    t0, c0 = time.time(), time.process_time()
+    steps = 0
+    for s in range(2):   # nses.py:371-384: both rollouts keep their RAM trajectory and are scored against the archive
+        th = O.perturb(theta, noise, idx[i], sigma, 1 if s == 0 else -1)
+        _, _, ln, bc = O.rollout(L, th, ref, seeds[2 * i + s], tslimit, want_bc=True)
+        O.novelty(archive, bc, k)
+        steps += ln
+    return int(steps), time.time() - t0, time.process_time() - c0
+
+
+def cpu_nses(noise, theta, ref, archive, k, sigma, tslimit, nact, n_pairs_total=2500, procs=None, sample_pairs=None):
+    """nses.py:318-400's worker on the oracle: an antithetic pair with RAM trajectories + the novelty of both rollouts against the
+    archive; one worker count (the headline sweep's best) unless told otherwise"""
+    global _BASE
+    from dne_hip import es
+    _, idx, seeds = es.generation_inputs(noise.size, theta.size, n_pairs_total, 0, 0, 1)
+    _BASE = (noise, theta, ref, sigma, tslimit, nact, idx, seeds, archive, k)
+    items = (lambda w: sample_pairs) if sample_pairs else (lambda w: min(max(2 * w, 16), 128))
+    rows, best = _cpu_sweep(_cpu_nses_pair, _sweep_counts(procs), n_pairs_total, items)
+    return {"value": best["rate_wall"], "unit": "env-steps/s", "cores": best["workers"], "kind": "port", "cpus_delivered": best["cpus_delivered"],
+            "sample": "first %d antithetic pairs of iteration 0 with trajectories + novelty (k = %d, archive of %d): %d env-steps over %d worker "
+                      "processes, %.1f s wall, %.1f CPU-seconds" % (best["items"], k, len(archive), best["env_steps"], best["workers"],
+                                                                      best["wall_s"], best["cpu_s"]), "sweep": rows}
+
+
 def cpu_ga(noise, sigma, tslimit, nact, children=1000, procs=None, sample=None):
     """ga.py:209-271's worker on the oracle: rebuild a root genome (normc), one episode; the first children of generation 0,
     at the same sweep of worker counts as cpu_es"""
@@ -327,6 +383,29 @@ def cpu_ga(noise, sigma, tslimit, nact, children=1000, procs=None, sample=None):
                       "%.1f CPU-seconds; best worker count of the sweep" % (best["items"], best["env_steps"], best["workers"],
                                                                             best["wall_s"], best["cpu_s"]),
             "sweep": rows}
+
+
+def cpu_sweep(noise, games, cpu_ref, tslimit, procs=None, sample_pairs=None):
+    """config 5 on the CPU: the fixture stands in for every emulator, so the six games are two workloads -- the 18-action network
+    (= the headline's CPU baseline, reused) and Asteroids' 14-action one (timed here) -- combined over the games that ran as
+    total env-steps / total time (equal steps per game)."""
+    from dne_hip import policies
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    rates, rows = {}, {}
+    if cpu_ref:
+        rates[18] = cpu_ref["value"]
+    for nact in sorted({g["n_actions"] for g in games}):
+        if nact in rates:
+            continue
+        gi = [g["game"] for g in games if g["n_actions"] == nact][0]
+        r = cpu_es(noise, policies.xavier_flat(nact, seed=2), O.get_ref_batch(seed=2, batch_size=128, nact=nact), 0.02, tslimit, nact,
+                   procs=procs, sample_pairs=sample_pairs)
+        rates[nact], rows[gi] = r["value"], {k: r[k] for k in ("value", "cores", "cpus_delivered", "sample")}
+    inv = sum(1.0 / rates[g["n_actions"]] for g in games)
+    return {"value": len(games) / inv, "unit": "env-steps/s", "kind": "port", "cores": (cpu_ref or {}).get("cores") or procs,
+            "per_action_count": {str(k): v for k, v in rates.items()}, "timed_here": rows,
+            "sample": "18-action games: the headline's cpu_baseline; other action counts timed here; combined over %d games" % len(games)}
 
 
 def config1_cpu(noise, nact=18, pop=256, sigma=0.02, tslimit=5000, sample_pairs=8):
