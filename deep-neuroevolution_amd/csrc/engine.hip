@@ -974,6 +974,11 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_DUO_W", 4, 8, &h->duo_w);
     if (h->duo_w != 4) h->duo_w = 8;
     env_int("DNE_DUO_GRID", 0, 1 << 16, &h->duo_grid);
+    // measured (tools/ga_lockstep_profile.py, tools/ab_inproc.py --pairs 312 / 625): Deep-GA children 97 .. 320
+    // alive, two windows, a grid of 512 workgroups at wave priority 3; ES pairs 97 .. 450 alive, three windows, the whole launch
+    // resident, no priority (its chain of small kernels must not starve); above those widths the streaming kernels win
+    if (cfg->policy_kind == DNE_KIND_ES) { h->fc_sub = 2; h->fc_sub_max = 450; h->fc_sub_nsub = 3; h->fc_sub_grid = 1 << 20; h->fc_sub_prio = 0; }
+    else { h->fc_sub = 1; h->fc_sub_max = 320; h->fc_sub_nsub = 2; h->fc_sub_grid = 512; h->fc_sub_prio = 3; }
     env_int("DNE_FC_SUB", 0, 2, &h->fc_sub);
     env_int("DNE_FC_SUB_MIN", 1, 1 << 30, &h->fc_sub_min);
     env_int("DNE_FC_SUB_MAX", 1, 1 << 30, &h->fc_sub_max);
