@@ -565,12 +565,12 @@ struct dne_handle {
     int duo_rounds = 1;              // DNE_DUO_ROUNDS: duos per wave and work item of the sweep (1-4)
     int duo_sync = 1;                // DNE_DUO_SYNC: row blocks per barrier of the sweep (1-8)
     int duo_w = 8;                   // DNE_DUO_W: rows in flight per stream of k_fc_duo (8: two waves per SIMD; 4: four)
-    int fc_sub = 1;                  // DNE_FC_SUB: the sub-slice fc (k_fc_sub: one wave per 128 / 120-row chain) in the mid range -- 0 off, 1 GA children (materialised), 2 also ES pairs
-    int fc_sub_min = 97, fc_sub_max = 1100;   // DNE_FC_SUB_MIN / _MAX: active groups (all windows) between which it runs
-    int fc_sub_nsub = 2;             // DNE_FC_SUB_NSUB: windows of that regime
+    int fc_sub = 1;                  // DNE_FC_SUB (ES 2, GA 1): the sub-slice fc (k_fc_sub: one wave per 128 / 120-row chain) in the mid range -- 0 off, 1 GA children (materialised), 2 also ES pairs
+    int fc_sub_min = 97, fc_sub_max = 320;   // DNE_FC_SUB_MIN / _MAX: active groups (all windows) between which it runs (max: 450 for ES pairs, 320 for GA children)
+    int fc_sub_nsub = 2;             // DNE_FC_SUB_NSUB: windows of that regime (ES 3, GA 2)
     int fc_sub_spw = 0;              // DNE_FC_SUB_SPW: sub-slices per wave (1, 2, 4, 8; 0 = by width)
-    int fc_sub_grid = 1024;          // DNE_FC_SUB_GRID: workgroups of k_fc_sub at most (4 waves each; 1024 = four waves per SIMD)
-    int fc_sub_prio = 0;             // DNE_FC_SUB_PRIO: s_setprio of k_fc_sub's waves (the regime is bound by a window's chain of small kernels: they must not starve)
+    int fc_sub_grid = 512;           // DNE_FC_SUB_GRID: workgroups of k_fc_sub at most, 4 waves each (GA 512 = two waves per SIMD; ES: the whole launch resident)
+    int fc_sub_prio = 0;             // DNE_FC_SUB_PRIO: s_setprio of k_fc_sub's waves (ES 0: the regime is bound by a window's chain of small kernels, they must not starve; GA 3 on its bounded grid)
     int fc_sub_head = 1;             // DNE_FC_SUB_HEAD: policy head + emulator step in one launch (k_tail_step) behind k_fc_sub instead of k_out + k_env_logic
     bool sub_now = false;            // decided per burst by eval_core
     float *y3s = nullptr;            // [member][32][256]: the chain sums k_fc_sub leaves for k_out<.., SUB>
