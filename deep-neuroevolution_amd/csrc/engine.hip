@@ -564,7 +564,6 @@ struct dne_handle {
     int conv2_ref_fpw = 8;           // DNE_CONV2_REF_FPW: reference frames per conv2 workgroup (8, 4, or 1 = the lock-step kernel)
     int duo_rounds = 1;              // DNE_DUO_ROUNDS: duos per wave and work item of the sweep (1-4)
     int duo_sync = 1;                // DNE_DUO_SYNC: row blocks per barrier of the sweep (1-8)
-    int fc_lds_ring = 0;             // DNE_FC_RING: the two-units-per-wave regime through k_fc_ring (noise rows shared through an LDS ring, one L1 fetch per workgroup and row)
     int duo_w = 8;                   // DNE_DUO_W: rows in flight per stream of k_fc_duo (8: two waves per SIMD; 4: four)
     int fc_sub = 1;                  // DNE_FC_SUB (ES 2, GA 1): the sub-slice fc (k_fc_sub: one wave per 128 / 120-row chain) in the mid range -- 0 off, 1 GA children (materialised), 2 also ES pairs
     int fc_sub_min = 97, fc_sub_max = 320;   // DNE_FC_SUB_MIN / _MAX: active groups (all windows) between which it runs (max: 450 for ES pairs, 320 for GA children)
@@ -721,7 +720,6 @@ struct dne_handle {
         A.m_slot = m_slot; A.m_off = m_off; A.m_scale = m_scale; A.bn = bn; A.bn_mom = bn_mom;
         A.done = use_done ? done : nullptr; A.L = L;
         A.sub_sums = sub_now ? 1 : 0;
-        A.noise_count = noise_count;
         if (tt_on) A.tt = tt; else A.tt.n = 0;
         return A;
     }
@@ -973,7 +971,6 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_DUO_SWEEP", 0, 2, &h->duo_sweep);
     env_int("DNE_DUO_SYNC", 1, 8, &h->duo_sync);
     env_int("DNE_DUO_ROUNDS", 1, 4, &h->duo_rounds);
-    env_int("DNE_FC_RING", 0, 1, &h->fc_lds_ring);
     env_int("DNE_DUO_W", 4, 8, &h->duo_w);
     if (h->duo_w != 4) h->duo_w = 8;
     env_int("DNE_DUO_GRID", 0, 1 << 16, &h->duo_grid);
@@ -1598,8 +1595,7 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         const int duo_grid = h->duo_grid ? h->duo_grid : (w4 ? 2 * h->fc_grid : h->fc_grid);
         const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 4 * rounds - 1) / (4 * rounds), blocks = std::min(items, duo_grid);
         const size_t out_lds = (size_t)h->out_lds_kb * 1024;   // an LDS reservation nobody uses: it only bounds k_out's workgroups per CU next to the streaming fc
-        if (h->fc_lds_ring && es && sweep && !solo) hipLaunchKernelGGL((k_fc_ring<true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->fc_prio);
-        else if (w4) hipLaunchKernelGGL((k_fc_duo<2, true, true, 4>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
+        if (w4) hipLaunchKernelGGL((k_fc_duo<2, true, true, 4>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
         else if (es && sweep) hipLaunchKernelGGL((k_fc_duo<2, true, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
         else if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
         else if (sweep) hipLaunchKernelGGL((k_fc_duo<1, false, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));

@@ -52,7 +52,6 @@ struct FwdArgs {
     float *bn;               // [members][608]: s1[16] h1[16] s2[32] h2[32] s3[256] h3[256]
     float *bn_mom;           // [members][608]: the batch moments behind them, mean / variance in the same layout (snapshots)
     const int32_t *done;     // per member, step mode only
-    size_t noise_count;      // floats in the table (k_fc_ring clamps its look-ahead fetches to it)
     int sub_sums;            // the fc left 32 chain sums per column (k_fc_sub: y3s[member][32][256]) instead of 4 quarter sums: the head folds them
     Layout L;
     TailTable tt;
@@ -1920,309 +1919,6 @@ __global__ __launch_bounds__(256, W == 8 ? 2 : 4) void k_fc_duo(FwdArgs A, const
         }   // rounds
         if constexpr (SWEEP)
             for (int i = 0; i < sw_tail; i++) sw_tick();
-    }
-}
-
-// ------------------------------------------------------- table-ordered fc, noise rows shared through LDS (round 4)
-// What bounds k_fc_duo is the CU's vector-memory path: per timeline tick a workgroup's eight units pull 8 x 8 KB of
-// noise rows through L1 although, in table lock-step, they all read from one window of <= 4096 table floats that advances by 2048
-// per tick.  Here that window lives in LDS: a ring of three 2048-float segments (+ a mirror of the first behind the last, so that a
-// tick's reads never wrap), every wave fetching a quarter of the NEXT segment per tick -- 8 KB per workgroup and tick through L1
-// instead of 64 KB -- and every unit reading its eight rows from the ring at its own float offset.  The offset is any integer
-// (es.py:67), and gfx950 reads LDS conflict-free only at a lane stride of one dword, so a lane owns columns l, l+64, l+128, l+192
-// (ds_read2st64_b32: two of them per instruction) and the base rows follow that mapping (four 4-byte loads per row, W = 4 rows in
-// flight per side).  Same rows, same k order, same roundings per column as every other fc variant: a schedule, not arithmetic.
-// Timeline: tick t covers table floats [fcw + F0 + 2048 t, + 4096) (segments t and t + 1); unit u starts at tick (key_u - F0) / 2048
-// with phase (key_u - F0) % 2048 and takes 121 ticks; one s_barrier per tick publishes segment t + 2.  Two-units-per-wave regime only.
-constexpr int RG_SEG = 2048, RG_RING = 3 * RG_SEG, RG_EXT = RG_RING + RG_SEG;   // [6144, 8192) mirrors [0, 2048)
-
-template <int N>
-__device__ __forceinline__ void rg_wait(float &a, float &b, float &c, float &d, float &e, float &f, float &g, float &h) {
-    asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) : [n] "n"(N));
-}
-// the four 4-byte loads of one base row in the stride-1 mapping, pinned behind the accumulator updates of the row they replace
-template <int ROW_OFF>
-__device__ __forceinline__ void rg_theta_row(float (&t)[4], unsigned voff4, const float *sbase, f32x2 &a0, f32x2 &a1, f32x2 &a2, f32x2 &a3) {
-    asm volatile("global_load_dword %[t0], %[vo], %[sb] offset:%[o0]\n global_load_dword %[t1], %[vo], %[sb] offset:%[o1]\n"
-                 " global_load_dword %[t2], %[vo], %[sb] offset:%[o2]\n global_load_dword %[t3], %[vo], %[sb] offset:%[o3]"
-                 : [t0] "+v"(t[0]), [t1] "+v"(t[1]), [t2] "+v"(t[2]), [t3] "+v"(t[3]), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3)
-                 : [vo] "v"(voff4), [sb] "s"(sbase), [o0] "n"(ROW_OFF), [o1] "n"(ROW_OFF + 256), [o2] "n"(ROW_OFF + 512), [o3] "n"(ROW_OFF + 768));
-}
-// one noise row of a unit from the ring: columns (l, l+64) and (l+128, l+192) of row I of the tick
-template <int I>
-__device__ __forceinline__ void rg_eps_row(f32x2 &e0, f32x2 &e1, unsigned vaddr) {
-    asm volatile("ds_read2st64_b32 %[a], %[va] offset0:%[o0] offset1:%[o1]\n ds_read2st64_b32 %[b], %[va] offset0:%[o2] offset1:%[o3]"
-                 : [a] "=v"(e0), [b] "=v"(e1) : [va] "v"(vaddr), [o0] "n"(4 * I), [o1] "n"(4 * I + 1), [o2] "n"(4 * I + 2), [o3] "n"(4 * I + 3));
-}
-
-template <bool HAS_BN>
-__global__ __launch_bounds__(256, 2) void k_fc_ring(FwdArgs A, const int *__restrict__ order, int n_units,
-                                                    const float *__restrict__ y2, float *__restrict__ y3t, int prio) {
-    constexpr int NV = 2, W = 4, NT = 968 / 8 /* ticks per unit */, TPC = 8 /* ticks per 64-row activation chunk */;
-    __shared__ __attribute__((aligned(16))) float ring[RG_EXT];
-    __shared__ long long pl_key[2][8];
-    __shared__ int pl_unit[2][8];
-    int par = 0;
-    const int tid = threadIdx.x, wv = uni(tid >> 6), lane = tid & 63;
-    const unsigned voff4 = lane * 4;
-    const unsigned ring_lds = (unsigned)(unsigned long long)(&ring[0]);   // low half of the flat address = the LDS byte offset
-    const Layout &L = A.L;
-    if (prio == 3) __builtin_amdgcn_s_setprio(3);
-    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
-    const int n_duos = (n_units + 1) >> 1, n_items = (n_duos + 3) >> 2;
-    typedef DuoSide<NV> Side;
-    auto finished = [&](int uu) {
-        int all_done = 1;
-#pragma unroll
-        for (int v = 0; v < NV; v++) all_done &= uni(A.done[(uu >> 2) * NV + v]) != 0;
-        return all_done != 0;
-    };
-    auto unit_key = [&](int uu) { return uni64(A.m_off[(size_t)(uu >> 2) * NV]) + (long long)(uu & 3) * SLICE_FLOATS; };
-    // ---- the ring: this wave's quarter (2 x 16 bytes per lane) of segment g, global -> registers -> LDS
-    f32x4 rf[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    const unsigned last16 = (unsigned)((A.noise_count - 4) * sizeof(float));   // byte offset of the last whole 16 bytes of the table
-    auto ring_issue = [&](long long front /* table float index of segment 0 */, int g) {
-        const long long seg = front + (long long)g * RG_SEG + wv * 512;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {   // past the table's end the address is clamped: those floats belong to no unit's rows
-            const long long want = (seg + k * 256 + lane * 4) * (long long)sizeof(float);
-            const unsigned bo = (unsigned)(want < (long long)last16 ? want : (long long)last16);
-            asm volatile("global_load_dwordx4 %[d], %[vo], %[sb]" : [d] "+v"(rf[k]) : [vo] "v"(bo), [sb] "s"(A.noise));
-        }
-    };
-    auto ring_store = [&](int g) {
-        const int slot = g % 3;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            float *dst = ring + slot * RG_SEG + wv * 512 + k * 256 + lane * 4;
-            *(f32x4 *)dst = rf[k];
-            if (slot == 0) *(f32x4 *)(dst + RG_RING) = rf[k];
-        }
-    };
-    auto publish = [&]() {   // the segment just stored becomes visible to the workgroup; nothing of the vector-memory queue is waited for
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        // ---- plan: the item's eight units (wave w: duo 4 item + w), their start ticks and phases against the first key
-        int uA = -1, uB = -1;
-        {
-            const int d = item * 4 + wv;
-            if (d < n_duos) {
-                uA = uni(order[2 * d]);
-                uB = 2 * d + 1 < n_units ? uni(order[2 * d + 1]) : -1;
-                if (A.done) {
-                    if (finished(uA)) uA = -1;
-                    if (uB >= 0 && finished(uB)) uB = -1;
-                }
-                if (uA < 0) { uA = uB; uB = -1; }
-            }
-        }
-        if (lane == 0) {
-            pl_unit[par][2 * wv] = uA; pl_unit[par][2 * wv + 1] = uB;
-            pl_key[par][2 * wv] = uA >= 0 ? unit_key(uA) : 0;
-            pl_key[par][2 * wv + 1] = uB >= 0 ? unit_key(uB) : 0;
-        }
-        __syncthreads();   // also: every wave is past its last ring read of the previous item
-        long long F0 = 0;
-        bool any = false;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int u = uni(pl_unit[par][k]);
-            const long long key = uni64(pl_key[par][k]);
-            if (u >= 0 && (!any || key < F0)) { F0 = key; any = true; }
-        }
-        int tmax = 0, sA = 0, sB = 0, phA = 0, phB = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const int u = uni(pl_unit[par][k]);
-            if (u < 0) continue;
-            const long long d = uni64(pl_key[par][k]) - F0;
-            const int s = (int)(d / RG_SEG), ph = (int)(d % RG_SEG);
-            tmax = max(tmax, s + NT);
-            if (k == 2 * wv) { sA = s; phA = ph; }
-            if (k == 2 * wv + 1) { sB = s; phB = ph; }
-        }
-        par ^= 1;
-        if (!any) continue;   // nothing alive in this item: the same verdict in every wave
-        const bool okA = uA >= 0, okB = uB >= 0;
-        if (!okB) uB = okA ? uA : 0;   // valid addresses for a side that is never computed or stored
-        if (!okA) uA = 0;
-        const long long front = (long long)L.fcw + F0;   // table float index of the timeline's origin
-
-        Side SA, SB;
-        auto init = [&](Side &Z, int uu) {
-            const int g = uu >> 2;
-            Z.sl = uu & 3;
-            const int slot = uni(A.m_slot[g * NV]);
-            Z.tnext = A.bases + (size_t)slot * A.base_stride + L.fcw + (size_t)Z.sl * SLICE_FLOATS;
-            Z.enext = nullptr;
-            const int ch = (8 * Z.sl + lane) & 31;
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                Z.mem[v] = g * NV + v;
-                Z.scale[v] = A.m_scale[Z.mem[v]];
-                Z.s2[v] = HAS_BN ? A.bn[(size_t)Z.mem[v] * 608 + 32 + ch] : 1.0f;
-                Z.h2[v] = HAS_BN ? A.bn[(size_t)Z.mem[v] * 608 + 64 + ch] : 0.0f;
-                Z.xs[v] = y2 + (size_t)Z.mem[v] * 3872 + 968 * Z.sl;
-                Z.acc[v][0] = Z.acc[v][1] = f32x2{0.0f, 0.0f};
-                Z.fold[v][0] = Z.fold[v][1] = f32x2{0.0f, 0.0f};
-                Z.xv[v] = Z.xn[v] = 0.0f;
-            }
-            Z.lb = 0;
-            Z.nb = FC_SUB0 / 8;
-        };
-        init(SA, uA);
-        init(SB, uB);
-        auto request_x = [&](Side &Z, int c) {
-            if (c >= 16) return;
-            unsigned vo = voff4;
-            asm volatile("" : "+v"(vo));
-            const unsigned xoff = c < 15 ? vo : min(vo, 28u);
-#pragma unroll
-            for (int v = 0; v < NV; v++)
-                asm volatile("global_load_dword %[d], %[vo], %[sb]" : [d] "=v"(Z.xn[v]), "+v"(Z.xv[v]) : [vo] "v"(xoff), [sb] "s"(Z.xs[v] + 64 * c));
-        };
-        auto take_x = [&](Side &Z, int c) {
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                asm volatile("" : "+v"(Z.xn[v]));
-                float t = Z.xn[v];
-                if (HAS_BN) {
-                    t = t * Z.s2[v];
-                    t = t + Z.h2[v];
-                }
-                t = t > 0.0f ? t : 0.0f;
-                Z.xv[v] = (c < 15 || lane < 8) ? t : 0.0f;
-            }
-        };
-        float tA[W][4], tB[W][4];
-#pragma unroll
-        for (int i = 0; i < W; i++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) tA[i][c] = tB[i][c] = 0.0f;
-        f32x2 eA[2][2], eB[2][2];
-        auto wait_all = [&]() {   // every vector-memory load of this wave has landed
-#pragma unroll
-            for (int i = 0; i < W; i++) {
-                rg_wait<0>(tA[i][0], tA[i][1], tA[i][2], tA[i][3], tB[i][0], tB[i][1], tB[i][2], tB[i][3]);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rf[0]), "+v"(rf[1]), "+v"(SA.xn[0]), "+v"(SA.xn[1]), "+v"(SB.xn[0]), "+v"(SB.xn[1]));
-        };
-        auto start_side = [&](Side &Z, float (&t)[W][4]) {   // the first W rows of the unit + its first activations; everything landed afterwards
-            request_x(Z, 0);
-            rg_theta_row<0>(t[0], voff4, Z.tnext, Z.acc[0][0], Z.acc[0][1], Z.acc[1][0], Z.acc[1][1]);
-            rg_theta_row<1024>(t[1], voff4, Z.tnext, Z.acc[0][0], Z.acc[0][1], Z.acc[1][0], Z.acc[1][1]);
-            rg_theta_row<2048>(t[2], voff4, Z.tnext, Z.acc[0][0], Z.acc[0][1], Z.acc[1][0], Z.acc[1][1]);
-            rg_theta_row<3072>(t[3], voff4, Z.tnext, Z.acc[0][0], Z.acc[0][1], Z.acc[1][0], Z.acc[1][1]);
-            Z.tnext += W * 256;
-            wait_all();
-            take_x(Z, 0);
-            request_x(Z, 1);
-        };
-        auto end_tick = [&](Side &Z) {
-            Z.tnext += 8 * 256;
-            if (Z.lb % TPC == TPC - 1 && Z.lb + 1 < NT) {
-                take_x(Z, Z.lb / TPC + 1);
-                request_x(Z, Z.lb / TPC + 2);
-            }
-            Z.lb++;
-            if (Z.lb == Z.nb) {   // end of a sub-slice (oracle fc_raw): the chain joins the quarter's left fold and starts again from 0
-                const bool first = Z.nb == FC_SUB0 / 8;
-#pragma unroll
-                for (int v = 0; v < NV; v++)
-#pragma unroll
-                    for (int hf = 0; hf < 2; hf++) {
-                        Z.fold[v][hf] = first ? Z.acc[v][hf] : Z.fold[v][hf] + Z.acc[v][hf];
-                        Z.acc[v][hf] = f32x2{0.0f, 0.0f};
-                    }
-                Z.nb += FC_SUBN / 8;
-            }
-        };
-        auto store = [&](Side &Z) {   // lane's columns l, l+64 (fold[.][0]) and l+128, l+192 (fold[.][1])
-#pragma unroll
-            for (int v = 0; v < NV; v++) {
-                float *o = y3t + ((size_t)Z.mem[v] * 4 + Z.sl) * 256 + lane;
-                o[0] = Z.fold[v][0][0]; o[64] = Z.fold[v][0][1]; o[128] = Z.fold[v][1][0]; o[192] = Z.fold[v][1][1];
-            }
-        };
-        auto row = [&](Side &Z, const f32x2 &e0, const f32x2 &e1, const float (&t)[4], int li) {
-            // an antithetic pair (dne_es_eval: scales +sigma / -sigma exactly): the second member's weight is base - p with the first's p
-            const f32x2 tlo = {t[0], t[1]}, thi = {t[2], t[3]};
-            const f32x2 sc = {Z.scale[0], Z.scale[0]};
-            const f32x2 pl = sc * e0, ph = sc * e1;
-            const float x0 = lane_bcast(Z.xv[0], li), x1 = lane_bcast(Z.xv[1], li);
-            const f32x2 xx0 = {x0, x0}, xx1 = {x1, x1};
-            const f32x2 wl0 = tlo + pl, wh0 = thi + ph, wl1 = tlo - pl, wh1 = thi - ph;
-            Z.acc[0][0] = __builtin_elementwise_fma(xx0, wl0, Z.acc[0][0]);
-            Z.acc[0][1] = __builtin_elementwise_fma(xx0, wh0, Z.acc[0][1]);
-            Z.acc[1][0] = __builtin_elementwise_fma(xx1, wl1, Z.acc[1][0]);
-            Z.acc[1][1] = __builtin_elementwise_fma(xx1, wh1, Z.acc[1][1]);
-        };
-        // one tick of the selected sides: eight rows each; then the ring moves on
-        auto tick = [&](auto da, auto db, int t) {
-            constexpr bool DA = decltype(da)::value, DB = decltype(db)::value;
-            constexpr int S = (DA ? 1 : 0) + (DB ? 1 : 0);
-            const unsigned vA = ring_lds + (unsigned)(((t % 3) * RG_SEG + phA) % RG_RING) * 4 + voff4;
-            const unsigned vB = ring_lds + (unsigned)(((t % 3) * RG_SEG + phB) % RG_RING) * 4 + voff4;
-            const int liA = (SA.lb % TPC) * 8, liB = (SB.lb % TPC) * 8;
-            if (DA) rg_eps_row<0>(eA[0][0], eA[0][1], vA);
-            if (DB) rg_eps_row<0>(eB[0][0], eB[0][1], vB);
-            auto one = [&](auto ii) {
-                constexpr int I = decltype(ii)::value;
-                constexpr int CUR = I & 1, NXT = CUR ^ 1, SL = I & 3;
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(eA[CUR][0]), "+v"(eA[CUR][1]), "+v"(eB[CUR][0]), "+v"(eB[CUR][1]));
-                if constexpr (I < 7) {
-                    if (DA) rg_eps_row<I + 1>(eA[NXT][0], eA[NXT][1], vA);
-                    if (DB) rg_eps_row<I + 1>(eB[NXT][0], eB[NXT][1], vB);
-                }
-                // younger than row I's base-row loads: the other W - 1 rows of every active side, and -- for the rows fetched during
-                // the previous tick -- the two ring loads issued at its end
-                rg_wait<(W - 1) * 4 * S + (I < 4 ? 2 : 0)>(tA[SL][0], tA[SL][1], tA[SL][2], tA[SL][3], tB[SL][0], tB[SL][1], tB[SL][2], tB[SL][3]);
-                if (DA) row(SA, eA[CUR][0], eA[CUR][1], tA[SL], liA + I);
-                if (DB) row(SB, eB[CUR][0], eB[CUR][1], tB[SL], liB + I);
-                __builtin_amdgcn_sched_barrier(0);
-                if (DA) rg_theta_row<(I % 4) * 1024>(tA[SL], voff4, SA.tnext + (I / 4) * 1024, SA.acc[0][0], SA.acc[0][1], SA.acc[1][0], SA.acc[1][1]);
-                if (DB) rg_theta_row<(I % 4) * 1024>(tB[SL], voff4, SB.tnext + (I / 4) * 1024, SB.acc[0][0], SB.acc[0][1], SB.acc[1][0], SB.acc[1][1]);
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            static_for<8>(one);
-            if (DA) end_tick(SA);
-            if (DB) end_tick(SB);
-        };
-        // ---- prime the ring: segments 0 and 1 stored, segment 2 requested
-        ring_issue(front, 0);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rf[0]), "+v"(rf[1]));
-        ring_store(0);
-        ring_issue(front, 1);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rf[0]), "+v"(rf[1]));
-        ring_store(1);
-        ring_issue(front, 2);
-        publish();
-        for (int t = 0; t < tmax; t++) {
-            const bool dA = okA && t >= sA && t < sA + NT, dB = okB && t >= sB && t < sB + NT;
-            if (dA && t == sA) start_side(SA, tA);
-            if (dB && t == sB) start_side(SB, tB);
-            if (dA && dB) tick(std::true_type{}, std::true_type{}, t);
-            else if (dA) tick(std::true_type{}, std::false_type{}, t);
-            else if (dB) tick(std::false_type{}, std::true_type{}, t);
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(rf[0]), "+v"(rf[1]));   // an idle wave still feeds the ring
-            const bool endA = dA && t == sA + NT - 1, endB = dB && t == sB + NT - 1;
-            if (endA || endB) {
-                wait_all();   // the over-fetched rows: nothing in flight into registers that die here
-                if (endA) store(SA);
-                if (endB) store(SB);
-            }
-            // segment t + 2 (requested a tick ago: in an active tick every wait of its second half has long covered it) joins the ring,
-            // segment t + 3 is requested -- every tick, needed or not, so that the vmcnt arithmetic of the rows never changes
-            asm volatile("" : "+v"(rf[0]), "+v"(rf[1]));
-            ring_store(t + 2);
-            ring_issue(front, t + 3);
-            publish();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rf[0]), "+v"(rf[1]));   // the last request lands before the registers are reused
     }
 }
 
