@@ -1601,10 +1601,16 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make
 // W = rows in flight per stream.  W = 8: 198 registers, two waves per SIMD.  W = 4 (round 4): the same bytes in flight per SIMD from
 // twice the waves (<= 128 registers, four waves per SIMD) -- the SQ counters of the W = 8 kernel alone show its waves issuing 17 % of
 // their cycles, stalled on instruction dependencies 41 % and parked (timeline start-up, barriers, loads) 41 %: more waves fill those.
-template <int NV, bool HAS_BN, bool SWEEP = false, int W = 8>
-__global__ __launch_bounds__(256, W == 8 ? 2 : 4) void k_fc_duo(FwdArgs A, const int *__restrict__ order, int n_units,
+// FAT (round 4): the kernel streams as fast from ONE workgroup per CU as from two (alone, 2500 pairs: 1.13 ms on a grid of 256, 1.14 on
+// 512; 2.07 on 128 -- the per-CU vector-memory path is what it saturates), but two of its 198-register workgroups fill a CU's register
+// file and the other windows' convolutions / renderer / head then wait for a slot instead of overlapping.  FAT touches one high
+// accumulation register, which puts the kernel's register footprint past 256 per lane: the hardware then places at most one of its
+// workgroups per CU, whatever window it comes from, and a 199-register k_conv12 workgroup always fits beside it.
+template <int NV, bool HAS_BN, bool SWEEP = false, int W = 8, bool FAT = false>
+__global__ __launch_bounds__(256, FAT ? 1 : W == 8 ? 2 : 4) void k_fc_duo(FwdArgs A, const int *__restrict__ order, int n_units,
                                                 const float *__restrict__ y2, float *__restrict__ y3t, int lag) {
     static_assert(W == 8 || W == 4, "sub-slice boundaries are multiples of 8 rows");
+    if constexpr (FAT) asm volatile("v_accvgpr_write_b32 a71, %0" : : "v"(0) : "a71");
     __shared__ long long sw_key[2][4];            // SWEEP: the waves' first table addresses / row-block counts, double-buffered by item parity
     __shared__ int sw_len[2][4];
     __shared__ int sw_plan[2][4][4][2];           // SWEEP: [parity][wave][round] -> the duo's units (A, B or -1)
