@@ -564,7 +564,7 @@ struct dne_handle {
     int conv2_ref_fpw = 8;           // DNE_CONV2_REF_FPW: reference frames per conv2 workgroup (8, 4, or 1 = the lock-step kernel)
     int duo_rounds = 1;              // DNE_DUO_ROUNDS: duos per wave and work item of the sweep (1-4)
     int duo_sync = 1;                // DNE_DUO_SYNC: row blocks per barrier of the sweep (1-8)
-    int duo_fat = 0;                 // DNE_DUO_FAT: k_fc_duo with a register footprint past 256 per lane = at most one of its workgroups per CU (it streams as fast from one), so the other windows' kernels always find room beside it
+    int duo_fat = 1;                 // DNE_DUO_FAT: k_fc_duo with a register footprint past 256 per lane = at most one of its workgroups per CU (it streams as fast from one), so the other windows' kernels always find room beside it
     int duo_w = 8;                   // DNE_DUO_W: rows in flight per stream of k_fc_duo (8: two waves per SIMD; 4: four)
     int fc_sub = 1;                  // DNE_FC_SUB (ES 2, GA 1): the sub-slice fc (k_fc_sub: one wave per 128 / 120-row chain) in the mid range -- 0 off, 1 GA children (materialised), 2 also ES pairs
     int fc_sub_min = 97, fc_sub_max = 320;   // DNE_FC_SUB_MIN / _MAX: active groups (all windows) between which it runs (max: 450 for ES pairs, 320 for GA children)

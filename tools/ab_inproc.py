@@ -19,6 +19,7 @@ ap.add_argument("--gens", type=int, default=8)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--rounds", type=int, default=2)
 ap.add_argument("--skip", default="", help="comma list of alone,lockstep,gen to leave out")
+ap.add_argument("--idx-align", type=int, default=1, help="timing experiment (fixed-width legs only): noise indices rounded down to a multiple of this")
 a = ap.parse_args()
 skip = set(a.skip.split(","))
 noise = es.SharedNoiseTable()
@@ -52,6 +53,7 @@ def engine(env):
 
 def fixed_width(e, T=6):
     _, idx, seeds = es.generation_inputs(noise.noise.size, e.P, a.pairs, 0, 0, 1)
+    idx = idx - idx % a.idx_align
     e.es_eval(idx, 0.02, T, seeds)
     t = time.time(); e.es_eval(idx, 0.02, T, seeds); wall = time.time() - t
     p = e.profile()
