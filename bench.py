@@ -54,10 +54,13 @@ MFMA_F32_PEAK = 157.3e12                       # MI355X_MICROARCH.md: dense fp32
 # reference pass (virtual batch norm): flops of one reference frame through one member's network (2 * MACs)
 REF_FLOP_PER_FRAME = 2 * (441 * 256 * 16 + 121 * 256 * 32 + 3872 * 256)
 FC_KERNELS = {   # the kernel behind the profiled ("full") fc launches of one evaluation (dne_profile.fc_full_kind)
-    3: "dne::k_fc_duo<2, true, true> (table-ordered streaming fc: a wave takes two (pair, k-slice) units that are neighbours in the noise "
+    4: "dne::k_fc_sub<2, true, true> (the mid range's sub-slice fc: one wave per 128 / 120-row chain of a pair, whole rows per load, eight rows "
+       "per stream in flight, no LDS, no barrier; the head folds the 32 chain sums -- a rank whose share starts below 451 pairs, e.g. N = 8)",
+    3: "dne::k_fc_duo<2, true, true, 8, true> (table-ordered streaming fc: a wave takes two (pair, k-slice) units that are neighbours in the noise "
        "table and walks them in table lock-step, 8 rows per stream in flight; the four waves of a workgroup -- eight adjacent units -- "
-       "walk one table timeline, an s_barrier per row block, so rows several units need reach HBM once; every window "
-       "of a lock-step with >= 800 active pairs on the rank; bn3 + output layer + argmax follow in k_out, outside the timed bracket)",
+       "walk one table timeline, an s_barrier per row block, so rows several units need reach HBM once; one workgroup per CU by register "
+       "footprint; every window of a lock-step with >= 451 active pairs on the rank; bn3 + output layer + argmax follow in k_out, outside the "
+       "timed bracket)",
     2: "dne::k_fc2<true, 4> (streaming fc + bn + out + argmax, two antithetic pairs per work item: every lock-step with "
        ">= 800 active pairs on the rank)",
     1: "dne::k_fc<2, false, true, 4> (streaming fc + bn + out + argmax, one pair per work item: every window with > 96 active "
@@ -96,7 +99,7 @@ def cpu_baseline(noise, theta, ref, sigma, tslimit, n_actions):
     return workloads.cpu_es(noise, theta, ref, sigma, tslimit, n_actions)
 
 
-FC_KERNEL_TAG = {3: "k_fc_duo", 2: "k_fc2", 1: "k_fc<"}
+FC_KERNEL_TAG = {4: "k_fc_sub", 3: "k_fc_duo", 2: "k_fc2", 1: "k_fc<"}
 
 
 def _pmc_profile(kind):

@@ -579,7 +579,7 @@ struct dne_handle {
     int duo_sweep = 2;               // DNE_DUO_SWEEP (0 = off): the four waves of a k_fc_duo workgroup walk one table timeline (1: two units per wave only, 2: also one unit per wave)
     int fc_prio = 3;                 // DNE_FC_PRIO: s_setprio of k_fc_duo's waves (0-3)
     int duo_lag = 0;                 // DNE_DUO_LAG: extra row batches by which the second unit of a duo trails the first
-    int fc_duo = 1, fc_duo_min = 800;   // DNE_FC_DUO / DNE_FC_DUO_MIN: table-ordered fc (k_unit_order + k_fc_duo + k_out) from this many active groups
+    int fc_duo = 1, fc_duo_min = 451;   // DNE_FC_DUO / DNE_FC_DUO_MIN: table-ordered fc (k_unit_order + k_fc_duo + k_out) from this many active groups (round 4: 451, right above the sub-slice fc's range; 800 before -- with one k_fc_duo workgroup per CU a 625-pair share takes 84.5 instead of 88.4 ms per generation)
     bool duo_now = false;            // decided per burst by eval_core (the unit order of each window is rebuilt then)
     int *unit_order = nullptr;       // [4 * groups]: per window, its (group, k-slice) units in noise-table order
     int spec_max = 4;                // DNE_SPEC_MAX: a single window of up to this many members (2 antithetic pairs; round 2: 8 -- the faster tail kernels of round 3 beat speculation at 4 pairs, 47 vs 56 us) steps speculatively -- every action's outcome is worked out under the forward pass; 0 = off
@@ -1002,7 +1002,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_CHAIN_MIN", 1, 1 << 30, &h->fc_chain_min);
     env_int("DNE_FC_RB", 2, 8, &h->fc_rb);
     env_int("DNE_FC_GRID", 1, 1 << 16, &h->fc_grid);
-    for (int s = 1; s < 4; s++) { hipStream_t st; CH(hipStreamCreate(&st)); h->sub_streams.push_back(st); }   // more than four windows measured slower (5 / 6 / 8 at full width: +7.5 / +5.4 / +7.2 %)
+    for (int s = 1; s < 4; s++) { hipStream_t st; CH(hipStreamCreate(&st)); h->sub_streams.push_back(st); }   // more than four windows measured slower (round 3, 5 / 6 / 8 at full width: +7.5 / +5.4 / +7.2 %; round 4 with one k_fc_duo workgroup per CU: +8.4 / +5.9 / +4.4 %)
     make_layout(cfg->policy_kind, cfg->n_actions, &h->L);
     h->M = cfg->max_members;
     h->F = cfg->policy_kind == DNE_KIND_ES ? (cfg->ref_count > 0 ? cfg->ref_count : 128) : 0;
@@ -1896,7 +1896,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     P.env_steps = 0;
     for (int i = 0; i < n; i++) P.env_steps += lengths[i];
     P.fc_full_ms = P.fc_full_launches = P.fc_full_units = 0;
-    P.fc_full_kind = duo_eval ? 3 : fc2_eval ? 2 : 1;
+    P.fc_full_kind = duo_eval ? 3 : fc2_eval ? 2 : sub_regime(groups) ? 4 : 1;   // (an evaluation that STARTS in the sub-slice fc's range: its bracketed launches are k_fc_sub's)
     P.fc_full_union_ms = 0;
     if (prof) {
         HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[0], h->ev_pool[1]));

@@ -29,7 +29,7 @@ for src, dst in (('bench_default.json', 'bench_default.json'), ('bench_driver_cm
                  ('tail_timeline_8.json', 'tail_timeline_8_pairs.json'), ('phase_clock_8.json', 'tail_phase_clock_8_pairs.json'),
                  ('phase_clock_24.json', 'tail_phase_clock_24_pairs.json'), ('ref_bench.json', 'ref_pass.json'),
                  ('ref_bench_one_chunk.json', 'ref_pass_one_chunk.json'), ('ref_pass_one_chunk_kernel_stats.csv', 'ref_pass_one_chunk_kernel_stats.csv'),
-                 ('launch_floor.jsonl', 'launch_floor.jsonl')):
+                 ('launch_floor.jsonl', 'launch_floor.jsonl'), ('valu_rate.jsonl', 'valu_rate.jsonl')):
     if os.path.exists(os.path.join(R, src)):
         shutil.copy(os.path.join(R, src), os.path.join(P, '%s_%s' % (PFX, dst)))
 ks = glob.glob(R + '/stats/**/*kernel_stats.csv', recursive=True)
@@ -39,5 +39,8 @@ if ks:
 
 # the per-regime HBM traffic of the streaming fc kernel (tools/collect_pmc_regimes.sh) -> profiles/<prefix>_pmc.json
 import subprocess
-if os.path.isdir(R + '/pmc_regimes'):
+if os.path.exists(R + '/%s_pmc.json' % PFX):
+    # summarised on the GPU box BEFORE the bench lines were taken (tools/collect_profiles.sh): the very file those lines quote
+    shutil.copy(R + '/%s_pmc.json' % PFX, P + '/%s_pmc.json' % PFX)
+elif os.path.isdir(R + '/pmc_regimes'):
     subprocess.check_call([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'summarize_pmc_regimes.py'), R + '/pmc_regimes', PFX])
