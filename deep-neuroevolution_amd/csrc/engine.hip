@@ -22,6 +22,7 @@
 #include "../../include/dne_hip.h"
 #include "env_synth.h"
 #include "forward.h"
+#include "forward_variants.h"
 #include "forward_large.h"
 #include "reduce.h"
 

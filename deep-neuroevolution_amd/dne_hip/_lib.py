@@ -69,7 +69,7 @@ class Profile(C.Structure):
 
 def build(force=False):
     """Compile libdne_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("engine.hip", "forward.h", "forward_large.h", "reduce.h", "env_synth.h")]
+    srcs = [os.path.join(_CSRC, f) for f in ("engine.hip", "forward.h", "forward_variants.h", "forward_large.h", "reduce.h", "env_synth.h")]
     srcs.append(os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include", "dne_hip.h"))
     if os.environ.get("DNE_LIB_PATH"):
         # another build of the same ABI was asked for by name: `make` only knows the in-tree library, so running it here would
