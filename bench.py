@@ -455,6 +455,15 @@ def run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, t
     leg("nses", lambda: W.nses(noise, transport=transport_bytes, **shared, **ns_kw))
     leg("sweep", lambda: W.six_games(noise, transport=transport_records, **shared, **sw_kw))
     ns_in = out.get("nses", {}).pop("_cpu_inputs", None)      # arrays for the CPU leg, not part of the report
+    # the legs that run the ES network stream through the same kernel as the headline: price their whole-job rate at the bytes per
+    # member-step the committed PMC summary holds for it (bench_mix regime) -- the streaming kernel's counted traffic, not the whole job's
+    per_unit, src, regime = _pmc_traffic(3, 1000.0)
+    for name in ("nses", "sweep"):
+        r = out.get(name, {}).get("roofline")
+        if r and per_unit:
+            r["traffic"] = out[name]["value"] * per_unit / 1e9
+            r["traffic_unit"] = "GB/s of counted k_fc_duo bytes at this leg's env-steps/s (%s, %s)" % (src, (regime or "").split(":")[0])
+            r["frac_counter"] = out[name]["value"] * per_unit / (HBM_PEAK * world)
     if rank == 0 and want_cpu:
         # the CPU legs of the extras run at the worker count the headline sweep found best (cpu_ref), on bounded samples
         procs = (cpu_ref or {}).get("cores") or None
