@@ -565,6 +565,7 @@ struct dne_handle {
     int conv2_ref_fpw = 8;           // DNE_CONV2_REF_FPW: reference frames per conv2 workgroup (8, 4, or 1 = the lock-step kernel)
     int duo_rounds = 1;              // DNE_DUO_ROUNDS: duos per wave and work item of the sweep (1-4)
     int duo_sync = 1;                // DNE_DUO_SYNC: row blocks per barrier of the sweep (1-8)
+    int burst = 32, burst_tail = 16; // DNE_BURST / DNE_BURST_TAIL: lock-steps between two compactions of the active list (a host round trip each), at large / with at most fc_tail_max groups alive (round 4: 32 at large, 16 before; 24 / 32 / 48 measured -0.5 .. -0.9 %, 8 +2.3 %, 64 +0.2 %; the tail indifferent)
     int duo_fat = 1;                 // DNE_DUO_FAT: k_fc_duo with a register footprint past 256 per lane = at most one of its workgroups per CU (it streams as fast from one), so the other windows' kernels always find room beside it
     int duo_w = 8;                   // DNE_DUO_W: rows in flight per stream of k_fc_duo (8: two waves per SIMD; 4: four)
     int fc_sub = 1;                  // DNE_FC_SUB (ES 2, GA 1): the sub-slice fc (k_fc_sub: one wave per 128 / 120-row chain) in the mid range -- 0 off, 1 GA children (materialised), 2 also ES pairs
@@ -974,6 +975,8 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_DUO_SYNC", 1, 8, &h->duo_sync);
     env_int("DNE_DUO_ROUNDS", 1, 4, &h->duo_rounds);
     env_int("DNE_DUO_FAT", 0, 1, &h->duo_fat);
+    env_int("DNE_BURST", 1, 256, &h->burst);
+    env_int("DNE_BURST_TAIL", 1, 256, &h->burst_tail);
     env_int("DNE_DUO_W", 4, 8, &h->duo_w);
     if (h->duo_w != 4) h->duo_w = 8;
     env_int("DNE_DUO_GRID", 0, 1 << 16, &h->duo_grid);
@@ -1700,7 +1703,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     hipLaunchKernelGGL(k_iota, dim3((groups + 255) / 256), dim3(256), 0, h->stream, h->list_a, groups);
     HCHECK(h, hipStreamSynchronize(h->stream));
 
-    // One global list of active groups, compacted every burst of 16 lock-steps.  Within a burst the list is cut
+    // One global list of active groups, compacted every burst of 32 lock-steps (16 in the tail).  Within a burst the list is cut
     // into nsub equal windows, each stepped on its own stream, so that while one window streams its noise slices
     // (HBM) the others run their MFMA convolutions and emulator frames.  nsub follows the active count:
     // two free-running streams at full width, three in the mid range (where no single kernel fills the chip),
@@ -1757,7 +1760,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     const bool fc2_eval = h->fc_pairs == 2 && gsize == 2 && h->L.kind == DNE_KIND_ES && h->uniform_base && groups >= h->fc2_min_total;
     const bool duo_eval = !h->large && h->fc_duo && (h->L.kind == DNE_KIND_ES ? gsize == 2 : (gsize == 1 && h->fc_duo_ga)) && groups >= h->fc_duo_min;
     while (total > 0 && t < tslimit) {
-        const int burst = std::min(16, tslimit - t);
+        const int burst = std::min(total <= h->fc_tail_max ? h->burst_tail : h->burst, tslimit - t);   // lock-steps until the next compaction
         const int nsub = pick_nsub(total);
         h->fc2_now = h->fc_pairs == 2 && total >= h->fc2_min_total;
         h->duo_now = !h->large && h->fc_duo && (h->L.kind == DNE_KIND_ES ? gsize == 2 : (gsize == 1 && h->fc_duo_ga)) && total >= h->fc_duo_min &&

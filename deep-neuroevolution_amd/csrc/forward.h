@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ l
         const int g = list ? list[item] : item;
 #pragma unroll
         for (int v = 0; v < NV; v++) { member[v] = g * NV + v; row[v] = member[v]; }
-        if (A.done) {   // finished group still in the list (compaction runs every 16 lock-steps): nothing to compute
+        if (A.done) {   // finished group still in the list (compaction runs every 32 lock-steps): nothing to compute
             bool all_done = true;
 #pragma unroll
             for (int v = 0; v < NV; v++) all_done = all_done && A.done[member[v]] != 0;

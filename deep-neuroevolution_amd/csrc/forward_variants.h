@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_fc2(FwdArgs A, const int *__restrict__ 
     int nm;
     {
         int g0 = list ? list[i0] : i0, g1 = list ? list[i1] : i1;
-        if (A.done) {   // finished pairs still in the list (compaction runs every 16 lock-steps) are not streamed
+        if (A.done) {   // finished pairs still in the list (compaction runs every 32 lock-steps) are not streamed
             const bool d0 = A.done[2 * g0] && A.done[2 * g0 + 1], d1 = A.done[2 * g1] && A.done[2 * g1 + 1];
             if (d0 && d1) continue;
             if (d0) g0 = g1;

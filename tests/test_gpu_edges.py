@@ -162,6 +162,7 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
     {"DNE_FC_SUB": "2", "DNE_FC_SUB_MIN": "2", "DNE_FC_SUB_SPW": "8"},   # ... a whole quarter per wave
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_FAT": "1"},   # ... the form that the hardware places once per CU (register footprint past 256), two units per wave
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_FAT": "1", "DNE_NSUB": "2"},   # ... one unit per wave, two windows
+    {"DNE_BURST": "5", "DNE_BURST_TAIL": "40"},                         # compaction of the active list every 5 / 40 lock-steps instead of 16
     {"DNE_FC_DUO": "0", "DNE_FC2_MIN": "2", "DNE_FC_TAIL_MAX": "1"},    # the duo path switched off: k_fc2
     {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1"},                      # k_fc<2> streaming kernel
     {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1", "DNE_FC_RB": "2"},    # ... with 2-row batches
