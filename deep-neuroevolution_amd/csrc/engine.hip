@@ -625,6 +625,7 @@ struct dne_handle {
     int ga_materialize = 0;          // DNE_GA_MATERIALIZE: GA children written out once per generation, the streaming fc then reads plain rows (default: on for GA engines)
     bool members_materialized = false;   // the current members are plain vectors (scale 0 everywhere): kernels that have one skip the noise stream
     std::vector<int> child_slots;    // base slots set aside for materialised children
+    int lfc_pad = 2;                 // DNE_LFC_PAD: LargeModel's streamed fc with a padded register footprint -- 1: at most two of its workgroups per CU, 2: one (0: as many as fit, five); same-box 282.5 / 285.2 / 291.2 k env-steps/s at 0 / 1 / 2
     int lfc_cols_max = 96;           // DNE_LFC_COLS_MAX: LargeModel windows of up to this many members use the column-split fc
     bool large = false;              // DNE_KIND_GA_LARGE: y1 [441][32], y2 / y3 [121][64] (conv3 output), y3t = the 512 fc outputs
     float *y1r[2] = {nullptr, nullptr}, *y2r[2] = {nullptr, nullptr}, *y3pr[2] = {nullptr, nullptr};   // reference pass scratch, two ways
@@ -1045,6 +1046,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     h->ga_materialize = cfg->policy_kind == DNE_KIND_ES ? 0 : 1;
     env_int("DNE_GA_MATERIALIZE", 0, 1, &h->ga_materialize);
     env_int("DNE_LFC_COLS_MAX", 0, 1 << 20, &h->lfc_cols_max);
+    env_int("DNE_LFC_PAD", 0, 2, &h->lfc_pad);
     if (h->large) h->fc_rb = 8;      // the streamed LargeModel fc: 8-row batches measured 8 % faster than 4
     env_int("DNE_FC_RB", 2, 8, &h->fc_rb);
     if (cfg->policy_kind == DNE_KIND_ES) h->ga_materialize = 0;   // ES members are antithetic pairs over one theta: nothing to write out
@@ -1558,7 +1560,9 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
             if (h->members_materialized) hipLaunchKernelGGL((k_lfc_cols<false>), dim3(8 * count), dim3(256), 0, st, A, list, (const float *)h->y3, h->y3t);
             else hipLaunchKernelGGL((k_lfc_cols<true>), dim3(8 * count), dim3(256), 0, st, A, list, (const float *)h->y3, h->y3t);
         } else if (h->members_materialized) {
-            if (h->fc_rb == 8) hipLaunchKernelGGL((k_lfc<false, 8>), lg, dim3(256), 0, st, A, list, 2 * count, (const float *)h->y3, h->y3t);
+            if (h->fc_rb == 8 && h->lfc_pad == 1) hipLaunchKernelGGL((k_lfc<false, 8, 1>), lg, dim3(256), 0, st, A, list, 2 * count, (const float *)h->y3, h->y3t);
+            else if (h->fc_rb == 8 && h->lfc_pad == 2) hipLaunchKernelGGL((k_lfc<false, 8, 2>), lg, dim3(256), 0, st, A, list, 2 * count, (const float *)h->y3, h->y3t);
+            else if (h->fc_rb == 8) hipLaunchKernelGGL((k_lfc<false, 8>), lg, dim3(256), 0, st, A, list, 2 * count, (const float *)h->y3, h->y3t);
             else hipLaunchKernelGGL((k_lfc<false, 4>), lg, dim3(256), 0, st, A, list, 2 * count, (const float *)h->y3, h->y3t);
         } else hipLaunchKernelGGL((k_lfc<true, 4>), lg, dim3(256), 0, st, A, list, 2 * count, (const float *)h->y3, h->y3t);
         hipLaunchKernelGGL(k_lout, dim3(count), dim3(256), 0, st, A, list, (const float *)h->y3t, h->action, logits);

@@ -1013,6 +1013,8 @@ __device__ __forceinline__ void out_wave_sums(float (&p)[NS][OUT_NA], int nact, 
 
 // NOISE = false: the members are plain vectors (GA children written out once per generation, scale 0): the noise rows are not
 // streamed at all -- fl(base + fl(0 * eps)) = base -- which halves the bytes of a member-step.
+// (a padded register footprint -- at most three / two of its workgroups per CU instead of four, k_fc_duo's FAT idea -- was measured for the
+//  GA's k_fc<1>: 1000 members 732 / 812 vs 739 us per lock-step, 500 members 398 / 373 vs 403, no gain over a generation; not kept)
 template <int NV, bool SHARED_W, bool HAS_BN, int RB, bool NOISE = true>
 __global__ __launch_bounds__(256) void k_fc(FwdArgs A, const int *__restrict__ list, int n_local, int F, int member0,
                                             const float *__restrict__ y2, float *__restrict__ y3,

@@ -112,9 +112,15 @@ constexpr size_t lconv_mfma_lds_bytes() {
 // of 4 in flight per wave.  The activations are relu(conv3) read 64 rows at a time, one per lane, and broadcast with v_readlane.
 // NOISE = false: every member's vector is materialised (a GA child = its parent + one mutation, written out once per
 // generation by k_materialize_children): the rows are read as they are -- half the bytes of streaming parent and noise rows.
-template <bool NOISE, int RB>
+// PAD (round 4, the lesson of k_fc_duo's FAT form): at 96 registers five of these workgroups fit a CU and the windows' launches together
+// fill every register file -- the convolutions (106 .. 189 registers), k_lout and the renderer of the OTHER windows then wait for a slot
+// instead of running beside the HBM stream.  PAD = 1 / 2 touches a high accumulation register so that at most two / one of its
+// workgroups fit a CU.
+template <bool NOISE, int RB, int PAD = 0>
 __global__ __launch_bounds__(256) void k_lfc(FwdArgs A, const int *__restrict__ list, int n_items, const float *__restrict__ y3,
                                              float *__restrict__ y4) {
+    if constexpr (PAD == 1) asm volatile("v_accvgpr_write_b32 a79, %0" : : "v"(0) : "a79");
+    if constexpr (PAD == 2) asm volatile("v_accvgpr_write_b32 a167, %0" : : "v"(0) : "a167");
     __shared__ float part[4][256];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const Layout &L = A.L;

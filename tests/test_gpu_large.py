@@ -64,11 +64,17 @@ def test_forward_every_layer_bit_exact(large_engine, oracle, big_noise):
         assert np.array_equal(logits[i], ol) and acts[i] == int(np.argmax(ol)), i
 
 
-@pytest.mark.parametrize("materialize", ["1", "0"])
-def test_genomes_evaluated_bit_exact(materialize, oracle, big_noise, monkeypatch):
+@pytest.mark.parametrize("materialize,knobs", [("1", {}), ("0", {}),
+                                               ("1", {"DNE_LFC_COLS_MAX": "0"}),                       # the streamed fc (k_lfc, one workgroup per CU by register footprint: the default above 96 members) at every count
+                                               ("1", {"DNE_LFC_COLS_MAX": "0", "DNE_LFC_PAD": "0"}),   # ... its unpadded form
+                                               ("1", {"DNE_LFC_COLS_MAX": "0", "DNE_LFC_PAD": "1"}),   # ... at most two per CU
+                                               ("0", {"DNE_LFC_COLS_MAX": "0"})])                      # ... parent + noise rows on the fly
+def test_genomes_evaluated_bit_exact(materialize, knobs, oracle, big_noise, monkeypatch):
     """materialize = 1 (default): children written out once per generation, the fc streams plain rows; 0: parent + noise rows on the fly"""
     from dne_hip import _lib, ga_gpu
     monkeypatch.setenv("DNE_GA_MATERIALIZE", materialize)
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
     e = _lib.Engine(_lib.KIND_GA_LARGE, NACT, max_members=16, record_bc=True)
     e.noise_upload(big_noise)
     e.ga_set_init_scale(ga_gpu.model_scale_by(NACT, _lib.KIND_GA_LARGE))
