@@ -648,7 +648,7 @@ def run_rank(args):
     extra = None
     if which:
         extra = run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, transport, args.tslimit,
-                           not args.no_cpu_baseline, args.extra_small, cpu_ref=cpu)
+                           not args.no_cpu_baseline and world == 1, args.extra_small, cpu_ref=cpu)   # CPU legs: rank 0 at N = 1 only
 
     if rank == 0:
         value = total_steps / wall
