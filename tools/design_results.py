@@ -43,7 +43,7 @@ one engine per setting, settings round-robin).  Boxes differ by ±2 %.
 | GA, LargeModel, 1000 children | {ex['ga_large']['value']/1e6:.3f} M env-steps/s (round 3: 0.278; its streamed fc one workgroup per CU too: same-box 282.5 → 291.2 k) | `extra.ga_large` |
 | NS-ES (config 4), pop 5000 | {ex['nses']['value']/1e6:.2f} M env-steps/s per iteration incl. novelty, exchange, blend, update, parent selection | `extra.nses` |
 | six-game sweep (config 5) | {ex['sweep']['value']/1e6:.2f} M env-steps/s over the six games | `extra.sweep` |
-| GPU suite | 125+ tests, ≈ 295 s on the box (incl. the five full-generation parity tests) | `gpurun_out/r04s/pytest_gpu.log` |
+| GPU suite | 130 tests, 300 s on the box (incl. the five full-generation parity tests), smoke, the driver's command | `gpurun_out/r04y/pytest_gpu.log` (`tools/r04_final_check.sh`) |
 
 Not measured: N = 2 / 4 / 8 GPUs (a gpurun box has one; section 8).  Not reached: VERDICT round 3's 2.5 M (this round: +{100*(d['value']/2202065-1):.1f} % on the driver's command;
 what bounds the streaming kernel and the experiments that did not move it are in section 4a), GA ≥ 1.15 M / 190 µs at 250 members (the lock-step there
