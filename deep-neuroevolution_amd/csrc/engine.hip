@@ -561,7 +561,6 @@ struct dne_handle {
     int duo_head_fused = 0;          // DNE_DUO_HEAD_FUSED: behind k_fc_duo the policy head and the emulator step share a launch (k_tail_step) instead of
                                      // k_out + k_env_logic; same-box A/B: 402.7 ms fused, 403.3 separate, 399.8 separate with k_out at two workgroups per CU -> off
     int fc_duo_ga = 0;               // DNE_FC_DUO_GA: the table-ordered fc for GA evaluations too (single members, one base vector per parent); measured slower, off
-    int fcref_mt8 = 0;               // DNE_FCREF_MT8
     int conv2_ref_fpw = 8;           // DNE_CONV2_REF_FPW: reference frames per conv2 workgroup (8, 4, or 1 = the lock-step kernel)
     int duo_rounds = 1;              // DNE_DUO_ROUNDS: duos per wave and work item of the sweep (1-4)
     int duo_sync = 1;                // DNE_DUO_SYNC: row blocks per barrier of the sweep (1-8)
@@ -939,6 +938,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipFuncSetAttribute((const void *)k_conv12t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
     CH(hipFuncSetAttribute((const void *)k_conv12t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Conv12Lds)));
     CH(hipFuncSetAttribute((const void *)k_unit_order, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CH(hipFuncSetAttribute((const void *)k_fc_ref<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FCREF4_LDS));   // the running fold
     CH(hipFuncSetAttribute((const void *)k_lconv_mfma<32, 64, 4, 2, 21, 11, 1, 34, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<32, 4, 2, 11, 34>()));
     CH(hipFuncSetAttribute((const void *)k_lconv_mfma<64, 64, 3, 1, 11, 11, 1, 68, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<64, 3, 1, 11, 68>()));
     CH(hipFuncSetAttribute((const void *)k_lconv_mfma<32, 64, 4, 2, 21, 11, 1, 34, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lconv_mfma_lds_bytes<32, 4, 2, 11, 34>()));
@@ -995,7 +995,6 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_SUB_GRID", 1, 1 << 20, &h->fc_sub_grid);
     env_int("DNE_FC_SUB_HEAD", 0, 1, &h->fc_sub_head);
     if (h->fc_sub_spw != 1 && h->fc_sub_spw != 2 && h->fc_sub_spw != 4 && h->fc_sub_spw != 8) h->fc_sub_spw = 0;
-    env_int("DNE_FCREF_MT8", 0, 1, &h->fcref_mt8);
     env_int("DNE_CONV2_REF_FPW", 1, 8, &h->conv2_ref_fpw);
     env_int("DNE_DUO_SOLO_BELOW", 0, 1 << 30, &h->duo_solo_below);
     env_int("DNE_DUO_HEAD_FUSED", 0, 1, &h->duo_head_fused);
@@ -1065,7 +1064,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     if (h->F) {
         const size_t rr = (size_t)h->ref_chunk * h->F;
         for (int w = 0; w < 2; w++) {
-            CH(h->alloc(&h->y1r[w], rr * 7056, "y1r[w]")); CH(h->alloc(&h->y2r[w], rr * 3872, "y2r[w]")); CH(h->alloc(&h->y3pr[w], rr * 4 * 256, "y3pr[w]"));
+            CH(h->alloc(&h->y1r[w], rr * 7056, "y1r[w]")); CH(h->alloc(&h->y2r[w], rr * Y2_PAD_ROW, "y2r[w]")); CH(h->alloc(&h->y3pr[w], rr * 4 * 256, "y3pr[w]"));
             CH(h->alloc(&h->fr1[w], rr * 2 * 16, "fr1[w]")); CH(h->alloc(&h->fr2[w], rr * 2 * 32, "fr2[w]"));
             CH(hipEventCreateWithFlags(&h->ev_ref[w], hipEventDisableTiming));
         }
@@ -1433,19 +1432,22 @@ static int ref_pass(dne_handle *h, int n) {
         // the convolutions leave per-frame moments behind; scale / shift per member is a 128-term sum per channel
         hipLaunchKernelGGL((k_bn_finalize<16>), dim3((nc * 16 + 255) / 256), dim3(256), 0, st, A, m0, nc, F, (const float *)fr1, 441, 0,
                            h->L.c1b, h->L.bn1b, h->L.bn1g);
-        if (F % 8 == 0 && h->conv2_ref_fpw == 8)
-            hipLaunchKernelGGL((k_conv2_ref<8>), dim3(nc * (F / 8)), dim3(256), 0, st, A, F, m0, (const float *)y1, y2, fr2);
+        const bool mc_fc = F == 16 || F == 32 || F == 64 || F == 128;   // fc on the matrix cores: y2 rows padded to 128 positions
+        if (mc_fc)
+            hipLaunchKernelGGL((k_conv2_ref<16, true>), dim3(nc * (F / 16)), dim3(256), 0, st, A, F, m0, (const float *)y1, y2, fr2);   // 16 frames per workgroup: the prologue (128 weight loads, ~10 us with the dispatch) once per 16
+        else if (F % 8 == 0 && h->conv2_ref_fpw == 8)
+            hipLaunchKernelGGL((k_conv2_ref<8, false>), dim3(nc * (F / 8)), dim3(256), 0, st, A, F, m0, (const float *)y1, y2, fr2);
         else if (F % 4 == 0 && h->conv2_ref_fpw >= 4)
-            hipLaunchKernelGGL((k_conv2_ref<4>), dim3(nc * (F / 4)), dim3(256), 0, st, A, F, m0, (const float *)y1, y2, fr2);
+            hipLaunchKernelGGL((k_conv2_ref<4, false>), dim3(nc * (F / 4)), dim3(256), 0, st, A, F, m0, (const float *)y1, y2, fr2);
         else
             hipLaunchKernelGGL((k_conv2<true>), dim3(nc * F), dim3(256), 0, st, A, (const int *)nullptr, 1, F, m0,
                                (const float *)y1, y2, 1, fr2);
         hipLaunchKernelGGL((k_bn_finalize<32>), dim3((nc * 32 + 255) / 256), dim3(256), 0, st, A, m0, nc, F, (const float *)fr2, 121, 32,
                            h->L.c2b, h->L.bn2b, h->L.bn2g);
-        if (F == 16 || F == 32 || F == 64 || F == 128) {   // matrix-core path
+        if (mc_fc) {   // matrix-core path
             const int grid = (nc + 7) / 8 * 8 * 4;   // (member, quarter) workgroups, those of a member on one XCD
-#define FCREF(MT, NG) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid * NG), dim3(256), 0, st, A, nc, m0, F, (const float *)y2, y3p)
-            if (F == 16) FCREF(1, 1); else if (F == 32) FCREF(2, 1); else if (F == 64) FCREF(4, 1); else if (h->fcref_mt8) FCREF(8, 1); else FCREF(4, 2);   // 128 frames: two groups of 64 (DNE_FCREF_MT8: one group of 128, one wave per SIMD)
+#define FCREF(MT, NG) hipLaunchKernelGGL((k_fc_ref<MT>), dim3(grid * NG), dim3(256), MT == 4 ? FCREF4_LDS : 0, st, A, nc, m0, F, (const float *)y2, y3p)
+            if (F == 16) FCREF(1, 1); else if (F == 32) FCREF(2, 1); else if (F == 64) FCREF(4, 1); else FCREF(4, 2);   // 128 frames: two groups of 64
 #undef FCREF
             hipLaunchKernelGGL(k_bn3_partials, dim3(nc), dim3(256), 0, st, A, m0, F, (const float *)y3p);
         } else {

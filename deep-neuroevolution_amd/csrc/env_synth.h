@@ -22,8 +22,18 @@ namespace dne {
 #ifdef DNE_PHASE_CLOCK
 __device__ long long g_phase[6][128][8];
 #define DNE_PHASE(K, I) do { if (threadIdx.x == 0 && blockIdx.x < 128) dne::g_phase[K][blockIdx.x][I] = (long long)wall_clock64(); } while (0)
+// accumulated form for kernels that loop over frames / stages: time between consecutive DNE_ACC points, summed per slot
+#define DNE_ACC_DECL long long pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long pprev_ = (long long)wall_clock64(); pacc_[7] = pprev_   /* slot 7: the workgroup's start */
+#define DNE_ACC(I) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = (long long)wall_clock64(); pacc_[I] += t_ - pprev_; pprev_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DNE_ACC_STORE(K) DNE_ACC_STORE_EVERY(K, 1)
+// every STRIDE-th workgroup of the launch (the first 128 of them): a sample over the whole launch instead of its first wave; slot 6: the end
+#define DNE_ACC_STORE_EVERY(K, STRIDE) do { if (threadIdx.x == 0 && blockIdx.x % (STRIDE) == 0 && blockIdx.x / (STRIDE) < 128) { pacc_[6] = (long long)wall_clock64(); for (int i_ = 0; i_ < 8; i_++) dne::g_phase[K][blockIdx.x / (STRIDE)][i_] = pacc_[i_]; } } while (0)
 #else
 #define DNE_PHASE(K, I) do { } while (0)
+#define DNE_ACC_DECL do { } while (0)
+#define DNE_ACC(I) do { } while (0)
+#define DNE_ACC_STORE(K) do { } while (0)
+#define DNE_ACC_STORE_EVERY(K, STRIDE) do { } while (0)
 #endif
 
 // RAM map (DESIGN.md "SynthAtari")

@@ -61,6 +61,7 @@ constexpr int OB_BYTES = 84 * 84 * 4;
 // fc sub-slices within a quarter of 968 rows (oracle ORC_FC_SUB): the first has 128 rows, the other seven 120 -- every boundary is
 // a multiple of 8 rows.  A kernel that walks a quarter row by row keeps the running left fold T: at a boundary T (+)= chain, chain = 0.
 constexpr int FC_SUB0 = 128, FC_SUBN = 120;
+constexpr int FCREF4_LDS = 16 * 256 * 16;   // k_fc_ref<4>: the running fold over the sub-slices, [16 accumulators][256 threads] 16-byte words
 // the fc output of column `col` before the bias, from what the fc kernels leave behind: 4 quarter sums [member][4][256], or -- behind
 // k_fc_sub -- the 32 chain sums [member][32][256], a quarter being the LEFT FOLD of its 8 (oracle fc_raw); then (q0 + q1) + (q2 + q3)
 __device__ __forceinline__ float fc_combine(const float *__restrict__ sums, int member, int col, bool sub) {
@@ -85,6 +86,12 @@ __device__ __forceinline__ float fc_combine(const float *__restrict__ sums, int 
 }
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment
 typedef float f4a __attribute__((ext_vector_type(4)));
+
+// f(integral_constant<int, 0>{}) ... f(integral_constant<int, N - 1>{}): a loop whose index is a constant expression in the body
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct Item {
     int member, row;
@@ -524,11 +531,20 @@ __global__ __launch_bounds__(256) void k_conv2(FwdArgs A, const int *__restrict_
 // (k_conv2<true> with one frame per workgroup re-read 64 KB of theta + eps for every 28 KB of activations), and the next
 // frame's conv1 output is fetched into registers under the MFMAs of the current one.  Same tiles, same MFMA order, same
 // moment tree as conv2_body -- same bits.
-template <int FPW>
+// Round 4 (the profiling build's phase clock, tools/ref_phase_clock.py): per frame the workgroup spent 4.3 us in its MFMAs, 2.7 us in
+// the 180 instructions of the epilogue behind them (16 predicated stores, the tile moments) and 0.8 us staging the next image --
+// beside a wave of the CU's other workgroup that streams MFMAs, an instruction outside one's own MFMA stream is issued about once
+// per MFMA (32 cycles).  So the epilogue of frame f now travels INSIDE the MFMA stream of frame f + 1 (a copy of the accumulators,
+// one basic block: the stores are unconditional -- PAD: y2 rows are 128 positions apart and the seven positions past the layer's
+// end land in the padding --, every lane group writes the wave's tile sums; __builtin_amdgcn_sched_group_barrier deals one or two
+// of those instructions behind each MFMA), and the staging moves 16 bytes per load and packs its arithmetic.  A schedule: same
+// MFMAs in the same order per accumulator, same moments, same bits.
+constexpr int Y2_PAD_ROW = 128 * 32;   // floats between the y2 rows of the reference pass when the fc runs on the matrix cores
+template <int FPW, bool PAD>
 __global__ __launch_bounds__(256, 2) void k_conv2_ref(FwdArgs A, int F, int member0, const float *__restrict__ y1 /*[n_local * F][441][16]*/,
-                                                   float *__restrict__ y2 /*[n_local * F][121][32]*/,
+                                                   float *__restrict__ y2 /*[n_local * F][121 (PAD: 128)][32]*/,
                                                    float *__restrict__ fr /*[n_local * F][2][32]*/) {
-    constexpr int PS = C2_PS, RW = C2_RW;
+    constexpr int PS = C2_PS, RW = C2_RW, Y2S = PAD ? Y2_PAD_ROW : 3872;
     __shared__ Conv2Lds S;
     float (&a_s)[24 * C2_RW * C2_PS] = S.a_s;
     float (&wsum)[4][2][16] = S.wsum;
@@ -539,17 +555,21 @@ __global__ __launch_bounds__(256, 2) void k_conv2_ref(FwdArgs A, int F, int memb
     const float *eps = A.noise + A.m_off[member] + A.L.c2w;
     const float sc = A.m_scale[member];
     const float *bn = A.bn + (size_t)member * 608;
-    float yv[28];
+    // staging: thread = four consecutive channels (c0 .. c0 + 3, fixed: 256 % 4 == 0) of pixels (tid >> 2) + 64 j
+    f32x4 yv[7];
     auto fetch = [&](int f) {
-        const float *src = y1 + ((size_t)mloc * F + f) * 7056;
+        const f32x4 *src = (const f32x4 *)(y1 + ((size_t)mloc * F + f) * 7056);
 #pragma unroll
-        for (int j = 0; j < 28; j++) {
+        for (int j = 0; j < 7; j++) {
             const int e = tid + 256 * j;
-            yv[j] = e < 7056 ? src[e] : 0.0f;
+            yv[j] = e < 1764 ? src[e] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     fetch(f0);
-    const float s1 = bn[tid & 15], h1 = bn[16 + (tid & 15)];
+    const int c0 = (tid & 3) * 4;
+    float s1[4], h1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { s1[i] = bn[c0 + i]; h1[i] = bn[16 + c0 + i]; }
     float b[64];
 #pragma unroll
     for (int kk = 0; kk < 64; kk++) {
@@ -571,21 +591,23 @@ __global__ __launch_bounds__(256, 2) void k_conv2_ref(FwdArgs A, int F, int memb
         const int p = min((mt0 + m) * 16 + lp, 120);
         off[m] = ((p / 11) * 2 * RW + (p % 11) * 2) * PS + lk;
     }
-    for (int fi = 0; fi < FPW; fi++) {
+    auto stage = [&]() {
 #pragma unroll
-        for (int j = 0; j < 28; j++) {
+        for (int j = 0; j < 7; j++) {
             const int e = tid + 256 * j;
-            if (e < 7056) {
-                const int c = e & 15, pix = e >> 4;
-                float t = yv[j] * s1;
-                t = t + h1;
-                t = t > 0.0f ? t : 0.0f;
-                a_s[((pix / 21 + 1) * RW + pix % 21 + 1) * PS + c] = t;
+            if (e < 1764) {
+                const int pix = e >> 2;
+                float *d = a_s + ((pix / 21 + 1) * RW + pix % 21 + 1) * PS + c0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float t = yv[j][i] * s1[i];
+                    t = t + h1[i];
+                    d[i] = t > 0.0f ? t : 0.0f;
+                }
             }
         }
-        __syncthreads();
-        if (fi + 1 < FPW) fetch(f0 + fi + 1);        // in flight under the MFMAs below
-        f32x4 acc[4];
+    };
+    auto mfmas = [&](f32x4 (&acc)[4]) {
 #pragma unroll
         for (int m = 0; m < 4; m++) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -603,25 +625,111 @@ __global__ __launch_bounds__(256, 2) void k_conv2_ref(FwdArgs A, int F, int memb
                 }
             }
         }
-        const size_t row = (size_t)mloc * F + f0 + fi;
-        float *o = y2 + row * 3872;
+    };
+    // a frame's results out: y2 rows, and this wave's four tiles' moments in tile order into wsum (every lane group holds the sums)
+    auto epilogue = [&](const f32x4 (&acc)[4], size_t row) {
+        float *o = y2 + row * Y2S;
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {   // D[row = 4*(l>>4) + r][col = l&15]
                 const int pos = (mt0 + m) * 16 + lk * 4 + r;
-                if (pos < 121) o[pos * 32 + nt * 16 + lp] = acc[m][r] + bias;
+                if (PAD || pos < 121) o[pos * 32 + nt * 16 + lp] = acc[m][r] + bias;
             }
         float Ws = 0.0f, Wq = 0.0f;                  // this wave's four tiles in tile order, then (tiles 0-3) + (tiles 4-7)
 #pragma unroll
         for (int m = 0; m < 4; m++) tile_moments(acc[m], (mt0 + m) * 16 + lk * 4, 121, Ws, Wq);
-        if (lk == 0) { wsum[wv][0][lp] = Ws; wsum[wv][1][lp] = Wq; }
-        __syncthreads();                             // also: every wave is done reading this frame's image
+        wsum[wv][0][lp] = Ws;
+        wsum[wv][1][lp] = Wq;
+    };
+    auto frame_moments = [&](size_t row) {
         if (tid < 64) {
             const int k = tid >> 5, c = tid & 31, h = c >> 4, l = c & 15;
             fr[(row * 2 + k) * 32 + c] = wsum[h][k][l] + wsum[h + 2][k][l];
         }
+    };
+    DNE_ACC_DECL;   // profiling build: 0 = prologue + staging, 1 = barrier, 2 = MFMAs (+ the previous frame's epilogue), 3 = barrier + frame moments
+    const size_t row0 = (size_t)mloc * F + f0;
+    f32x4 acc[4], accp[4];
+    for (int fi = 0; fi < FPW; fi++) {
+        stage();
+        DNE_ACC(0);
+        __syncthreads();
+        DNE_ACC(1);
+        if (fi + 1 < FPW) fetch(f0 + fi + 1);        // in flight under the MFMAs below
+        if (fi == 0) {
+            mfmas(acc);
+        } else {
+            // 32 steps of eight MFMAs (two k-groups x four position tiles); behind each, one of the 32 pieces of the previous frame's
+            // epilogue (pieces 0-15: a store; 16-31: a quarter of a tile's moments -- the exchange requested in one piece is read in
+            // the next); the operand reads run two steps ahead through a ring of three register sets.  One fence per step.
+            const size_t prow = row0 + fi - 1;
+            float *o = y2 + prow * Y2S;
+            float Ws = 0.0f, Wq = 0.0f, ts = 0.0f, tq = 0.0f, ts1 = 0.0f, tq1 = 0.0f, xs_ = 0.0f, xq_ = 0.0f;
+            float xr[3][4][2];
+            auto rd = [&](int p, float (&x)[4][2]) {
+                const int oo = ((p >> 3) * RW + ((p >> 1) & 3)) * PS + (p & 1) * 8;
+#pragma unroll
+                for (int m = 0; m < 4; m++) { x[m][0] = a_s[off[m] + oo]; x[m][1] = a_s[off[m] + oo + 4]; }
+            };
+#pragma unroll
+            for (int m = 0; m < 4; m++) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rd(0, xr[0]);
+            rd(1, xr[1]);
+            static_for<32>([&](auto P) {
+                constexpr int p = decltype(P)::value;
+                if constexpr (p + 2 < 32) rd(p + 2, xr[(p + 2) % 3]);
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[p % 3][m][u], b[2 * p + u], acc[m], 0, 0, 0);
+                if constexpr (p < 16) {
+                    constexpr int m = p / 4, r = p % 4;
+                    const int pos = (mt0 + m) * 16 + lk * 4 + r;
+                    if (PAD || pos < 121) o[pos * 32 + nt * 16 + lp] = accp[m][r] + bias;
+                } else {   // tile_moments(accp[m], ...) in four pieces
+                    constexpr int m = (p - 16) / 4, q = (p - 16) % 4;
+                    if constexpr (q == 0) {
+                        float a[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) a[r] = (mt0 + m) * 16 + lk * 4 + r < 121 ? accp[m][r] : 0.0f;
+                        ts = a[0] + a[1];
+                        ts = ts + a[2];
+                        ts = ts + a[3];
+                        tq = a[0] * a[0];
+                        tq = __builtin_fmaf(a[1], a[1], tq);
+                        tq = __builtin_fmaf(a[2], a[2], tq);
+                        tq = __builtin_fmaf(a[3], a[3], tq);
+                    } else if constexpr (q == 1) {
+                        xs_ = __shfl_xor(ts, 16);
+                        xq_ = __shfl_xor(tq, 16);
+                    } else if constexpr (q == 2) {
+                        ts1 = ts + xs_;
+                        tq1 = tq + xq_;
+                        xs_ = __shfl_xor(ts1, 32);
+                        xq_ = __shfl_xor(tq1, 32);
+                    } else {
+                        const float Ts = ts1 + xs_, Tq = tq1 + xq_;
+                        Ws = Ws + Ts;
+                        Wq = Wq + Tq;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            wsum[wv][0][lp] = Ws;
+            wsum[wv][1][lp] = Wq;
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) accp[m] = acc[m];
+        DNE_ACC(2);
+        __syncthreads();                             // every wave is done reading this frame's image; wsum of the previous frame is complete
+        if (fi > 0) frame_moments(row0 + fi - 1);
+        DNE_ACC(3);
     }
+    epilogue(accp, row0 + FPW - 1);
+    __syncthreads();
+    frame_moments(row0 + FPW - 1);
+    DNE_ACC_STORE_EVERY(4, gridDim.x / 128);
 }
 
 // ------------------------------------------------------------------------------- conv1 -> conv2 in one kernel (lock-steps)
@@ -1311,10 +1419,6 @@ __device__ __forceinline__ void wait_rows(f32x4 &a, f32x4 &b, f32x4 &c, f32x4 &d
 // when the front reaches their unit's first row (a wave-uniform count of s_barrier, no fence: the rolling loads stay in flight), and
 // one s_barrier per row block keeps the four in table lock-step, so that all eight units ask for a table row within the same few
 // loads and HBM delivers it once.  A schedule, not arithmetic: same chains, same bits.
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // W = rows in flight per stream.  W = 8: 198 registers, two waves per SIMD.  W = 4 (round 4): the same bytes in flight per SIMD from
 // twice the waves (<= 128 registers, four waves per SIMD) -- the SQ counters of the W = 8 kernel alone show its waves issuing 17 % of
@@ -1654,7 +1758,7 @@ __global__ __launch_bounds__(256, FAT ? 1 : W == 8 ? 2 : 4) void k_fc_duo(FwdArg
 // 44 k-values, weights are formed per lane as theta + sigma*eps straight into the B operand.  The MFMA's
 // k-ordered fmaf chain per slice + the ((s0+s1)+(s2+s3)) + bias combine (k_bn3_partials) are the oracle's order.
 template <int MT>
-__global__ __launch_bounds__(256, MT == 8 ? 1 : 2) void k_fc_ref(FwdArgs A, int n_local, int member0, int F /* reference frames per member: MT * 16 * frame groups */,
+__global__ __launch_bounds__(256, 2) void k_fc_ref(FwdArgs A, int n_local, int member0, int F /* reference frames per member: MT * 16 * frame groups */,
                                                 const float *__restrict__ y2, float *__restrict__ y3p /*[n_local][4][F][256]*/) {
     // One workgroup of 4 waves per (member, quarter, group of MT * 16 frames); wave w owns columns 64w .. 64w+63 as four interleaved
     // 16-column MFMA tiles (tile c = columns 64w + 4*lane + c), so a lane's four B operands of a k-row are one 16-byte load.  8-row
@@ -1681,102 +1785,172 @@ __global__ __launch_bounds__(256, MT == 8 ? 1 : 2) void k_fc_ref(FwdArgs A, int 
     const int kbeg = 968 * sl, col0 = 64 * wv + 4 * lp;
     const float *eps = A.noise + A.m_off[member] + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
     const float *th = A.bases + (size_t)A.m_slot[member] * A.base_stride + L.fcw + (size_t)(kbeg + lk) * 256 + col0;
-    const float *ysrc = y2 + ((size_t)mloc * F + (size_t)fg * FG) * 3872 + kbeg;
+    const float *ysrc = y2 + ((size_t)mloc * F + (size_t)fg * FG) * Y2_PAD_ROW + kbeg;   // padded rows (k_conv2_ref<.., true>)
     if (tid < 64) bn2[tid] = A.bn[(size_t)member * 608 + 32 + tid];   // scale[32] then shift[32]
     // Loads and LDS stores of a unit are unconditional: a unit whose second stage does not exist (the odd stage that ends a
     // sub-slice, the end of the quarter) fetches a clamped stage into a buffer nobody reads.  With the loads under `if (u < n)`
     // the compiler could not pair them with their waits and put s_waitcnt vmcnt(0) between the two stages' loads.
-    float yr[2][LD];
-    f4u er[2][KK];
-    f4a tr[2][KK];
-    auto load_unit = [&](int s0) {
+    // Round 4 (the profiling build's phase clock, tools/ref_phase_clock.py): of a unit's 2.4 us the 64 MFMAs took 0.9 -- issuing the
+    // next unit's twelve loads took 0.7 and storing it (LDS writes, weights) 0.6: beside the CU's other workgroup streaming MFMAs an
+    // instruction outside one's own MFMA stream is issued about once per MFMA.  Now nothing but the barrier sits between two units'
+    // MFMAs: the loads run TWO units ahead through register sets the loop body alternates between, so storing the next unit (its
+    // LDS buffers and its weights, a second set) depends on nothing the current unit does, and both -- load issue and store -- are
+    // dealt in pieces behind the four 8-MFMA chunks of the unit's first stage (one fence per chunk).  The body holds four units:
+    // the register set in flight across the back edge is renamed there by the allocator (v_mov_b64 behind a wait), a quarter of
+    // the sets instead of half.  Tried and dropped: inline-asm loads into `+v` variables (renamed all the same, without the wait:
+    // registers copied before their data arrives), hard-register constraints (copies around every asm), accumulation registers named
+    // in the asm text (the compiler uses them itself as soon as the kernel declares any).
+    constexpr bool FULL = (FG * KC) % 256 == 0;                 // every thread stages LD activations per stage
+    struct Ld { float yr[2][LD]; f4u er[2][KK]; f4a tr[2][KK]; };
+    auto load_stage = [&](Ld &R, int s0, int u) {
+        const int s = s0 + u < NST ? s0 + u : NST - 1;
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int s = s0 + u < NST ? s0 + u : NST - 1;
+        for (int j = 0; j < LD; j++) {
+            const int e = tid + 256 * j;
+            R.yr[u][j] = FULL || e < FG * KC ? ysrc[(size_t)(e / KC) * Y2_PAD_ROW + s * KC + e % KC] : 0.0f;
+        }
 #pragma unroll
-            for (int j = 0; j < LD; j++) {
-                const int e = tid + 256 * j;
-                yr[u][j] = e < FG * KC ? ysrc[(size_t)(e / KC) * 3872 + s * KC + e % KC] : 0.0f;
-            }
-#pragma unroll
-            for (int kk = 0; kk < KK; kk++) {
-                const size_t ro = (size_t)(s * KC + 4 * kk) * 256;
-                er[u][kk] = *(const f4u *)(eps + ro);
-                tr[u][kk] = *(const f4a *)(th + ro);
-            }
+        for (int kk = 0; kk < KK; kk++) {
+            const size_t ro = (size_t)(s * KC + 4 * kk) * 256;
+            R.er[u][kk] = *(const f4u *)(eps + ro);
+            R.tr[u][kk] = *(const f4a *)(th + ro);
         }
     };
-    float w[2][KK][4];
-    auto store_unit = [&](int s0) {   // activations of the unit into their LDS buffers, its weights into w
+    auto store_stage = [&](const Ld &R, int s0, int u, float (&wd)[2][KK][4]) {   // activations into their LDS buffer, weights into wd
+        const int s = s0 + u < NST ? s0 + u : NST - 1;
+#pragma unroll
+        for (int j = 0; j < LD; j++) {
+            const int e = tid + 256 * j;
+            if (FULL || e < FG * KC) {
+                const int ch = (kbeg + s * KC + e % KC) & 31;
+                float t = R.yr[u][j] * bn2[ch];
+                t = t + bn2[32 + ch];
+                xs[(s0 + u) & 3][(e / KC) * XS + e % KC] = t > 0.0f ? t : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KK; kk++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) { float pv = sc * R.er[u][kk][c]; wd[u][kk][c] = R.tr[u][kk][c] + pv; }
+    };
+    // a unit = two stages, or the odd one that ends a sub-slice (stages 16, 31, 46, ..., 121 end one)
+    constexpr int S0 = FC_SUB0 / KC, SN = FC_SUBN / KC;
+    auto unit_len = [&](int s) {
+        const int end = s < S0 ? S0 : S0 + ((s - S0) / SN + 1) * SN;
+        return end - s < 2 ? end - s : 2;
+    };
+    // MT == 4: the running fold lives in LDS ([16][256] 16-byte words = 64 KB dynamic, lane-contiguous: conflict-free, touched
+    // eight times per workgroup) -- as a second register set of the accumulators' size it leaves no room for the second load set
+    constexpr bool FOLD_LDS = MT == 4;
+    constexpr int FR = FOLD_LDS ? 1 : MT;
+    extern __shared__ __attribute__((aligned(16))) float fold_dyn[];
+    f32x4 *const fold_s = (f32x4 *)fold_dyn + tid;
+    f32x4 acc[MT][4], fold[FR][4];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < FR; m++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) fold[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    Ld R0, R1;
+    float wA[2][KK][4], wB[2][KK][4];
+    float aA[2][KK][MT], aB[2][KK][MT];   // a unit's sixteen A operands: requested behind the barrier INSIDE the previous unit, under its second stage
+    auto request = [&](float (&a)[2][KK][MT], int s0) {
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const int s = s0 + u < NST ? s0 + u : NST - 1;
+            const float *xb = xs[(s0 + u) & 3];
 #pragma unroll
-            for (int j = 0; j < LD; j++) {
-                const int e = tid + 256 * j;
-                if (e < FG * KC) {
-                    const int ch = (kbeg + s * KC + e % KC) & 31;
-                    float t = yr[u][j] * bn2[ch];
-                    t = t + bn2[32 + ch];
-                    xs[(s0 + u) & 3][(e / KC) * XS + e % KC] = t > 0.0f ? t : 0.0f;
-                }
-            }
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int kk = 0; kk < KK; kk++) a[u][kk][m] = xb[(m * 16 + lp) * XS + 4 * kk + lk];
+        }
+    };
+    int st = 0, s1 = unit_len(0);
+    bool first = true;
+    load_stage(R0, 0, 0);
+    load_stage(R0, 0, 1);
+    load_stage(R1, s1, 0);    // unit 1 in flight behind unit 0
+    load_stage(R1, s1, 1);
+    __syncthreads();          // bn2 visible
+    store_stage(R0, 0, 0, wA);
+    store_stage(R0, 0, 1, wA);
+    __syncthreads();
+    request(aA, 0);
+    DNE_ACC_DECL;   // profiling build: 0 = first stage's MFMAs with the pieces, 1 = barrier, 2 = next operands requested, 3 = second stage's MFMAs, 4 = fold
+    auto step = [&](Ld &Rcur /* in flight: unit s1 */, Ld &Rnext, float (&w)[2][KK][4], float (&wn)[2][KK][4], float (&a)[2][KK][MT],
+                    float (&an)[2][KK][MT]) {
+        const int n = s1 - st, s2 = s1 + unit_len(s1);
+        static_for<2 * KK>([&](auto J) {   // first stage: chunk j = k-group j / 2, position tiles of half j % 2
+            constexpr int j = decltype(J)::value, kk = j >> 1, h = j & 1;
+#pragma unroll
+            for (int m = h * MT / 2; m < (h + 1) * MT / 2; m++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][kk][m], w[0][kk][c], acc[m][c], 0, 0, 0);
+            if constexpr (j == 0) load_stage(Rnext, s2, 0);
+            else if constexpr (j == 1) load_stage(Rnext, s2, 1);
+            else if constexpr (j == 2) store_stage(Rcur, s1, 0, wn);   // into the buffers the unit being computed does not read
+            else store_stage(Rcur, s1, 1, wn);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        DNE_ACC(0);
+        __syncthreads();          // the next unit's buffers are complete (its predecessor's readers passed the previous barrier)
+        DNE_ACC(1);
+        request(an, s1);
+        __builtin_amdgcn_sched_barrier(0);
+        DNE_ACC(2);
+        if (n == 2) {
 #pragma unroll
             for (int kk = 0; kk < KK; kk++)
 #pragma unroll
-                for (int c = 0; c < 4; c++) { float pv = sc * er[u][kk][c]; w[u][kk][c] = tr[u][kk][c] + pv; }
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][kk][m], w[1][kk][c], acc[m][c], 0, 0, 0);
         }
-    };
-    f32x4 acc[MT][4], fold[MT][4];
+        DNE_ACC(3);
+        if (s1 == S0 || (s1 > S0 && (s1 - S0) % SN == 0)) {   // end of a sub-slice: the chains join the quarter's running fold and start again from 0
 #pragma unroll
-    for (int m = 0; m < MT; m++)
+            for (int m = 0; m < MT; m++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) acc[m][c] = fold[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    load_unit(0);
-    __syncthreads();          // bn2 visible
-    store_unit(0);
-    __syncthreads();
-    int st = 0;
-#pragma unroll 1
-    for (int sub = 0; sub < 8; sub++) {   // the units of one sub-slice are the inner loop; the fold sits between two runs of it
-        const int end_st = (FC_SUB0 + sub * FC_SUBN) / KC;      // stages 16, 31, 46, ..., 121
-#pragma unroll 1
-        while (st < end_st) {
-            const int n = end_st - st < 2 ? end_st - st : 2, ns = st + n;   // 2 stages, or the odd one that ends the sub-slice
-            load_unit(ns);
-#pragma unroll
-            for (int u = 0; u < 2; u++)
-                if (u < n) {
-                    const float *xb = xs[(st + u) & 3];
-#pragma unroll
-                    for (int kk = 0; kk < KK; kk++) {
-#pragma unroll
-                        for (int m = 0; m < MT; m++) {
-                            const float a = xb[(m * 16 + lp) * XS + 4 * kk + lk];
-#pragma unroll
-                            for (int c = 0; c < 4; c++) acc[m][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, w[u][kk][c], acc[m][c], 0, 0, 0);
-                        }
+                for (int c = 0; c < 4; c++) {
+                    if constexpr (FOLD_LDS) {
+                        f32x4 *p = fold_s + (m * 4 + c) * 256;
+                        if (first) *p = acc[m][c];
+                        else *p = *p + acc[m][c];
+                    } else {
+                        fold[m][c] = first ? acc[m][c] : fold[m][c] + acc[m][c];
                     }
+                    acc[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-            store_unit(ns);   // into the two buffers the unit just computed did not read
-            __syncthreads();
-            st = ns;
+            first = false;
+            DNE_ACC(4);
         }
-        // end of a sub-slice: the chains join the quarter's running fold and start again from 0
-#pragma unroll
-        for (int m = 0; m < MT; m++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                fold[m][c] = sub == 0 ? acc[m][c] : fold[m][c] + acc[m][c];
-                acc[m][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        st = s1;
+        s1 = s2;
+    };
+    static_assert(S0 % 2 == 0 && SN % 2 == 1 && S0 + 7 * SN == NST && KK == 2 && MT <= 4, "64 units: 8 per sub-slice");
+#pragma unroll 1
+    for (int it = 0; it < 16; it++) {   // one exit, a whole number of bodies
+        step(R1, R0, wA, wB, aA, aB);
+        step(R0, R1, wB, wA, aB, aA);
+        step(R1, R0, wA, wB, aA, aB);
+        step(R0, R1, wB, wA, aB, aA);
     }
+    DNE_ACC_STORE_EVERY(5, gridDim.x / 128);
     float *out = y3p + (((size_t)(mloc * 4 + sl) * F) + (size_t)fg * FG) * 256 + col0;
 #pragma unroll
-    for (int m = 0; m < MT; m++)
+    for (int m = 0; m < MT; m++) {
+        f32x4 f[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if constexpr (FOLD_LDS) f[c] = fold_s[(m * 4 + c) * 256];
+            else f[c] = fold[m][c];
+        }
 #pragma unroll
         for (int r = 0; r < 4; r++)   // D[row = 4*(l>>4) + r][col = l&15] of tile c -> frame m*16 + 4*lk + r, column col0 + c
-            *(f32x4 *)(out + (size_t)(m * 16 + lk * 4 + r) * 256) = f32x4{fold[m][0][r], fold[m][1][r], fold[m][2][r], fold[m][3][r]};
+            *(f32x4 *)(out + (size_t)(m * 16 + lk * 4 + r) * 256) = f32x4{f[0][r], f[1][r], f[2][r], f[3][r]};
+    }
 }
 
 // bn3 statistics from the four k-slice partials: y3 = ((p0+p1)+(p2+p3)) + bias per frame, then the batch

@@ -5,7 +5,8 @@
 #   (tools/collect_pmc_regimes.sh: FETCH_SIZE / WRITE_SIZE, each in its own run, kernel-trace only); the matrix-core PMC pass
 #   (tools/collect_pmc_mfma.sh); the env-free micro-benchmarks; population shares (what a rank sees at N = 2 / 4 / 8); lock-step
 #   length profiles; tail latency at fixed width + its per-kernel durations, launch timeline and in-kernel phase clock; the
-#   reference pass alone (chunked and as one chunk under rocprofv3); the launch floor; the Deep-GA lock-step profiles.
+#   reference pass alone (chunked and as one chunk under rocprofv3), its kernels' in-kernel phase clock, shader clock / power under it and
+#   under the bench (tools/clock_watch.py); the launch floor; the Deep-GA lock-step profiles.
 # Outputs land in gpurun_out/<tag>/; `python tools/refresh_profiles.py gpurun_out/<tag> r03` copies the summaries into profiles/.
 set -u
 TAG=${1:-r04p}
@@ -38,6 +39,9 @@ for p in 8 24; do DNE_LIB_PATH=$R/deep-neuroevolution_amd/csrc/libdne_hip_clock.
 python "$R/tools/ref_bench.py" > "$O/ref_bench.json" 2>/dev/null
 REF_CHUNK=5000 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/ref_alone" -o r -- python "$R/tools/ref_bench.py" > "$O/ref_bench_one_chunk.json" 2>/dev/null
 cp "$(find "$O/ref_alone" -name '*kernel_stats.csv' | head -1)" "$O/ref_pass_one_chunk_kernel_stats.csv" 2>/dev/null; rm -rf "$O/ref_alone"
+DNE_LIB_PATH=$R/deep-neuroevolution_amd/csrc/libdne_hip_clock.so REF_CHUNK=5000 python "$R/tools/ref_phase_clock.py" > "$O/ref_phase_clock.json" 2>/dev/null
+REF_REPS=100 REF_CHUNK=5000 python "$R/tools/clock_watch.py" "$O/clock_watch_ref.csv" -- python "$R/tools/ref_bench.py" > /dev/null 2>&1
+python "$R/tools/clock_watch.py" "$O/clock_watch_bench.csv" -- python "$R/bench.py" --steps 12 --warmup 3 --no-cpu-baseline --extra none > /dev/null 2>&1
 "$R/tools/micro/launch_floor" > "$O/launch_floor.jsonl" 2>/dev/null
 python "$R/tools/ga_lockstep_profile.py" > "$O/ga_lockstep_profile.json" 2> "$O/ga_lockstep_profile.err"
 python "$R/tools/ga_lockstep_profile.py" --large > "$O/ga_large_lockstep_profile.json" 2> "$O/ga_large_lockstep_profile.err"

@@ -19,5 +19,6 @@ idx = np.array([rs.randint(0, 250_000_000 - e.P + 1) for _ in range(2500)], np.i
 e.set_members(np.zeros(5000, np.int32), np.repeat(idx, 2), np.tile(np.array([0.02, -0.02], np.float32), 2500))
 e.ref_pass(5000)
 t = time.time()
-for _ in range(3): e.ref_pass(5000)
-print(json.dumps({"ref_pass_ms": (time.time() - t) / 3 * 1e3, "knobs": {k: v for k, v in os.environ.items() if k.startswith("DNE_")}}))
+N = int(os.environ.get("REF_REPS", "3"))
+for _ in range(N): e.ref_pass(5000)
+print(json.dumps({"ref_pass_ms": (time.time() - t) / N * 1e3, "knobs": {k: v for k, v in os.environ.items() if k.startswith("DNE_")}}))

@@ -29,7 +29,9 @@ for src, dst in (('bench_default.json', 'bench_default.json'), ('bench_driver_cm
                  ('tail_timeline_8.json', 'tail_timeline_8_pairs.json'), ('phase_clock_8.json', 'tail_phase_clock_8_pairs.json'),
                  ('phase_clock_24.json', 'tail_phase_clock_24_pairs.json'), ('ref_bench.json', 'ref_pass.json'),
                  ('ref_bench_one_chunk.json', 'ref_pass_one_chunk.json'), ('ref_pass_one_chunk_kernel_stats.csv', 'ref_pass_one_chunk_kernel_stats.csv'),
-                 ('launch_floor.jsonl', 'launch_floor.jsonl'), ('valu_rate.jsonl', 'valu_rate.jsonl')):
+                 ('launch_floor.jsonl', 'launch_floor.jsonl'), ('valu_rate.jsonl', 'valu_rate.jsonl'),
+                 ('ref_phase_clock.json', 'ref_phase_clock.json'), ('clock_watch_ref.csv', 'clock_watch_ref.csv'),
+                 ('clock_watch_bench.csv', 'clock_watch_bench.csv')):
     if os.path.exists(os.path.join(R, src)):
         shutil.copy(os.path.join(R, src), os.path.join(P, '%s_%s' % (PFX, dst)))
 ks = glob.glob(R + '/stats/**/*kernel_stats.csv', recursive=True)
