@@ -544,10 +544,14 @@ template <int FPW, bool PAD>
 __global__ __launch_bounds__(256, 2) void k_conv2_ref(FwdArgs A, int F, int member0, const float *__restrict__ y1 /*[n_local * F][441][16]*/,
                                                    float *__restrict__ y2 /*[n_local * F][121 (PAD: 128)][32]*/,
                                                    float *__restrict__ fr /*[n_local * F][2][32]*/) {
-    constexpr int PS = C2_PS, RW = C2_RW, Y2S = PAD ? Y2_PAD_ROW : 3872;
-    __shared__ Conv2Lds S;
-    float (&a_s)[24 * C2_RW * C2_PS] = S.a_s;
-    float (&wsum)[4][2][16] = S.wsum;
+    // LDS image: pixel stride 20 floats, channel c at float (c % 4) * 4 + c / 4 of its pixel -- the four k-groups a lane feeds to four
+    // consecutive MFMAs (channels lk, lk + 4, lk + 8, lk + 12) are then ONE 16-byte read (0.25 operand reads per MFMA instead of 0.5,
+    // every tap an immediate offset from one address per position tile), conflict-free: consecutive positions are 40 floats apart,
+    // eight of them start on eight different 8-bank groups, the second lane group of a ds_read_b128 cycle sits 4 banks on, and an
+    // output row's wrap (2 * 27 * 20 floats) continues the sequence (1080 - 11 * 40 = 10 * 64)
+    constexpr int PS = 20, RW = C2_RW, Y2S = PAD ? Y2_PAD_ROW : 3872;
+    __shared__ __attribute__((aligned(16))) float a_s[24 * RW * PS];
+    __shared__ float wsum[4][2][16];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
     const int nt = wv & 1, mt0 = 4 * (wv >> 1);
     const int gpm = F / FPW, mloc = blockIdx.x / gpm, f0 = (blockIdx.x % gpm) * FPW, member = member0 + mloc;
@@ -583,13 +587,13 @@ __global__ __launch_bounds__(256, 2) void k_conv2_ref(FwdArgs A, int F, int memb
         const int y = pix / 24, x = pix % 24;
         if (y < 1 || y > 21 || x < 1 || x > 21)
 #pragma unroll
-            for (int c = 0; c < 16; c++) a_s[(y * RW + x) * PS + c] = 0.0f;
+            for (int c = 0; c < 16; c++) a_s[(y * RW + x) * PS + c] = 0.0f;   // (any order: all sixteen)
     }
     int off[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         const int p = min((mt0 + m) * 16 + lp, 120);
-        off[m] = ((p / 11) * 2 * RW + (p % 11) * 2) * PS + lk;
+        off[m] = ((p / 11) * 2 * RW + (p % 11) * 2) * PS + lk * 4;
     }
     auto stage = [&]() {
 #pragma unroll
@@ -597,12 +601,12 @@ __global__ __launch_bounds__(256, 2) void k_conv2_ref(FwdArgs A, int F, int memb
             const int e = tid + 256 * j;
             if (e < 1764) {
                 const int pix = e >> 2;
-                float *d = a_s + ((pix / 21 + 1) * RW + pix % 21 + 1) * PS + c0;
+                float *d = a_s + ((pix / 21 + 1) * RW + pix % 21 + 1) * PS + (c0 >> 2);   // channel c0 + i -> float 4 i + c0 / 4
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     float t = yv[j][i] * s1[i];
                     t = t + h1[i];
-                    d[i] = t > 0.0f ? t : 0.0f;
+                    d[4 * i] = t > 0.0f ? t : 0.0f;
                 }
             }
         }
@@ -615,13 +619,11 @@ __global__ __launch_bounds__(256, 2) void k_conv2_ref(FwdArgs A, int F, int memb
 #pragma unroll
             for (int kw = 0; kw < 4; kw++) {
 #pragma unroll
-                for (int c4 = 0; c4 < 4; c4++) {   // k = (kh*4+kw)*16 + c4*4 + (l>>4)
-                    const int kk = (kh * 4 + kw) * 4 + c4;
+                for (int m = 0; m < 4; m++) {
+                    const f32x4 x = *(const f32x4 *)(a_s + off[m] + (kh * RW + kw) * PS);
 #pragma unroll
-                    for (int m = 0; m < 4; m++) {
-                        const float x = a_s[off[m] + (kh * RW + kw) * PS + c4 * 4];
-                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, b[kk], acc[m], 0, 0, 0);
-                    }
+                    for (int c4 = 0; c4 < 4; c4++)   // k = (kh*4+kw)*16 + c4*4 + (l>>4), ascending per accumulator
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[c4], b[(kh * 4 + kw) * 4 + c4], acc[m], 0, 0, 0);
                 }
             }
         }
@@ -660,62 +662,75 @@ __global__ __launch_bounds__(256, 2) void k_conv2_ref(FwdArgs A, int F, int memb
         if (fi == 0) {
             mfmas(acc);
         } else {
-            // 32 steps of eight MFMAs (two k-groups x four position tiles); behind each, one of the 32 pieces of the previous frame's
-            // epilogue (pieces 0-15: a store; 16-31: a quarter of a tile's moments -- the exchange requested in one piece is read in
-            // the next); the operand reads run two steps ahead through a ring of three register sets.  One fence per step.
+            // 16 steps = the 16 taps: sixteen MFMAs (four k-groups x four position tiles) behind four 16-byte operand reads that were
+            // requested one step earlier (two register sets); behind them two of the 32 pieces of the previous frame's epilogue (pieces
+            // 0-15: a store; 16-31: a quarter of a tile's moments -- the exchange requested in one piece is read in the next).  One
+            // fence per step.
             const size_t prow = row0 + fi - 1;
             float *o = y2 + prow * Y2S;
-            float Ws = 0.0f, Wq = 0.0f, ts = 0.0f, tq = 0.0f, ts1 = 0.0f, tq1 = 0.0f, xs_ = 0.0f, xq_ = 0.0f;
-            float xr[3][4][2];
-            auto rd = [&](int p, float (&x)[4][2]) {
-                const int oo = ((p >> 3) * RW + ((p >> 1) & 3)) * PS + (p & 1) * 8;
+            float Ws = 0.0f, Wq = 0.0f;
+            float ts[2] = {0.f, 0.f}, tq[2] = {0.f, 0.f}, ts1[2] = {0.f, 0.f}, tq1[2] = {0.f, 0.f}, xs_[2] = {0.f, 0.f}, xq_[2] = {0.f, 0.f};   // two tiles in flight
+            f32x4 xr[2][4];
+            auto rd = [&](int t, f32x4 (&x)[4]) {
 #pragma unroll
-                for (int m = 0; m < 4; m++) { x[m][0] = a_s[off[m] + oo]; x[m][1] = a_s[off[m] + oo + 4]; }
+                for (int m = 0; m < 4; m++) x[m] = *(const f32x4 *)(a_s + off[m] + ((t >> 2) * RW + (t & 3)) * PS);
             };
+            auto store_piece = [&](auto P) {
+                constexpr int p = decltype(P)::value, m = p / 4, r = p % 4;
+                const int pos = (mt0 + m) * 16 + lk * 4 + r;
+                if (PAD || pos < 121) o[pos * 32 + nt * 16 + lp] = accp[m][r] + bias;
+            };
+            auto moment_piece = [&](auto M, auto Q) {   // tile_moments(accp[m], ...) in four pieces; the tiles' sums join Ws / Wq in tile order
+                constexpr int m = decltype(M)::value, q = decltype(Q)::value, i = m & 1;
+                if constexpr (q == 0) {
+                    float a[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) a[r] = (mt0 + m) * 16 + lk * 4 + r < 121 ? accp[m][r] : 0.0f;
+                    ts[i] = a[0] + a[1];
+                    ts[i] = ts[i] + a[2];
+                    ts[i] = ts[i] + a[3];
+                    tq[i] = a[0] * a[0];
+                    tq[i] = __builtin_fmaf(a[1], a[1], tq[i]);
+                    tq[i] = __builtin_fmaf(a[2], a[2], tq[i]);
+                    tq[i] = __builtin_fmaf(a[3], a[3], tq[i]);
+                } else if constexpr (q == 1) {
+                    xs_[i] = __shfl_xor(ts[i], 16);
+                    xq_[i] = __shfl_xor(tq[i], 16);
+                } else if constexpr (q == 2) {
+                    ts1[i] = ts[i] + xs_[i];
+                    tq1[i] = tq[i] + xq_[i];
+                    xs_[i] = __shfl_xor(ts1[i], 32);
+                    xq_[i] = __shfl_xor(tq1[i], 32);
+                } else {
+                    const float Ts = ts1[i] + xs_[i], Tq = tq1[i] + xq_[i];
+                    Ws = Ws + Ts;
+                    Wq = Wq + Tq;
+                }
+            };
+            // steps 0-7: two stores each; steps 8-15: the moments, two tiles in flight so that no exchange is read in the step that requests it
+            constexpr int MSEQ[16][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 0}, {0, 3}, {1, 1}, {1, 2}, {2, 0}, {1, 3}, {2, 1}, {2, 2}, {3, 0}, {2, 3}, {3, 1}, {3, 2}, {-1, 0}};
 #pragma unroll
             for (int m = 0; m < 4; m++) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
             rd(0, xr[0]);
-            rd(1, xr[1]);
-            static_for<32>([&](auto P) {
-                constexpr int p = decltype(P)::value;
-                if constexpr (p + 2 < 32) rd(p + 2, xr[(p + 2) % 3]);
+            static_for<16>([&](auto T) {
+                constexpr int t = decltype(T)::value;
+                if constexpr (t + 1 < 16) rd(t + 1, xr[(t + 1) & 1]);
 #pragma unroll
-                for (int u = 0; u < 2; u++)
+                for (int m = 0; m < 4; m++)
 #pragma unroll
-                    for (int m = 0; m < 4; m++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[p % 3][m][u], b[2 * p + u], acc[m], 0, 0, 0);
-                if constexpr (p < 16) {
-                    constexpr int m = p / 4, r = p % 4;
-                    const int pos = (mt0 + m) * 16 + lk * 4 + r;
-                    if (PAD || pos < 121) o[pos * 32 + nt * 16 + lp] = accp[m][r] + bias;
-                } else {   // tile_moments(accp[m], ...) in four pieces
-                    constexpr int m = (p - 16) / 4, q = (p - 16) % 4;
-                    if constexpr (q == 0) {
-                        float a[4];
-#pragma unroll
-                        for (int r = 0; r < 4; r++) a[r] = (mt0 + m) * 16 + lk * 4 + r < 121 ? accp[m][r] : 0.0f;
-                        ts = a[0] + a[1];
-                        ts = ts + a[2];
-                        ts = ts + a[3];
-                        tq = a[0] * a[0];
-                        tq = __builtin_fmaf(a[1], a[1], tq);
-                        tq = __builtin_fmaf(a[2], a[2], tq);
-                        tq = __builtin_fmaf(a[3], a[3], tq);
-                    } else if constexpr (q == 1) {
-                        xs_ = __shfl_xor(ts, 16);
-                        xq_ = __shfl_xor(tq, 16);
-                    } else if constexpr (q == 2) {
-                        ts1 = ts + xs_;
-                        tq1 = tq + xq_;
-                        xs_ = __shfl_xor(ts1, 32);
-                        xq_ = __shfl_xor(tq1, 32);
-                    } else {
-                        const float Ts = ts1 + xs_, Tq = tq1 + xq_;
-                        Ws = Ws + Ts;
-                        Wq = Wq + Tq;
-                    }
+                    for (int c4 = 0; c4 < 4; c4++) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[t & 1][m][c4], b[4 * t + c4], acc[m], 0, 0, 0);
+                if constexpr (t < 8) {
+                    store_piece(std::integral_constant<int, 2 * t>{});
+                    store_piece(std::integral_constant<int, 2 * t + 1>{});
+                } else {
+                    static_for<2>([&](auto H) {
+                        constexpr int e = 2 * (t - 8) + decltype(H)::value;
+                        if constexpr (MSEQ[e][0] >= 0) moment_piece(std::integral_constant<int, MSEQ[e][0]>{}, std::integral_constant<int, MSEQ[e][1]>{});
+                    });
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
+            moment_piece(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});
             wsum[wv][0][lp] = Ws;
             wsum[wv][1][lp] = Wq;
         }
@@ -1802,18 +1817,38 @@ __global__ __launch_bounds__(256, 2) void k_fc_ref(FwdArgs A, int n_local, int m
     // in the asm text (the compiler uses them itself as soon as the kernel declares any).
     constexpr bool FULL = (FG * KC) % 256 == 0;                 // every thread stages LD activations per stage
     struct Ld { float yr[2][LD]; f4u er[2][KK]; f4a tr[2][KK]; };
+    // addresses as (wave-uniform 64-bit base) + (per-lane 32-bit byte offset, fixed for the kernel): the loads take the base from
+    // scalar registers and need no vector address arithmetic (16 v_lshl_add_u64 per unit otherwise -- every instruction between
+    // two MFMAs costs its issue slot, section 4b of DESIGN.md)
+    typedef const __attribute__((address_space(1))) char *gptr;   // global, not generic: an integer cast alone would make these flat loads
+    const gptr eps_u = (gptr)uni64((long long)(A.noise + A.m_off[member] + L.fcw + (size_t)kbeg * 256));
+    const gptr th_u = (gptr)uni64((long long)(A.bases + (size_t)A.m_slot[member] * A.base_stride + L.fcw + (size_t)kbeg * 256));
+    const gptr y_u = (gptr)uni64((long long)ysrc);
+    const unsigned woff = (unsigned)(lk * 256 + col0) * 4u;
+    unsigned yoff[LD];
+#pragma unroll
+    for (int j = 0; j < LD; j++) {
+        const int e = tid + 256 * j;
+        yoff[j] = (unsigned)((e / KC) * Y2_PAD_ROW + e % KC) * 4u;
+    }
+    auto sbase = [](gptr p) { asm volatile("" : "+s"(p)); return p; };   // the uniform sum stays one scalar value: without this the compiler
+                                                                          // hoists (base + lane offset) out of the loop as a 64-bit VGPR pair and adds the rest per load
+    auto voff = [](unsigned o) { asm volatile("" : "+v"(o)); return o; };   // ... and the 32-bit offset is widened where it is used (instruction selection works per block)
     auto load_stage = [&](Ld &R, int s0, int u) {
         const int s = s0 + u < NST ? s0 + u : NST - 1;
+        const gptr yb = sbase(y_u + (size_t)(s * KC) * 4);
 #pragma unroll
         for (int j = 0; j < LD; j++) {
             const int e = tid + 256 * j;
-            R.yr[u][j] = FULL || e < FG * KC ? ysrc[(size_t)(e / KC) * Y2_PAD_ROW + s * KC + e % KC] : 0.0f;
+            R.yr[u][j] = FULL || e < FG * KC ? *(const __attribute__((address_space(1))) float *)(yb + voff(yoff[j])) : 0.0f;
         }
+        const gptr eb = sbase(eps_u + (size_t)(s * KC) * 1024), tb = sbase(th_u + (size_t)(s * KC) * 1024);
+        const unsigned wo = voff(woff);
 #pragma unroll
-        for (int kk = 0; kk < KK; kk++) {
-            const size_t ro = (size_t)(s * KC + 4 * kk) * 256;
-            R.er[u][kk] = *(const f4u *)(eps + ro);
-            R.tr[u][kk] = *(const f4a *)(th + ro);
+        for (int kk = 0; kk < KK; kk++) {   // 4 rows = 4096 bytes on: past the loads' immediate offset, so a scalar base of its own
+            const gptr ebk = kk ? sbase(eb + 4096 * kk) : eb, tbk = kk ? sbase(tb + 4096 * kk) : tb;
+            R.er[u][kk] = *(const __attribute__((address_space(1))) f4u *)(ebk + wo);
+            R.tr[u][kk] = *(const __attribute__((address_space(1))) f4a *)(tbk + wo);
         }
     };
     auto store_stage = [&](const Ld &R, int s0, int u, float (&wd)[2][KK][4]) {   // activations into their LDS buffer, weights into wd
@@ -1828,10 +1863,19 @@ __global__ __launch_bounds__(256, 2) void k_fc_ref(FwdArgs A, int n_local, int m
                 xs[(s0 + u) & 3][(e / KC) * XS + e % KC] = t > 0.0f ? t : 0.0f;
             }
         }
+        typedef float f32x2v __attribute__((ext_vector_type(2)));
+        const f32x2v sc2 = {sc, sc};
 #pragma unroll
         for (int kk = 0; kk < KK; kk++)
 #pragma unroll
-            for (int c = 0; c < 4; c++) { float pv = sc * R.er[u][kk][c]; wd[u][kk][c] = R.tr[u][kk][c] + pv; }
+            for (int c = 0; c < 4; c += 2) {   // theta + (sigma * eps), two columns per packed instruction (mul, then add: -ffp-contract=off)
+                const f32x2v e2 = {R.er[u][kk][c], R.er[u][kk][c + 1]}, t2 = {R.tr[u][kk][c], R.tr[u][kk][c + 1]};
+                f32x2v pv, wv2;   // as asm: the compiler splits about half of these into single multiplies and adds
+                asm("v_pk_mul_f32 %0, %1, %2" : "=v"(pv) : "v"(sc2), "v"(e2));
+                asm("v_pk_add_f32 %0, %1, %2" : "=v"(wv2) : "v"(t2), "v"(pv));
+                wd[u][kk][c] = wv2[0];
+                wd[u][kk][c + 1] = wv2[1];
+            }
     };
     // a unit = two stages, or the odd one that ends a sub-slice (stages 16, 31, 46, ..., 121 end one)
     constexpr int S0 = FC_SUB0 / KC, SN = FC_SUBN / KC;
