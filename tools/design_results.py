@@ -35,7 +35,7 @@ one engine per setting, settings round-robin).  Boxes differ by ±2 %.
 | roofline kernel `k_fc_duo<2,true,true,8,true>` | {r['avg_launch_ms']:.3f} ms per ≈ {r['units_per_launch']:.0f}-unit launch, {r['launches']} launches (every window with ≥ 451 active pairs on the rank); `frac` = `frac_algorithmic` {r['frac']:.3f}; **`frac_counter` {r['frac_counter']:.3f}** at the bytes measured on the bench's own launch mix; over the union of the concurrent launches {r['concurrent_launches']['frac']:.2f} / **{r['concurrent_launches']['frac_counter']:.3f}** ({r['concurrent_launches']['busy_ms_per_generation']:.0f} ms of a generation's {d['ms_per_step']:.0f} have at least one such launch running); whole job {r['whole_job']['frac']:.2f}; `floors`: distinct rows {r['floors']['hbm_distinct_rows_ms']:.3f} ms, VALU issue {r['floors']['valu_issue_ms']:.3f} ms per launch — neither is what the kernel sits on (section 4a) | bench line |
 | HBM-side traffic (`FETCH_SIZE`×2 + `WRITE_SIZE`, separate `--pmc` passes) | **bench mix: {reg['bench_mix']['hbm_bytes_per_unit']/1e6:.3f} MB per member-step** ({reg['bench_mix']['dispatches']} launches of `bench.py --steps 3 --warmup 1`, dispatch count = the bench's launch count: {reg['bench_mix']['dispatches_match_bench']}); fixed width: 2500 pairs in one window {reg['full_1window']['hbm_bytes_per_unit']/1e6:.2f} MB (round 3: 1.00), in three / four windows {reg['full_3windows']['hbm_bytes_per_unit']/1e6:.2f} / {reg['full_4windows']['hbm_bytes_per_unit']/1e6:.2f} (0.85 / 0.79) — one workgroup per CU keeps a timeline's requests together —, 1250 pairs in four windows {reg['half_4windows']['hbm_bytes_per_unit']/1e6:.2f}, 800 pairs {reg['third_4windows']['hbm_bytes_per_unit']/1e6:.2f}; §8d figure 4.06 MB, every pair's slice once 2.01 MB, every distinct row once 0.20 MB | `profiles/{PFX}_pmc.json` |
 | `k_fc_duo` alone, SQ counters (2500 pairs, one window) | per wave: issuing {100*sq['SQ_ACTIVE_INST_ANY']:.0f} % (VALU {100*sq['SQ_ACTIVE_INST_VALU']:.0f} %), parked {100*sq['SQ_WAIT_ANY']:.0f} %, issue-stalled {100*sq['SQ_WAIT_INST_ANY']:.0f} % of its cycles (round 3's two-per-CU form: 17.5 / 41 / 41 %) at half the wave-cycles per unit; {pmc['sq']['k_fc_duo']['SQ_INSTS_VALU_per_unit']/2/968:.1f} VALU instructions per row-side | `profiles/{PFX}_pmc.json` (`sq`) |
-| reference pass | {d['roofline_ref_pass']['ms_per_generation']:.1f} ms per generation inside the bench = {d['roofline_ref_pass']['frac']:.2f} of the fp32 MFMA peak ({ref['ref_pass_ms']:.1f} ms alone); unchanged this round | bench line, `profiles/{PFX}_ref_pass.json` |
+| reference pass | {d['roofline_ref_pass']['ms_per_generation']:.1f} ms per generation inside the bench = {d['roofline_ref_pass']['frac']:.2f} of the fp32 MFMA peak at 2.4 GHz ({ref['ref_pass_ms']:.1f} ms alone; round 3: 43.5 / 42.4; section 4b: MFMA pipes busy 83 / 77 / 71 % of conv1 / conv2 / fc time, round 3: 83 / 72 / 65) | bench line, `profiles/{PFX}_ref_pass.json` |
 | CPU baseline (oracle, single-threaded worker processes, best wall-clock rate of a worker-count sweep) | **{c['value']/1e3:.1f} k env-steps/s with {c['cores']} workers** ({c['cpus_delivered']} CPUs delivered, {c['rate_per_cpu_second']:.0f} env-steps per CPU-second); 2 workers {sw[2]['rate_wall']/1e3:.2f} k, 64 workers {sw[64]['rate_wall']/1e3:.1f} k, 256 workers {sw[256]['rate_wall']/1e3:.1f} k.  The container's cgroup grants 16 of the box's 256 logical CPUs: GPU / CPU = **{c['gpu_over_cpu']:.0f}× against that share**, ≈ {d['value']/(c['rate_per_cpu_second']*128):.0f}× against 128 physical cores at the same per-CPU rate.  Extras: GA {ex['ga']['cpu_baseline']['value']/1e3:.1f} k, NS-ES (trajectories + novelty) {ex['nses']['cpu_baseline']['value']/1e3:.1f} k, sweep {ex['sweep']['cpu_baseline']['value']/1e3:.1f} k, config 1 (pop 256, exactly 2 workers) **{ex['config1']['value']:.0f}** | bench line |
 | population shares on one GPU (what a rank sees at N = 2 / 4 / 8): 1250 / 625 / 312 pairs | **{sh[1250]:.1f} / {sh[625]:.1f} / {sh[312]:.1f} ms** per generation (round 3: 211.6 / 106.1 / 58.9) ⇒ expected strong-scaling efficiency before the all-gather {d['ms_per_step']/(2*sh[1250]):.2f} / {d['ms_per_step']/(4*sh[625]):.2f} / {d['ms_per_step']/(8*sh[312]):.2f} — a prediction, not a measurement | `profiles/{PFX}_population_shares.jsonl` |
 | tail lock-step latency (all alive for 208 steps) | {t(1)} µs at 1 pair, {t(2)} at 2, {t(4)} at 4, {t(8)} at 8, {t(16)} at 16, {t(24)} at 24, {t(48)} at 48 (unchanged: no tail work this round; VERDICT's weight-stationary experiment was not run — the round went into parity at full size, the measurement chain, the mid range and the co-run) | `profiles/{PFX}_tail_bench.json` |
