@@ -1,5 +1,8 @@
 #!/bin/bash
-# reference-pass kernels: parity, same-box A/B against the committed library, per-kernel durations, phase clock
+# reference-pass kernels: parity, same-box A/B against a baseline library, per-kernel durations (ONE chunk of 5000 members under rocprofv3),
+# phase clock.  The baseline is whatever was built into deep-neuroevolution_amd/csrc/libdne_hip_base.so beforehand, e.g. the last commit:
+#   git stash; make -C deep-neuroevolution_amd/csrc libdne_hip.so; cp deep-neuroevolution_amd/csrc/libdne_hip.so deep-neuroevolution_amd/csrc/libdne_hip_base.so; git stash pop; make -C deep-neuroevolution_amd/csrc libdne_hip.so clock
+#   gpurun --timeout 1200 -- 'bash tools/ref_ab.sh <tag>'
 TAG=${1:-r04ref}
 O=$PWD/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
