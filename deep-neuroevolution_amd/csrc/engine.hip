@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -565,6 +566,8 @@ struct dne_handle {
     int duo_rounds = 1;              // DNE_DUO_ROUNDS: duos per wave and work item of the sweep (1-4)
     int duo_sync = 1;                // DNE_DUO_SYNC: row blocks per barrier of the sweep (1-8)
     int burst = 32, burst_tail = 16; // DNE_BURST / DNE_BURST_TAIL: lock-steps between two compactions of the active list (a host round trip each), at large / with at most fc_tail_max groups alive (round 4: 32 at large, 16 before; 24 / 32 / 48 measured -0.5 .. -0.9 %, 8 +2.3 %, 64 +0.2 %; the tail indifferent)
+    int ring_on = 1;                 // DNE_FC_RING (round 5): k_fc_ring instead of k_fc_duo -- the workgroup's noise rows through an LDS ring filled by LDS-DMA, the base rows from a column-permuted copy of the fc matrix; 1: where two units share a wave (>= DNE_DUO_SOLO_BELOW active pairs), 2: in the whole k_fc_duo range
+    float *theta_perm = nullptr;     // [3872 + 16][256]: base slot 0's fc matrix, every row stored as columns l, l+64, l+128, l+192 per lane (k_theta_perm, once per evaluation)
     int duo_fat = 1;                 // DNE_DUO_FAT: k_fc_duo with a register footprint past 256 per lane = at most one of its workgroups per CU (it streams as fast from one), so the other windows' kernels always find room beside it
     int duo_w = 8;                   // DNE_DUO_W: rows in flight per stream of k_fc_duo (8: two waves per SIMD; 4: four)
     int fc_sub = 1;                  // DNE_FC_SUB (ES 2, GA 1): the sub-slice fc (k_fc_sub: one wave per 128 / 120-row chain) in the mid range -- 0 off, 1 GA children (materialised), 2 also ES pairs
@@ -630,6 +633,14 @@ struct dne_handle {
     float *y1r[2] = {nullptr, nullptr}, *y2r[2] = {nullptr, nullptr}, *y3pr[2] = {nullptr, nullptr};   // reference pass scratch, two ways
     float *fr1[2] = {nullptr, nullptr}, *fr2[2] = {nullptr, nullptr};   // per-frame batch-norm moments of conv1 / conv2 ([rows][2][C])
     hipEvent_t ev_ref[2] = {nullptr, nullptr};
+    // DNE_REF_OVERLAP (round 5): the reference pass runs chunk by chunk on two streams of its own and a window starts its lock-steps
+    // as soon as the chunks of ITS members are through (policies.py:399: the pass precedes that member's first step -- unchanged),
+    // so the first windows stream their noise slices while the later chunks keep the matrix cores busy
+    int ref_overlap = 0;
+    int ref_prio = 1;                // DNE_REF_PRIO: 1 = the reference pass's own streams at the lowest priority (the windows' short kernels go first)
+    hipStream_t ref_streams[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev_chunk;   // recorded behind the last kernel of reference chunk c
+    int ref_chunks_async = 0;        // chunks of the pass that is in flight beside the first burst (0: the pass has been joined)
     int *list_a = nullptr, *list_b = nullptr, *count_dev = nullptr;
     int *count_host = nullptr;       // pinned: the active count comes back once per burst (a pageable destination makes the copy a staged, synchronous one)
     uint8_t *bc = nullptr; size_t bc_bytes = 0;
@@ -670,6 +681,7 @@ struct dne_handle {
     // RCCL communicator (dne_comm_init); the library is opened on demand
     void *rccl_lib = nullptr; void *comm = nullptr; int comm_rank = 0, comm_size = 1;
     bool comm_borrowed = false;      // dne_comm_share: the communicator belongs to another handle of this process
+    std::mutex comm_mu;                  // dne_comm_init publishes its communicator and dne_comm_abort retires one under this lock
     std::atomic<bool> comm_off{false};   // dne_comm_abort (possibly from another host thread than a dne_comm_init still in flight): this handle takes no part in RCCL any more, a late result is dropped
     double *comm_scratch = nullptr;
 
@@ -882,10 +894,12 @@ extern "C" int dne_num_params(int kind, int nact) {
 
 extern "C" const char *dne_last_error(dne_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+constexpr size_t OVERFETCH_FLOATS = 2 * 8 * 256 + 64;   // one row block of the streaming fc + the 64 floats of slack the table always had
 static int grow_bases(dne_handle *h, int cap) {
     if (cap <= h->base_cap) return 0;
     float *nb = nullptr;
-    HCHECK(h, h->alloc(&nb, (size_t)cap * h->base_stride, "bases"));
+    HCHECK(h, h->alloc(&nb, (size_t)cap * h->base_stride + OVERFETCH_FLOATS, "bases"));   // (the same over-fetch behind the last slot)
+    HCHECK(h, hipMemsetAsync(nb + (size_t)cap * h->base_stride, 0, OVERFETCH_FLOATS * sizeof(float), h->stream));
     if (h->bases) {
         HCHECK(h, hipMemcpyAsync(nb, h->bases, (size_t)h->base_cap * h->base_stride * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         HCHECK(h, hipStreamSynchronize(h->stream));
@@ -949,6 +963,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipFuncSetAttribute((const void *)k_out<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
     env_int("DNE_NSUB_FULL", 1, 4, &h->nsub_full);
+    env_int("DNE_REF_OVERLAP", 0, 1, &h->ref_overlap); env_int("DNE_REF_PRIO", 0, 1, &h->ref_prio);
     env_int("DNE_NSUB_MID", 1, 4, &h->nsub_mid);
     env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
     env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
@@ -975,7 +990,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_DUO_SWEEP", 0, 2, &h->duo_sweep);
     env_int("DNE_DUO_SYNC", 1, 8, &h->duo_sync);
     env_int("DNE_DUO_ROUNDS", 1, 4, &h->duo_rounds);
-    env_int("DNE_DUO_FAT", 0, 1, &h->duo_fat);
+    env_int("DNE_DUO_FAT", 0, 1, &h->duo_fat); env_int("DNE_FC_RING", 0, 2, &h->ring_on);
     env_int("DNE_BURST", 1, 256, &h->burst);
     env_int("DNE_BURST_TAIL", 1, 256, &h->burst_tail);
     env_int("DNE_DUO_W", 4, 8, &h->duo_w);
@@ -1053,6 +1068,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     else { CH(h->alloc(&h->y1, M * 7056, "y1")); CH(h->alloc(&h->y2, M * 3872, "y2")); CH(h->alloc(&h->y3, M * 256, "y3")); CH(h->alloc(&h->y3t, M * 4 * 256, "y3t")); }
     CH(h->alloc(&h->unit_order, M * 4, "unit_order"));
     if (!h->large && h->fc_sub) CH(h->alloc(&h->y3s, M * 32 * 256, "y3s"));
+    if (!h->large && h->ring_on && cfg->policy_kind == DNE_KIND_ES) CH(h->alloc(&h->theta_perm, (size_t)(3872 + 16) * 256, "theta_perm"));
     if (cfg->n_actions > SPEC_ACTIONS - 2) h->spec_max = 0;
     if (h->spec_max > 0) {   // candidate outcomes of the speculative tail: [list position][action]
         const size_t rows = (size_t)h->spec_max * SPEC_ACTIONS;
@@ -1067,6 +1083,9 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
             CH(h->alloc(&h->y1r[w], rr * 7056, "y1r[w]")); CH(h->alloc(&h->y2r[w], rr * Y2_PAD_ROW, "y2r[w]")); CH(h->alloc(&h->y3pr[w], rr * 4 * 256, "y3pr[w]"));
             CH(h->alloc(&h->fr1[w], rr * 2 * 16, "fr1[w]")); CH(h->alloc(&h->fr2[w], rr * 2 * 32, "fr2[w]"));
             CH(hipEventCreateWithFlags(&h->ev_ref[w], hipEventDisableTiming));
+            int lo = 0, hi = 0;
+            CH(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = the numerically largest = least urgent
+            CH(hipStreamCreateWithPriority(&h->ref_streams[w], hipStreamNonBlocking, h->ref_prio ? lo : 0));
         }
     }
     CH(h->alloc(&h->list_a, M, "list_a")); CH(h->alloc(&h->list_b, M, "list_b")); CH(h->alloc(&h->count_dev, 8 + TT_MAX, "count_dev"));
@@ -1138,6 +1157,8 @@ extern "C" void dne_destroy(dne_handle *h) {
     if (h->count_host) hipHostFree(h->count_host);
     for (hipEvent_t e : h->fc_ring) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_ref) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_chunk) hipEventDestroy(e);
+    for (hipStream_t st : h->ref_streams) if (st) hipStreamDestroy(st);
     if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->ev_b) hipEventDestroy(h->ev_b);
     for (size_t s = 1; s < h->sub_streams.size(); s++) hipStreamDestroy(h->sub_streams[s]);
@@ -1213,8 +1234,10 @@ extern "C" int dne_noise_alloc(dne_handle *h, size_t count) {
     if (count == 0) return h->fail("dne_noise_alloc: empty table");
     HCHECK(h, h->release(h->noise));
     h->noise_count = 0;
-    HCHECK(h, h->alloc(&h->noise, count + 64, "noise"));
-    HCHECK(h, hipMemset(h->noise + count, 0, 64 * sizeof(float)));
+    // the streaming fc kernels (k_fc_duo, k_fc_sub) fetch one 8-row block past a unit's last row and never use it: for small action
+    // counts that block ends behind the member's parameter slice, i.e. up to OVERFETCH_FLOATS behind the table's last legal slice
+    HCHECK(h, h->alloc(&h->noise, count + OVERFETCH_FLOATS, "noise"));
+    HCHECK(h, hipMemset(h->noise + count, 0, OVERFETCH_FLOATS * sizeof(float)));
     h->noise_count = count;
     h->trace("noise table allocated: %zu floats", count);
     return 0;
@@ -1403,7 +1426,8 @@ extern "C" int dne_set_members(dne_handle *h, int n, const int32_t *slot, const 
 }
 
 // policies.py:399: the reference batch through every member's perturbed network -> per-member BN scale/shift
-static int ref_pass(dne_handle *h, int n) {
+static int ref_pass(dne_handle *h, int n, bool async = false /* eval_core: leave the chunks in flight, ev_chunk[c] behind each */) {
+    h->ref_chunks_async = 0;
     if (h->L.kind != DNE_KIND_ES) return 0;
     if (!h->ref_set) return h->fail("reference batch not set (dne_set_ref_batch)");
     const int F = h->F;
@@ -1411,14 +1435,16 @@ static int ref_pass(dne_handle *h, int n) {
     // chunks alternate between two streams with their own scratch: the statistics kernels (one workgroup per
     // member, latency-bound) of one chunk run under the MFMA convolutions of the next
     const int nways = n > h->ref_chunk ? 2 : 1;
+    async = async && nways > 1;
     if (nways > 1) {
         HCHECK(h, hipEventRecord(h->ev_ref[0], h->stream));
-        HCHECK(h, hipStreamWaitEvent(h->sub_streams[1], h->ev_ref[0], 0));
+        HCHECK(h, hipStreamWaitEvent(async ? h->ref_streams[1] : h->sub_streams[1], h->ev_ref[0], 0));
+        if (async) HCHECK(h, hipStreamWaitEvent(h->ref_streams[0], h->ev_ref[0], 0));
     }
     int c = 0;
     for (int m0 = 0; m0 < n; m0 += h->ref_chunk, c++) {
         const int nc = std::min(h->ref_chunk, n - m0), w = c % nways;
-        hipStream_t st = h->sub_streams[w];
+        hipStream_t st = async ? h->ref_streams[w] : h->sub_streams[w];
         float *y1 = h->y1r[w], *y2 = h->y2r[w], *y3p = h->y3pr[w];
         float *fr1 = h->fr1[w], *fr2 = h->fr2[w];
         const int fpw = h->conv1_fpw >= 8 ? 8 : h->conv1_fpw >= 4 ? 4 : h->conv1_fpw >= 2 ? 2 : 1;   // F is a multiple of 8
@@ -1457,8 +1483,17 @@ static int ref_pass(dne_handle *h, int n) {
                                (float *)nullptr);
             hipLaunchKernelGGL(k_bn3_rows, dim3(nc), dim3(256), 0, st, A, m0, F, (const float *)y3p);
         }
+        if (async) {
+            while ((int)h->ev_chunk.size() <= c) {
+                hipEvent_t e;
+                HCHECK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                h->ev_chunk.push_back(e);
+            }
+            HCHECK(h, hipEventRecord(h->ev_chunk[c], st));
+        }
     }
-    if (nways > 1) {
+    if (async) h->ref_chunks_async = c;
+    else if (nways > 1) {
         HCHECK(h, hipEventRecord(h->ev_ref[1], h->sub_streams[1]));
         HCHECK(h, hipStreamWaitEvent(h->stream, h->ev_ref[1], 0));
     }
@@ -1475,6 +1510,19 @@ extern "C" int dne_debug_phase_clock(dne_handle *h, long long *out) {
 #else
     (void)out;
     return h->fail("dne_debug_phase_clock: this library was built without DNE_PHASE_CLOCK (make clock)");
+#endif
+}
+
+// profiling build: k_fc_duo's tick stamps of its last launch (env_synth.h: g_duo_tick [64][8][288][2], g_duo_plan [64][8][8])
+extern "C" int dne_debug_duo_ticks(dne_handle *h, long long *ticks, long long *plan) {
+#ifdef DNE_PHASE_CLOCK
+    HCHECK(h, hipDeviceSynchronize());
+    HCHECK(h, hipMemcpyFromSymbol(ticks, HIP_SYMBOL(dne::g_duo_tick), sizeof(long long) * dne::DUO_TICK_WGS * 8 * dne::DUO_TICK_MAX * 2));
+    HCHECK(h, hipMemcpyFromSymbol(plan, HIP_SYMBOL(dne::g_duo_plan), sizeof(long long) * dne::DUO_TICK_WGS * 8 * 8));
+    return 0;
+#else
+    (void)ticks; (void)plan;
+    return h->fail("dne_debug_duo_ticks: this library was built without DNE_PHASE_CLOCK (make clock)");
 #endif
 }
 
@@ -1607,7 +1655,13 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         const int duo_grid = h->duo_grid ? h->duo_grid : (w4 ? 2 * h->fc_grid : h->fc_grid);
         const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 4 * rounds - 1) / (4 * rounds), blocks = std::min(items, duo_grid);
         const size_t out_lds = (size_t)h->out_lds_kb * 1024;   // an LDS reservation nobody uses: it only bounds k_out's workgroups per CU next to the streaming fc
-        if (w4) hipLaunchKernelGGL((k_fc_duo<2, true, true, 4>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
+        const bool ring = es && gsize == 2 && sweep && h->theta_perm && h->uniform_base && (h->ring_on > 1 || !solo);
+        if (ring) {   // one unit per wave, eight units per workgroup whatever the regime
+            const int ring_blocks = std::min((n_units + 7) / 8, duo_grid);
+            if (h->duo_fat) hipLaunchKernelGGL((k_fc_ring<true, 8>), dim3(ring_blocks), dim3(512), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, (const float *)h->theta_perm, h->fc_prio << 9);
+            else hipLaunchKernelGGL((k_fc_ring<false, 8>), dim3(ring_blocks), dim3(512), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, (const float *)h->theta_perm, h->fc_prio << 9);
+        }
+        else if (w4) hipLaunchKernelGGL((k_fc_duo<2, true, true, 4>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
         else if (es && sweep && h->duo_fat) hipLaunchKernelGGL((k_fc_duo<2, true, true, 8, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
         else if (es && sweep) hipLaunchKernelGGL((k_fc_duo<2, true, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
         else if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
@@ -1701,9 +1755,16 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     if (prof) HCHECK(h, hipEventRecord(h->event(0), h->stream));
     h->trace("eval: %d members (groups of %d), tslimit %d: reset launched", n, gsize, tslimit);
     if (h->debug_sync) { HCHECK(h, hipStreamSynchronize(h->stream)); HCHECK(h, hipGetLastError()); }
-    if (ref_pass(h, n)) return -1;
+    if (h->theta_perm && h->uniform_base && gsize == 2)   // k_fc_ring reads base slot 0's fc matrix in its own column order
+        hipLaunchKernelGGL(k_theta_perm, dim3(3872 + 16), dim3(256), 0, h->stream, (const float *)(h->bases + h->L.fcw), h->theta_perm, 3872);
+    if (ref_pass(h, n, h->ref_overlap && !h->debug_sync)) return -1;
     if (h->debug_sync) { HCHECK(h, hipDeviceSynchronize()); HCHECK(h, hipGetLastError()); }
     h->trace("eval: reference pass %s", h->debug_sync ? "done" : "launched");
+    if (h->ref_chunks_async) {   // the pass is in flight on its own streams: its end, for the profile, is the later of their last chunks
+        const int last = h->ref_chunks_async - 1;
+        HCHECK(h, hipStreamWaitEvent(h->ref_streams[last & 1], h->ev_chunk[last - 1], 0));
+        HCHECK(h, hipEventRecord(h->event(1), h->ref_streams[last & 1]));
+    } else
     HCHECK(h, hipEventRecord(h->event(1), h->stream));
     const int groups = n / gsize;
     hipLaunchKernelGGL(k_iota, dim3((groups + 255) / 256), dim3(256), 0, h->stream, h->list_a, groups);
@@ -1787,6 +1848,13 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 if (cnt == 0) continue;
                 hipStream_t sst = h->sub_streams[s];
                 const int *lst = cur + lo;
+                if (h->ref_chunks_async && t == 0 && st == 0) {
+                    // first lock-step of the evaluation: the list is 0, 1, 2, ... so the window's members are [lo * gsize, (lo + cnt) * gsize);
+                    // the chunks alternate between two streams, each in order: the window's last chunk and the one before it cover all
+                    const int c_hi = ((lo + cnt) * gsize - 1) / h->ref_chunk;
+                    HCHECK(h, hipStreamWaitEvent(sst, h->ev_chunk[c_hi], 0));
+                    if (c_hi > 0) HCHECK(h, hipStreamWaitEvent(sst, h->ev_chunk[c_hi - 1], 0));
+                }
                 std::array<size_t, 4> e{};
                 // events only around full-width launches: in the latency-bound tail every event packet is a bubble
                 // (with k_fc2 enabled the profiled launches are exactly the k_fc2 ones: the roofline kernel of bench.py)
@@ -1875,6 +1943,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
             }
         }
         t += burst;
+        h->ref_chunks_async = 0;   // every window has waited for its chunks and the windows cover the list: the pass is over with this burst
         for (int s = 1; s < nsub; s++) HCHECK(h, hipStreamSynchronize(h->sub_streams[s]));
         hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, (const int32_t *)h->done, gsize, (const int *)cur,
                            total, nxt, h->count_dev);
@@ -2415,12 +2484,16 @@ extern "C" int dne_comm_init(dne_handle *h, int rank, int nranks, const void *un
     // atomic flag -- no error text (h->fail writes the shared buffer), no trace -- and returns a code.  The handle must not be
     // destroyed while an initialisation is still in flight (bench.py leaves through os._exit in that case).
     const ncclResult_t init_rc = g_rccl.CommInitRank(&c, nranks, id, rank);
-    if (h->comm_off.load(std::memory_order_acquire)) {
-        if (init_rc == ncclSuccess && c) g_rccl.CommAbort(c);
-        return -2;   // DNE_COMM_DROPPED
+    {   // the flag is read and the communicator published under the lock dne_comm_abort takes: an abort either comes first (this
+        // call drops its communicator) or finds the published one and aborts it -- never a live communicator on a handle that is off
+        std::lock_guard<std::mutex> lk(h->comm_mu);
+        if (h->comm_off.load(std::memory_order_acquire)) {
+            if (init_rc == ncclSuccess && c) g_rccl.CommAbort(c);
+            return -2;   // DNE_COMM_DROPPED
+        }
+        if (init_rc == ncclSuccess) { h->comm = c; h->comm_rank = rank; h->comm_size = nranks; }
     }
     if (init_rc != ncclSuccess) return h->fail("ncclCommInitRank -> %s", g_rccl.GetErrorString(init_rc));
-    h->comm = c; h->comm_rank = rank; h->comm_size = nranks;
     HCHECK(h, h->alloc(&h->comm_scratch, 64, "comm_scratch"));
     h->trace("comm ready");
     return 0;
@@ -2467,6 +2540,7 @@ extern "C" int dne_comm_share(dne_handle *h, dne_handle *owner) {
 // Give up on RCCL for this handle (the ranks agreed on another carrier): an existing communicator is aborted, one that a
 // still-running dne_comm_init on another thread produces later is dropped.  Afterwards the handle behaves like a single rank.
 extern "C" int dne_comm_abort(dne_handle *h) {
+    std::lock_guard<std::mutex> lk(h->comm_mu);
     h->comm_off.store(true, std::memory_order_release);
     if (h->comm && !h->comm_borrowed && g_rccl.lib) g_rccl.CommAbort((ncclComm_t)h->comm);
     h->comm = nullptr; h->comm_rank = 0; h->comm_size = 1;

@@ -27,7 +27,14 @@ __device__ long long g_phase[6][128][8];
 #define DNE_ACC(I) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = (long long)wall_clock64(); pacc_[I] += t_ - pprev_; pprev_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #define DNE_ACC_STORE(K) DNE_ACC_STORE_EVERY(K, 1)
 // every STRIDE-th workgroup of the launch (the first 128 of them): a sample over the whole launch instead of its first wave; slot 6: the end
-#define DNE_ACC_STORE_EVERY(K, STRIDE) do { if (threadIdx.x == 0 && blockIdx.x % (STRIDE) == 0 && blockIdx.x / (STRIDE) < 128) { pacc_[6] = (long long)wall_clock64(); for (int i_ = 0; i_ < 8; i_++) dne::g_phase[K][blockIdx.x / (STRIDE)][i_] = pacc_[i_]; } } while (0)
+// (a launch of fewer than 128 workgroups: stride 1, not 0)
+#define DNE_ACC_STORE_EVERY(K, STRIDE) do { const unsigned st_ = (STRIDE) > 0 ? (unsigned)(STRIDE) : 1u; if (threadIdx.x == 0 && blockIdx.x % st_ == 0 && blockIdx.x / st_ < 128) { pacc_[6] = (long long)wall_clock64(); for (int i_ = 0; i_ < 8; i_++) dne::g_phase[K][blockIdx.x / st_][i_] = pacc_[i_]; } } while (0)
+// k_fc_duo's table timeline (tools/duo_tick_clock.py): for 64 workgroups spread over the launch, the second work item of each --
+// per wave and tick the shader clock in front of and behind the tick's s_barrier, plus the item's plan (start delay and length of
+// every wave in ticks) and the 100 MHz wall clock at both ends (calibrates the shader clock)
+constexpr int DUO_TICK_WGS = 64, DUO_TICK_MAX = 288;
+__device__ long long g_duo_tick[DUO_TICK_WGS][8][DUO_TICK_MAX][2];   // (k_fc_duo: waves 0-3; k_fc_ring: all eight)
+__device__ long long g_duo_plan[DUO_TICK_WGS][8][8];   // delay, len, tmax, ticks recorded, memtime start, memtime end, wall start, wall end
 #else
 #define DNE_PHASE(K, I) do { } while (0)
 #define DNE_ACC_DECL do { } while (0)

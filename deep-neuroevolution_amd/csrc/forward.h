@@ -551,7 +551,9 @@ __global__ __launch_bounds__(256, 2) void k_conv2_ref(FwdArgs A, int F, int memb
     // output row's wrap (2 * 27 * 20 floats) continues the sequence (1080 - 11 * 40 = 10 * 64)
     constexpr int PS = 20, RW = C2_RW, Y2S = PAD ? Y2_PAD_ROW : 3872;
     __shared__ __attribute__((aligned(16))) float a_s[24 * RW * PS];
-    __shared__ float wsum[4][2][16];
+    // two sets: the loop's frames use set 0 (a barrier lies between every read and the next write); the last frame's epilogue
+    // writes set 1, because wave 0 may still be reading frame FPW - 2's sums from set 0 when the other waves get there
+    __shared__ float wsum[2][4][2][16];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, lk = lane >> 4;
     const int nt = wv & 1, mt0 = 4 * (wv >> 1);
     const int gpm = F / FPW, mloc = blockIdx.x / gpm, f0 = (blockIdx.x % gpm) * FPW, member = member0 + mloc;
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2_ref(FwdArgs A, int F, int memb
         }
     };
     // a frame's results out: y2 rows, and this wave's four tiles' moments in tile order into wsum (every lane group holds the sums)
-    auto epilogue = [&](const f32x4 (&acc)[4], size_t row) {
+    auto epilogue = [&](const f32x4 (&acc)[4], size_t row, int set) {
         float *o = y2 + row * Y2S;
 #pragma unroll
         for (int m = 0; m < 4; m++)
@@ -641,13 +643,13 @@ __global__ __launch_bounds__(256, 2) void k_conv2_ref(FwdArgs A, int F, int memb
         float Ws = 0.0f, Wq = 0.0f;                  // this wave's four tiles in tile order, then (tiles 0-3) + (tiles 4-7)
 #pragma unroll
         for (int m = 0; m < 4; m++) tile_moments(acc[m], (mt0 + m) * 16 + lk * 4, 121, Ws, Wq);
-        wsum[wv][0][lp] = Ws;
-        wsum[wv][1][lp] = Wq;
+        wsum[set][wv][0][lp] = Ws;
+        wsum[set][wv][1][lp] = Wq;
     };
-    auto frame_moments = [&](size_t row) {
+    auto frame_moments = [&](size_t row, int set) {
         if (tid < 64) {
             const int k = tid >> 5, c = tid & 31, h = c >> 4, l = c & 15;
-            fr[(row * 2 + k) * 32 + c] = wsum[h][k][l] + wsum[h + 2][k][l];
+            fr[(row * 2 + k) * 32 + c] = wsum[set][h][k][l] + wsum[set][h + 2][k][l];
         }
     };
     DNE_ACC_DECL;   // profiling build: 0 = prologue + staging, 1 = barrier, 2 = MFMAs (+ the previous frame's epilogue), 3 = barrier + frame moments
@@ -731,19 +733,19 @@ __global__ __launch_bounds__(256, 2) void k_conv2_ref(FwdArgs A, int F, int memb
                 __builtin_amdgcn_sched_barrier(0);
             });
             moment_piece(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});
-            wsum[wv][0][lp] = Ws;
-            wsum[wv][1][lp] = Wq;
+            wsum[0][wv][0][lp] = Ws;
+            wsum[0][wv][1][lp] = Wq;
         }
 #pragma unroll
         for (int m = 0; m < 4; m++) accp[m] = acc[m];
         DNE_ACC(2);
         __syncthreads();                             // every wave is done reading this frame's image; wsum of the previous frame is complete
-        if (fi > 0) frame_moments(row0 + fi - 1);
+        if (fi > 0) frame_moments(row0 + fi - 1, 0);
         DNE_ACC(3);
     }
-    epilogue(accp, row0 + FPW - 1);
+    epilogue(accp, row0 + FPW - 1, 1);
     __syncthreads();
-    frame_moments(row0 + FPW - 1);
+    frame_moments(row0 + FPW - 1, 1);
     DNE_ACC_STORE_EVERY(4, gridDim.x / 128);
 }
 
@@ -1419,6 +1421,11 @@ __device__ __forceinline__ void gload4_after(f32x4 &dst, unsigned voff, const fl
     asm volatile("global_load_dwordx4 %[d], %[vo], %[sb] offset:%[of]" DNE_EPS_MOD
                  : [d] "+v"(dst), "+v"(a0), "+v"(a1) : [vo] "v"(voff), [sb] "s"(sbase), [of] "n"(OFF));
 }
+template <int OFF>   // a base row, pinned behind the accumulator updates of the row it replaces (k_fc_ring)
+__device__ __forceinline__ void gload4_theta_after(f32x4 &dst, unsigned voff, const float *sbase, f32x2 &a0, f32x2 &a1, f32x2 &a2, f32x2 &a3) {
+    asm volatile("global_load_dwordx4 %[d], %[vo], %[sb] offset:%[of]" DNE_THETA_MOD
+                 : [d] "+v"(dst), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : [vo] "v"(voff), [sb] "s"(sbase), [of] "n"(OFF));
+}
 template <int N>
 __device__ __forceinline__ void wait_rows(f32x4 &a, f32x4 &b) {
     asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(a), "+v"(b) : [n] "n"(N));
@@ -1469,9 +1476,26 @@ __global__ __launch_bounds__(256, FAT ? 1 : W == 8 ? 2 : 4) void k_fc_duo(FwdArg
     const bool solo = (lag & 256) != 0;   // sparse windows: one unit per wave (twice the waves, nothing to share anyway)
     const int sw_sync = ((lag >> 11) & 7) + 1;   // SWEEP: one s_barrier every sw_sync row blocks of the workgroup's timeline
     int sw_t = 0;                                // SWEEP: the workgroup's time in row blocks (the same sequence in every wave)
+#ifdef DNE_PHASE_CLOCK
+    bool tk_on = false;   // profiling build: this work item's ticks are stamped (env_synth.h: g_duo_tick)
+    int tk_i = 0;
+    const int tk_wg = blockIdx.x / 4;
+#endif
     auto sw_tick = [&]() {
         sw_t++;
+#ifdef DNE_PHASE_CLOCK
+        long long tk_b = 0;
+        if (tk_on) { __builtin_amdgcn_sched_barrier(0); tk_b = (long long)__builtin_amdgcn_s_memtime(); }
+#endif
         if (sw_sync == 1 || sw_t % sw_sync == 0) __builtin_amdgcn_s_barrier();
+#ifdef DNE_PHASE_CLOCK
+        if (tk_on) {
+            const long long tk_a = (long long)__builtin_amdgcn_s_memtime();
+            if (lane == 0 && tk_i < DUO_TICK_MAX) { g_duo_tick[tk_wg][wv][tk_i][0] = tk_b; g_duo_tick[tk_wg][wv][tk_i][1] = tk_a; }
+            tk_i++;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
     };
     const int rounds = SWEEP ? ((lag >> 14) & 3) + 1 : 1;   // SWEEP: duos a wave takes one after the other on the workgroup's timeline
     lag &= 255;
@@ -1542,8 +1566,24 @@ __global__ __launch_bounds__(256, FAT ? 1 : W == 8 ? 2 : 4) void k_fc_duo(FwdArg
                 tmax = max(tmax, delay + lj);
             }
             mine = uni(mine); tmax = uni(tmax);
+#ifdef DNE_PHASE_CLOCK
+            tk_on = blockIdx.x % 4 == 0 && tk_wg < DUO_TICK_WGS && item == (int)(blockIdx.x + gridDim.x);
+            tk_i = 0;
+            if (tk_on && lane == 0) {
+                long long *pl = g_duo_plan[tk_wg][wv];
+                pl[0] = mine; pl[1] = total; pl[2] = tmax; pl[3] = 0;
+                pl[4] = (long long)__builtin_amdgcn_s_memtime(); pl[6] = (long long)wall_clock64();
+            }
+#endif
             if (total == 0) {      // a wave without work still takes part in the workgroup's barriers
                 for (int i = 0; i < tmax; i++) sw_tick();
+#ifdef DNE_PHASE_CLOCK
+                if (tk_on && lane == 0) {
+                    long long *pl = g_duo_plan[tk_wg][wv];
+                    pl[3] = tk_i; pl[5] = (long long)__builtin_amdgcn_s_memtime(); pl[7] = (long long)wall_clock64();
+                }
+                tk_on = false;
+#endif
                 continue;
             }
             for (int i = 0; i < mine; i++) sw_tick();
@@ -1618,8 +1658,8 @@ __global__ __launch_bounds__(256, FAT ? 1 : W == 8 ? 2 : 4) void k_fc_duo(FwdArg
         };
         // A rolling window of W rows per stream: row i of a block is consumed and its registers are refilled at once with row i
         // of the next block, so W rows per stream stay in flight and no register is ever copied.  The block after a unit's
-        // last one is fetched too and never used: it lies inside the member's own parameter slice (fc bias, bn3 and the
-        // output layer follow the fc matrix).
+        // last one is fetched too and never used: fc bias, bn3 and the output layer follow the fc matrix, and the allocations are
+        // padded by a block for small action counts (engine.hip OVERFETCH_FLOATS).
         f32x4 eA[W], tA[W], eB[W], tB[W];
 #pragma unroll
         for (int i = 0; i < W; i++) eA[i] = tA[i] = eB[i] = tB[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1762,6 +1802,293 @@ __global__ __launch_bounds__(256, FAT ? 1 : W == 8 ? 2 : 4) void k_fc_duo(FwdArg
         }   // rounds
         if constexpr (SWEEP)
             for (int i = 0; i < sw_tail; i++) sw_tick();
+#ifdef DNE_PHASE_CLOCK
+        if (tk_on && lane == 0) {
+            long long *pl = g_duo_plan[tk_wg][wv];
+            pl[3] = tk_i; pl[5] = (long long)__builtin_amdgcn_s_memtime(); pl[7] = (long long)wall_clock64();
+        }
+        tk_on = false;
+#endif
+    }
+}
+
+// ------------------------------------------------------- k_fc_ring (round 5): the workgroup's noise rows through an LDS ring
+// What k_fc_duo waits for (profiles/r05_duo_tick_clock.json, r05_pmc_fc_duo_mem.json): a tick of its table timeline costs
+// 0.45 us + 0.12 us per streaming unit -- a fixed HBM round trip (every row is consumed exactly one tick after it was requested, and
+// the unit at the front of the timeline misses every cache) plus the CU's vector-memory path at ~56 B/clk for the 16 KB each unit
+// pulls through it, although the eight units of a workgroup read the SAME 4096-float window of the table within a tick.
+// Here the window lives in LDS: a ring of 2048-float segments (one tick of the timeline each) that the four waves fill by LDS-DMA
+// (global_load_lds_dwordx4: no register round trip) RING_PD ticks ahead -- every table row passes the vector-memory path once per
+// workgroup instead of once per unit (72 KB per full tick instead of 128 KB), and its HBM latency is hidden by the prefetch distance
+// instead of being paid every tick.  A unit's row starts at an arbitrary float of the table (es.py:67 draws any integer), so the LDS
+// reads cannot be 16-byte reads; lane l takes columns l, l+64, l+128, l+192 instead -- consecutive lanes read consecutive banks at any
+// alignment (two ds_read2st64_b32 per row) -- and the base rows come from a copy of the fc matrix whose rows are stored in that
+// order (k_theta_perm, once per evaluation), so that they stay one 16-byte load per lane and row.  Which lane holds which column
+// is not arithmetic: every output's chain still runs over k in order from zero (oracle fc_raw) -- same bits.
+constexpr int RING_SLOTS = 6, RING_SEG = 2048, RING_PD = 4;   // slots (+ one mirror of slot 0 behind the last), floats per segment, prefetch distance in ticks
+
+__global__ __launch_bounds__(256) void k_theta_perm(const float *__restrict__ fcw /*[rows][256]*/, float *__restrict__ out /*[rows + 16][256]*/, int rows) {
+    const int r = blockIdx.x, t = threadIdx.x;   // out[r][4 l + j] = in[r][l + 64 j]; the rows behind the matrix (over-fetched, never used) are zero
+    out[(size_t)r * 256 + t] = r < rows ? fcw[(size_t)r * 256 + (t >> 2) + 64 * (t & 3)] : 0.0f;
+}
+
+// 16 bytes per lane from global memory straight into LDS at lds_dst + lane * 16 (wave-uniform destination); counted by vmcnt like any
+// other vector load, visible to other waves' ds_reads after the issuing wave's counted wait and a barrier
+__device__ __forceinline__ void glds16(const float *sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// row I of a unit's current block: floats vaddr/4 + 256 I + {0, 64, 128, 192} of the ring (the lane's four columns); lands asynchronously
+template <int I>
+__device__ __forceinline__ void ring_row(f32x2 &lo, f32x2 &hi, unsigned vaddr) {
+    asm volatile("ds_read2st64_b32 %0, %2 offset0:%3 offset1:%4\n\tds_read2st64_b32 %1, %2 offset0:%5 offset1:%6"
+                 : "=v"(lo), "=v"(hi) : "v"(vaddr), "n"(4 * I), "n"(4 * I + 1), "n"(4 * I + 2), "n"(4 * I + 3));
+}
+
+// One workgroup = NW waves = NW units that follow each other in table order, ONE unit per wave: two waves per SIMD hide each other's
+// VALU latency (one wave per SIMD issued a packed op every ~8 cycles: the first form of this kernel, two units per wave on four
+// waves, spent 0.93 us of wave time per 16 row-sides), and a wave's only loop with loads in flight is entered behind a full drain
+// and left into one -- no phase change carries registers that a load is still writing (the compiler places copies there).
+template <bool FAT, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void k_fc_ring(FwdArgs A, const int *__restrict__ order, int n_units, const float *__restrict__ y2,
+                                                     float *__restrict__ y3t, const float *__restrict__ theta_perm, int flags) {
+    constexpr int NV = 2, W = 8, NBLK = 968 / W, BPC = 64 / W, R = RING_SLOTS, PD = RING_PD;
+    constexpr int QF = RING_SEG / NW;       // floats of a segment each wave requests per tick
+    constexpr int ND = QF / 256;            // = LDS-DMA instructions per wave and tick (1 KB each)
+    static_assert(RING_SEG == W * 256 && QF % 256 == 0, "one segment = one tick of the timeline, whole 1 KB pieces per wave");
+    // at most one workgroup per CU by register footprint: > 128 registers per lane with two of its waves per SIMD leaves
+    // room for a 199-register k_conv12 wave beside them and none for a second workgroup of this kernel
+    if constexpr (FAT) asm volatile("v_accvgpr_write_b32 a63, %0" : : "v"(0) : "a63");
+    __shared__ __attribute__((aligned(16))) float ring[(R + 1) * RING_SEG];
+    __shared__ long long sw_key[2][NW];     // the waves' units' table addresses (or -1), double-buffered by item parity
+    const int tid = threadIdx.x, wv = uni(tid >> 6), lane = tid & 63;
+    const unsigned voff = lane * 16, vlane4 = lane * 4;
+    const unsigned lds_ring = (unsigned)(size_t)ring;
+    const Layout &L = A.L;
+    {
+        const int prio = (flags >> 9) & 3;
+        if (prio == 3) __builtin_amdgcn_s_setprio(3);
+        else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    }
+    const int n_items = (n_units + NW - 1) / NW;
+    int par = 0;
+#ifdef DNE_PHASE_CLOCK
+    bool tk_on = false;
+    int tk_i = 0;
+    const int tk_wg = blockIdx.x / 4;
+#endif
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        int uu = item * NW + wv < n_units ? uni(order[item * NW + wv]) : -1;
+        if (uu >= 0 && A.done) {   // units of finished pairs are dropped
+            int all_done = 1;
+#pragma unroll
+            for (int v = 0; v < NV; v++) all_done &= uni(A.done[(uu >> 2) * NV + v]) != 0;
+            if (all_done) uu = -1;
+        }
+        const bool ok = uu >= 0;
+        // absolute float index of the unit's first weight in the noise table
+        const long long key = ok ? uni64(A.m_off[(size_t)(uu >> 2) * NV]) + (long long)L.fcw + (long long)(uu & 3) * SLICE_FLOATS : -1;
+        if (lane == 0) sw_key[par][wv] = key;
+        __syncthreads();
+        long long K0 = 0x7fffffffffffffffll, kmax = -1;
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            const long long k = sw_key[par][j];
+            if (k >= 0) { K0 = min(K0, k); kmax = max(kmax, k); }
+        }
+        par ^= 1;
+        K0 = uni64(K0); kmax = uni64(kmax);
+        if (kmax < 0) continue;                       // every unit of this item belongs to a finished pair (the same answer in every wave)
+        K0 &= ~3ll;                                   // 16-byte-aligned DMA sources
+        const int tmax = (int)((kmax - K0) >> 11) + NBLK;
+        const float *seg0 = A.noise + K0 + wv * QF;   // this wave's share of segment 0
+        int tau = 0, slot = 0;                        // the workgroup's time in ticks (= segments) and the ring slot of segment tau
+        // this wave's share of segment j (clamped to the last segment anybody reads: the number of DMAs per tick must not change, the
+        // counted waits below rely on it) into slot sj
+        auto dma_seg = [&](int j, int sj) {
+            const float *src = seg0 + (size_t)min(j, tmax) * RING_SEG;
+            const unsigned dst = lds_ring + (unsigned)(sj * RING_SEG + wv * QF) * 4u;
+#pragma unroll
+            for (int d = 0; d < ND; d++) glds16(src + 256 * d, voff, dst + 1024 * d);
+        };
+        // a block that starts in the last slot runs on into the mirror of slot 0 behind it
+        auto mirror_due = [&]() { int sj = slot + PD; if (sj >= R) sj -= R; return sj == 0; };
+#pragma unroll
+        for (int j = 0; j < PD; j++) dma_seg(j, j);
+        dma_seg(0, R);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int q = ok ? (int)((key - K0) >> 11) : 0;               // the unit's first row sits dlt floats into segment q
+        const int dlt = ok ? (int)(key - K0) - q * RING_SEG : 0;
+#ifdef DNE_PHASE_CLOCK
+        tk_on = blockIdx.x % 4 == 0 && tk_wg < DUO_TICK_WGS && item == (int)(blockIdx.x + gridDim.x);
+        tk_i = 0;
+        if (tk_on && lane == 0) {
+            long long *pl = g_duo_plan[tk_wg][wv];
+            pl[0] = q; pl[1] = ok ? NBLK : 0; pl[2] = tmax; pl[3] = 0;
+            pl[4] = (long long)__builtin_amdgcn_s_memtime(); pl[6] = (long long)wall_clock64();
+        }
+#endif
+        // the end of a tick: segment tau + PD requested (an active wave has issued a due mirror copy in the middle of the tick), barrier
+        auto tick_end = [&](bool idle) {
+            int sj = slot + PD;
+            if (sj >= R) sj -= R;
+            dma_seg(tau + PD, sj);
+            if (idle && sj == 0) dma_seg(tau + PD, R);
+#ifdef DNE_PHASE_CLOCK
+            long long tk_b = 0;
+            if (tk_on) { __builtin_amdgcn_sched_barrier(0); tk_b = (long long)__builtin_amdgcn_s_memtime(); }
+#endif
+            if (idle) {   // nothing else retires an idle wave's DMAs: all but this tick's own (ND, or 2 ND with the mirror)
+                if (sj == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * ND) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+#ifdef DNE_PHASE_CLOCK
+            if (tk_on) {
+                const long long tk_a = (long long)__builtin_amdgcn_s_memtime();
+                if (lane == 0 && tk_i < DUO_TICK_MAX) { g_duo_tick[tk_wg][wv][tk_i][0] = tk_b; g_duo_tick[tk_wg][wv][tk_i][1] = tk_a; }
+                tk_i++;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+            tau++;
+            slot = slot + 1 == R ? 0 : slot + 1;
+        };
+        auto idle_until = [&](int T) { while (tau < T) tick_end(true); };
+        idle_until(q);
+        if (ok) {
+            const int g = uu >> 2, sl = uu & 3;
+            const float *tnext = theta_perm + (size_t)sl * SLICE_FLOATS;   // (every member of an ES evaluation has base slot 0: the engine checks)
+            const int ch = (8 * sl + lane) & 31;   // bn2 channel of this lane's activation rows (968 = 8 mod 32)
+            const int mem0 = g * NV;
+            const float scale0 = A.m_scale[mem0];  // an antithetic pair: +sigma, -sigma exactly
+            float s2[NV], h2[NV], xv[NV], xn[NV];
+            const float *xs[NV];
+            f32x2 acc[NV][2], fold[NV][2];
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                s2[v] = A.bn[(size_t)(mem0 + v) * 608 + 32 + ch];
+                h2[v] = A.bn[(size_t)(mem0 + v) * 608 + 64 + ch];
+                xs[v] = y2 + (size_t)(mem0 + v) * 3872 + 968 * sl;
+                acc[v][0] = acc[v][1] = fold[v][0] = fold[v][1] = f32x2{0.0f, 0.0f};
+                xv[v] = xn[v] = 0.0f;
+            }
+            // activations: chunk c = rows 64 c .. 64 c + 63 of the unit's slice, one row per lane; the raw values of chunk c + 1 are requested
+            // when chunk c starts and turned into relu(bn2(.)) eight ticks later (loads complete in order: long landed)
+            auto request_x = [&](int c) {
+                if (c >= 16) return;
+                unsigned vo = voff;
+                asm volatile("" : "+v"(vo));
+                const unsigned xoff = c < 15 ? vo >> 2 : min(vo >> 2, 28u);
+#pragma unroll
+                for (int v = 0; v < NV; v++)
+                    asm volatile("global_load_dword %[d], %[vo], %[sb]" : [d] "=v"(xn[v]), "+v"(xv[v]) : [vo] "v"(xoff), [sb] "s"(xs[v] + 64 * c));
+            };
+            auto take_x = [&](int c) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) {
+                    asm volatile("" : "+v"(xn[v]));
+                    float t = xn[v];
+                    t = t * s2[v];
+                    t = t + h2[v];
+                    t = t > 0.0f ? t : 0.0f;
+                    xv[v] = (c < 15 || lane < 8) ? t : 0.0f;
+                }
+            };
+            f32x4 t[W];
+            f32x2 e[2][2];   // the noise values of the current / next row (two register sets), columns (l, l+64) and (l+128, l+192)
+#pragma unroll
+            for (int i = 0; i < W; i++) t[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 2; i++) e[i][0] = e[i][1] = f32x2{0.f, 0.f};
+            auto refill = [&](auto ii) {   // row I of the next block of base rows, into the registers of the row just consumed
+                constexpr int I = decltype(ii)::value;
+                gload4_theta_after<(I % 4) * 1024>(t[I], voff, tnext + (I / 4) * 1024, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+            };
+            // the first block of base rows and the first two chunks of activations: everything landed before the loop is entered (the
+            // compiler may copy registers at the loop's entry; it must not copy one that a load is still writing)
+            request_x(0);
+            static_for<W>(refill);
+            tnext += W * 256;
+#pragma unroll
+            for (int i = 0; i < W; i++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[i]));
+            take_x(0);
+            request_x(1);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn[0]), "+v"(xn[1]));
+            // before row i is read, the loads issued after its own are the (W - 1) other rows and the ND DMAs of the tick's end (a lower
+            // bound: mirror copies and activation loads only make the wait stricter)
+            constexpr int PENDING = (W - 1) + ND;
+            int nb = FC_SUB0 / W;   // row block at which the current sub-slice ends
+            for (int lb = 0; lb < NBLK; lb++) {
+                const int li = (lb % BPC) * W;
+                const unsigned va = vlane4 + (lds_ring + (unsigned)(slot * RING_SEG + dlt) * 4u);
+                const bool mir = mirror_due();
+                ring_row<0>(e[0][0], e[0][1], va);
+                static_for<W>([&](auto ii) {
+                    constexpr int I = decltype(ii)::value;
+                    asm volatile("s_waitcnt vmcnt(%[n]) lgkmcnt(0)" : "+v"(t[I]), "+v"(e[I & 1][0]), "+v"(e[I & 1][1]) : [n] "n"(PENDING));
+                    if constexpr (I + 1 < W) {   // the next row's noise values are on their way while this row is computed
+                        ring_row<I + 1>(e[(I + 1) & 1][0], e[(I + 1) & 1][1], va);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    {
+                        const f32x2 tlo = {t[I][0], t[I][1]}, thi = {t[I][2], t[I][3]};
+                        // fl(-sigma eps) = -fl(sigma eps): the second member's weight is base - p with the first member's p (es.py:415, 419)
+                        const f32x2 sc = {scale0, scale0};
+                        const f32x2 pl = sc * e[I & 1][0], ph = sc * e[I & 1][1];
+                        const float x0 = lane_bcast(xv[0], li + I), x1 = lane_bcast(xv[1], li + I);
+                        const f32x2 xx0 = {x0, x0}, xx1 = {x1, x1};
+                        const f32x2 wl0 = tlo + pl, wh0 = thi + ph, wl1 = tlo - pl, wh1 = thi - ph;
+                        acc[0][0] = __builtin_elementwise_fma(xx0, wl0, acc[0][0]);
+                        acc[0][1] = __builtin_elementwise_fma(xx0, wh0, acc[0][1]);
+                        acc[1][0] = __builtin_elementwise_fma(xx1, wl1, acc[1][0]);
+                        acc[1][1] = __builtin_elementwise_fma(xx1, wh1, acc[1][1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    refill(ii);
+                    if constexpr (I == 3) {   // a due mirror copy goes out in the middle of the tick: behind the tick's end it would be the
+                        if (mir) dma_seg(tau + PD, R);   // first thing the next tick's counted waits retire, a fresh HBM round trip
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                tnext += W * 256;
+                if (lb % BPC == BPC - 1 && lb + 1 < NBLK) {
+                    take_x(lb / BPC + 1);
+                    request_x(lb / BPC + 2);
+                }
+                if (lb + 1 == nb) {   // end of a sub-slice (oracle fc_raw): the chain joins the quarter's left fold and starts again from 0
+                    const bool first = nb == FC_SUB0 / W;
+#pragma unroll
+                    for (int v = 0; v < NV; v++)
+#pragma unroll
+                        for (int hf = 0; hf < 2; hf++) {
+                            fold[v][hf] = first ? acc[v][hf] : fold[v][hf] + acc[v][hf];
+                            acc[v][hf] = f32x2{0.0f, 0.0f};
+                        }
+                    nb += FC_SUBN / W;
+                }
+                tick_end(false);
+            }
+#pragma unroll
+            for (int i = 0; i < W; i++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[i]));   // the over-fetched block, the last DMAs
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                float *o = y3t + ((size_t)(mem0 + v) * 4 + sl) * 256 + lane;
+                o[0] = fold[v][0][0]; o[64] = fold[v][0][1]; o[128] = fold[v][1][0]; o[192] = fold[v][1][1];
+            }
+        }
+        idle_until(tmax);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last ticks' DMAs (nobody reads them): not into the next item's ring
+#ifdef DNE_PHASE_CLOCK
+        if (tk_on && lane == 0) {
+            long long *pl = g_duo_plan[tk_wg][wv];
+            pl[3] = tk_i; pl[5] = (long long)__builtin_amdgcn_s_memtime(); pl[7] = (long long)wall_clock64();
+        }
+        tk_on = false;
+#endif
     }
 }
 
@@ -2518,7 +2845,8 @@ __global__ __launch_bounds__(256) void k_fc_cols(FwdArgs A, const int *__restric
 // columns) through k_fc_duo's rolling window -- W rows per stream always in flight, each row's registers refilled the moment it is
 // consumed, no LDS, no barrier -- and stores the chain's 256 sums to y3s[member][32][256]; the head (FwdArgs::sub_sums) folds them in
 // the oracle's order.  250 members = 8000 waves: the whole machine streams.  The block behind a chain's last one is fetched and never
-// used: it lies inside the member's own parameter slice (the next sub-slice, or fc bias / bn3 / output layer behind the fc matrix).
+// used: the next sub-slice, or what follows the fc matrix (fc bias / bn3 / output layer, and for small action counts the floats behind the
+// member's slice: the bases and noise allocations carry a block of padding for that, engine.hip OVERFETCH_FLOATS).
 template <int NV, bool HAS_BN, bool NOISE>
 __global__ __launch_bounds__(256) void k_fc_sub(FwdArgs A, const int *__restrict__ list, int n_groups, int spw /* sub-slices per wave: 1, 2, 4, 8 */,
                                                 int prio, const float *__restrict__ y2, float *__restrict__ y3s /*[member][32][256]*/) {

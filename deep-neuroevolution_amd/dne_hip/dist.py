@@ -259,15 +259,16 @@ class RelayClient:
             p.subscribe(**{TASK_CHANNEL: lambda msg: handler(msg['data'])})
             p.run_in_thread(sleep_time=0.001)
         self._declare_task_local(*retry_get(self.master_redis, (TASK_ID_KEY, TASK_DATA_KEY)))
+        # forward worker results to the master in batches (dist.py:127-133): block for the first result, then keep draining for
+        # one millisecond past it, so that a burst of workers finishing together costs the master one RPUSH instead of many
         batches = 0
         while max_batches is None or batches < max_batches:
-            results = []
-            start_time = curr_time = time.time()
-            while curr_time - start_time < 0.001:
-                results.append(self.local_redis.blpop(RESULTS_KEY)[1])
-                curr_time = time.time()
-            self.results_published += len(results)
-            self.master_redis.rpush(RESULTS_KEY, *results)
+            batch = [self.local_redis.blpop(RESULTS_KEY)[1]]
+            deadline = time.time() + 0.001
+            while time.time() < deadline:
+                batch.append(self.local_redis.blpop(RESULTS_KEY)[1])
+            self.master_redis.rpush(RESULTS_KEY, *batch)
+            self.results_published += len(batch)
             batches += 1
 
     def flush_results(self):

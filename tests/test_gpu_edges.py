@@ -162,6 +162,9 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
     {"DNE_FC_SUB": "2", "DNE_FC_SUB_MIN": "2", "DNE_FC_SUB_SPW": "8"},   # ... a whole quarter per wave
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_FAT": "1"},   # ... the form that the hardware places once per CU (register footprint past 256), two units per wave
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_FAT": "1", "DNE_NSUB": "2"},   # ... one unit per wave, two windows
+    {"DNE_FC_RING": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0"},   # k_fc_ring (round 5): the workgroup's noise rows through an LDS ring (LDS-DMA), base rows from the column-permuted copy; two units per wave
+    {"DNE_FC_RING": "2", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1"},   # ... one unit per wave
+    {"DNE_FC_RING": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_NSUB": "2", "DNE_DUO_FAT": "0"},   # ... two windows, two workgroups per CU
     {"DNE_BURST": "5", "DNE_BURST_TAIL": "40"},                         # compaction of the active list every 5 / 40 lock-steps instead of 16
     {"DNE_FC_DUO": "0", "DNE_FC2_MIN": "2", "DNE_FC_TAIL_MAX": "1"},    # the duo path switched off: k_fc2
     {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1"},                      # k_fc<2> streaming kernel
@@ -328,6 +331,34 @@ def test_reference_batch_sizes(nref, members, oracle, small_noise):
         for i in (0, members - 1, members // 2):
             obn, omom = oracle.es_ref_pass_moments(L, th + np.float32(scale[i]) * small_noise[off[i]:off[i] + L.P], ref)
             assert np.array_equal(bn[i], obn) and np.array_equal(mom[i], omom), (nref, i)
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("knobs", [{"DNE_REF_OVERLAP": "1", "DNE_NSUB": "3"}, {"DNE_REF_OVERLAP": "1", "DNE_NSUB": "2", "DNE_REF_PRIO": "0"},
+                                   {"DNE_REF_OVERLAP": "1", "DNE_NSUB": "4", "DNE_FC_RING": "2", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1"}])
+def test_reference_pass_under_the_first_lock_steps(knobs, oracle, small_noise, monkeypatch):
+    """DNE_REF_OVERLAP: the reference pass runs chunk by chunk on its own streams and a window starts stepping as soon as the
+    chunks of its own members are through (policies.py:399: the pass still precedes that member's first step) -- 7 chunks of 4
+    members under 2 .. 4 windows, every return / length against the oracle"""
+    from dne_hip import _lib
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    e = _lib.Engine(_lib.KIND_ES, NACT, max_members=26, ref_count=NREF, ref_chunk=4)
+    try:
+        e.noise_upload(small_noise)
+        ref = oracle.get_ref_batch(seed=0, batch_size=NREF, nact=NACT)
+        e.set_ref_batch(ref)
+        L = oracle.layout(0, NACT)
+        th = oracle.es_init_theta(L, 0)
+        e.set_theta(th)
+        idx = np.array([11, 222_222, 2_900_001, 1_234_567, 42, 77_777, 2_000_000, 3, 1_500_123, 900_000, 2_950_000, 512, 300_300], np.int64)
+        seeds = (np.arange(26, dtype=np.uint32) * 2654435761).astype(np.uint32)
+        for _ in range(2):   # twice: the second evaluation re-uses the chunk events
+            ret, sg, ln = e.es_eval(idx, 0.02, 40, seeds)
+            oret, osg, oln = oracle.es_eval(L, th, small_noise, idx, 0.02, 40, ref, seeds)
+            assert np.array_equal(ln, oln) and np.array_equal(ret, oret) and np.array_equal(sg, osg), knobs
+        assert e.check_redzones() == 0
     finally:
         e.close()
 

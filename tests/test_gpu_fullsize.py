@@ -178,6 +178,68 @@ def test_full_generation_bit_exact(full, oracle, oracle_es_gen0):
     assert np.array_equal(theta_gpu, oth)
 
 
+@pytest.mark.slow
+@pytest.mark.timeout(2400)
+def test_generations_past_zero_bit_exact(full, oracle, oracle_es_gen0):
+    """Parity past generation 0 (es.py:193-353 runs generation after generation on an evolving theta and a carried Adam state,
+    optimizers.py:36-50).  Generations 0, 1, 2 of config 2 through es.es_generation -- the bench's path: device-resident exchange +
+    update -- with the CPU oracle over every host core per generation: all 2500 x 2 returns / sign-returns / lengths of every
+    generation, theta after every update, Adam's m, v, t after generation 2.  Then the GPU alone runs on to the end of the bench's
+    warm-up (generations 3, 4) and generation 5 -- the first one bench.py times -- is checked again, the oracle starting from the
+    engine's theta and optimizer state at that point: the episode-length mix, the 451 .. 799-pair k_fc_duo launches and the 32-step
+    compaction of the timed region, value by value."""
+    import hashlib
+    import oracle_pool
+    from dne_hip import es
+    e, noise, th, ref = full
+    cfg = es.Config(**BENCH_CONFIG)
+    e.set_theta(th); e.optimizer_reset()
+    try:
+        opt = oracle.Adam(th, BENCH_OPT["args"]["stepsize"])
+        oth = th
+
+        def check(gen, oret, osg, oln):
+            nonlocal oth
+            _, idx, _ = es.generation_inputs(noise.noise.size, e.P, N_PAIRS, gen, 0, 1)
+            rec, ratio = es.es_generation(e, noise.noise.size, cfg, N_PAIRS, gen, 5000, BENCH_OPT)
+            assert np.array_equal(rec["noise_idx"], idx)
+            assert np.array_equal(rec["len"], oln), (gen, np.flatnonzero((rec["len"] != oln).any(axis=1))[:8])
+            assert np.array_equal(rec["ret"], oret) and np.array_equal(rec["aux"], osg), gen
+            g = oracle.es_gradient(noise.noise, idx, oret, e.P)
+            oratio, t2 = opt.update(g, cfg.l2coeff)
+            oth = t2.copy()
+            assert np.array_equal(e.get_theta(), oth), gen
+            assert np.isfinite(ratio) and abs(ratio - oratio) <= 1e-4 * abs(oratio)
+            return int(rec["len"].sum())
+
+        o = oracle_es_gen0
+        assert np.array_equal(o["ref"], ref)
+        steps = [check(0, o["ret"], o["sg"], o["ln"])]
+        for gen in (1, 2):
+            _, idx, seeds = es.generation_inputs(noise.noise.size, e.P, N_PAIRS, gen, 0, 1)
+            oret, osg, oln, _ = oracle_pool.es_generation(noise.noise, oth, ref, idx, seeds, cfg.noise_stdev, 5000, NACT)
+            steps.append(check(gen, oret, osg, oln))
+        m, v, t = e.optimizer_get_state()
+        assert t == 3 == opt.t and np.array_equal(m, opt.m) and np.array_equal(v, opt.v)
+        # the rest of bench.py's warm-up on the GPU alone, then its first timed generation against the oracle
+        for gen in (3, 4):
+            es.es_generation(e, noise.noise.size, cfg, N_PAIRS, gen, 5000, BENCH_OPT)
+        oth = e.get_theta()
+        m, v, t = e.optimizer_get_state()
+        assert t == 5
+        opt = oracle.Adam(oth, BENCH_OPT["args"]["stepsize"]); opt.m[:] = m; opt.v[:] = v; opt.t = t
+        print("theta after 5 warm-up generations sha256", hashlib.sha256(oth.tobytes()).hexdigest())
+        _, idx, seeds = es.generation_inputs(noise.noise.size, e.P, N_PAIRS, 5, 0, 1)
+        oret, osg, oln, _ = oracle_pool.es_generation(noise.noise, oth, ref, idx, seeds, cfg.noise_stdev, 5000, NACT)
+        steps.append(check(5, oret, osg, oln))
+        m, v, t = e.optimizer_get_state()
+        assert t == 6 and np.array_equal(m, opt.m) and np.array_equal(v, opt.v)
+        print("env-steps per generation (0, 1, 2, 5):", steps)
+        assert e.check_redzones() == 0
+    finally:
+        e.set_theta(th); e.optimizer_reset()
+
+
 def test_ga_full_size_properties(oracle, noise_table):
     """Config 3 at full size: 1000 children, top-20 truncation, 250M table (ga.py:136-149, 251-271).  Generation 0 (every
     child its own normc genome) and a generation of children of 20 cached parents: idempotent, independent of the slot a

@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--archive", type=int, default=32); ap.add_argument("--pop", type=int, default=5000); ap.add_argument("--iterations", type=int, default=2)
 a = ap.parse_args()
 r = W.nses(es.SharedNoiseTable(), iterations=a.iterations, pop=a.pop, archive_extra=max(a.archive - 3, 0))
+r.pop("_cpu_inputs", None)   # numpy arrays for bench.py's cpu_baseline leg, not part of the report
 for it in r.pop("iterations"):
     print(json.dumps(it))
 print(json.dumps(r))
