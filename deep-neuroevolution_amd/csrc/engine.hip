@@ -592,6 +592,7 @@ struct dne_handle {
     float *spec_y1 = nullptr;
     int spec_bands = 7;              // DNE_SPEC_BANDS: 256-thread workgroups per candidate frame
     int spec_conv1 = 1;              // DNE_SPEC_CONV1: conv1 of every candidate stack in the launch that picks the action
+    bool ring_now = false;           // this burst's table-ordered windows run k_fc_ring (their convolutions leave activated y2)
     bool uniform_base = false;       // every member perturbs base slot 0 (set by dne_es_eval, cleared by dne_set_members)
     int render_bands = 8, band_threads = 512;   // tail: workgroups per frame (DNE_RENDER_BANDS, 1 = render inside k_tail_step) and their size
     int render_wg_max = 512;         // ... halved until members x bands fits this many workgroups (DNE_RENDER_WG_MAX)
@@ -1065,7 +1066,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_RB", 2, 8, &h->fc_rb);
     if (cfg->policy_kind == DNE_KIND_ES) h->ga_materialize = 0;   // ES members are antithetic pairs over one theta: nothing to write out
     if (h->large) { CH(h->alloc(&h->y1, M * 14112, "y1")); CH(h->alloc(&h->y2, M * 7744, "y2")); CH(h->alloc(&h->y3, M * 7744, "y3")); CH(h->alloc(&h->y3t, M * 512, "y3t")); }
-    else { CH(h->alloc(&h->y1, M * 7056, "y1")); CH(h->alloc(&h->y2, M * 3872, "y2")); CH(h->alloc(&h->y3, M * 256, "y3")); CH(h->alloc(&h->y3t, M * 4 * 256, "y3t")); }
+    else { CH(h->alloc(&h->y1, M * 7056, "y1")); CH(h->alloc(&h->y2, M * 3872 + 64, "y2"));   /* (+ 64: k_fc_ring fetches the eight activations behind a slice's end and never uses them) */ CH(h->alloc(&h->y3, M * 256, "y3")); CH(h->alloc(&h->y3t, M * 4 * 256, "y3t")); }
     CH(h->alloc(&h->unit_order, M * 4, "unit_order"));
     if (!h->large && h->fc_sub) CH(h->alloc(&h->y3s, M * 32 * 256, "y3s"));
     if (!h->large && h->ring_on && cfg->policy_kind == DNE_KIND_ES) CH(h->alloc(&h->theta_perm, (size_t)(3872 + 16) * 256, "theta_perm"));
@@ -1555,7 +1556,8 @@ extern "C" int dne_get_bn_moments(dne_handle *h, int n, float *out) {
 }
 
 // one policy decision for the groups in `list` (count groups of gsize members)
-static void launch_forward(dne_handle *h, const int *list, int count, int gsize, bool use_done, hipStream_t st = nullptr) {
+static void launch_forward(dne_handle *h, const int *list, int count, int gsize, bool use_done, hipStream_t st = nullptr,
+                           bool act2 = false /* leave relu(bn2(y2)) instead of y2: the window's fc is k_fc_ring */) {
     if (!st) st = h->stream;
     const FwdArgs A = h->fwd(use_done);
     if (h->large) {   // LargeModel: three matrix-core convolutions (forward_large.h); members are single (GA)
@@ -1577,14 +1579,15 @@ static void launch_forward(dne_handle *h, const int *list, int count, int gsize,
     const int s1 = items <= h->conv_split_max ? 7 : items <= h->conv_split_mid ? 4 : 1, s2 = items <= h->conv_split_max ? 4 : items <= 2 * h->conv_split_mid ? 2 : 1;
     if (h->conv_fused && items >= h->conv_fused_min && !h->dbg_skip) {   // one workgroup per member through both convolutions, y1 stays in LDS
         float *y1 = use_done ? nullptr : h->y1;                           // dne_act / debug_activations want y1; evaluations do not
-        if (es) hipLaunchKernelGGL((k_conv12<true>), dim3(items), dim3(256), sizeof(Conv12Lds), st, A, list, gsize, (const uint8_t *)h->stacks, y1, h->y2);
-        else hipLaunchKernelGGL((k_conv12<false>), dim3(items), dim3(256), sizeof(Conv12Lds), st, A, list, gsize, (const uint8_t *)h->stacks, y1, h->y2);
+        if (es) hipLaunchKernelGGL((k_conv12<true>), dim3(items), dim3(256), sizeof(Conv12Lds), st, A, list, gsize, (const uint8_t *)h->stacks, y1, h->y2, act2 ? 1 : 0);
+        else hipLaunchKernelGGL((k_conv12<false>), dim3(items), dim3(256), sizeof(Conv12Lds), st, A, list, gsize, (const uint8_t *)h->stacks, y1, h->y2, 0);
         return;
     }
     if (items <= h->conv12t_max && !h->dbg_skip) {   // the tail: four workgroups per member through both convolutions, no y1 round trip
         float *y1 = use_done ? nullptr : h->y1;
         if (es) hipLaunchKernelGGL((k_conv12t<true>), dim3(items * 4), dim3(512), sizeof(Conv12Lds), st, A, list, gsize, (const uint8_t *)h->stacks, y1, h->y2);
         else hipLaunchKernelGGL((k_conv12t<false>), dim3(items * 4), dim3(512), sizeof(Conv12Lds), st, A, list, gsize, (const uint8_t *)h->stacks, y1, h->y2);
+        if (act2) hipLaunchKernelGGL(k_y2_activate, dim3(items), dim3(256), 0, st, A, list, gsize, h->y2);
         return;
     }
     if (!(h->dbg_skip & 1))
@@ -1593,6 +1596,7 @@ static void launch_forward(dne_handle *h, const int *list, int count, int gsize,
     if (h->dbg_skip & 2) return;
     if (es) hipLaunchKernelGGL((k_conv2<true>), dim3(items * s2), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2, s2, (float *)nullptr);
     else hipLaunchKernelGGL((k_conv2<false>), dim3(items * s2), dim3(256), 0, st, A, list, gsize, 1, 0, (const float *)h->y1, h->y2, s2, (float *)nullptr);
+    if (act2) hipLaunchKernelGGL(k_y2_activate, dim3(items), dim3(256), 0, st, A, list, gsize, h->y2);
 }
 
 static void launch_fc(dne_handle *h, const int *list, int count, int gsize, float *logits, hipStream_t st = nullptr,
@@ -1655,11 +1659,10 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         const int duo_grid = h->duo_grid ? h->duo_grid : (w4 ? 2 * h->fc_grid : h->fc_grid);
         const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 4 * rounds - 1) / (4 * rounds), blocks = std::min(items, duo_grid);
         const size_t out_lds = (size_t)h->out_lds_kb * 1024;   // an LDS reservation nobody uses: it only bounds k_out's workgroups per CU next to the streaming fc
-        const bool ring = es && gsize == 2 && sweep && h->theta_perm && h->uniform_base && (h->ring_on > 1 || !solo);
-        if (ring) {   // one unit per wave, eight units per workgroup whatever the regime
+        if (h->ring_now) {   // one unit per wave, eight units per workgroup whatever the regime
             const int ring_blocks = std::min((n_units + 7) / 8, duo_grid);
-            if (h->duo_fat) hipLaunchKernelGGL((k_fc_ring<true, 8>), dim3(ring_blocks), dim3(512), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, (const float *)h->theta_perm, h->fc_prio << 9);
-            else hipLaunchKernelGGL((k_fc_ring<false, 8>), dim3(ring_blocks), dim3(512), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, (const float *)h->theta_perm, h->fc_prio << 9);
+            if (h->duo_fat) hipLaunchKernelGGL((k_fc_ring<true, 8>), dim3(ring_blocks), dim3(576), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, (const float *)h->theta_perm, h->fc_prio << 9);
+            else hipLaunchKernelGGL((k_fc_ring<false, 8>), dim3(ring_blocks), dim3(576), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, (const float *)h->theta_perm, h->fc_prio << 9);
         }
         else if (w4) hipLaunchKernelGGL((k_fc_duo<2, true, true, 4>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
         else if (es && sweep && h->duo_fat) hipLaunchKernelGGL((k_fc_duo<2, true, true, 8, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
@@ -1738,7 +1741,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     h->tt_on = false;
     // per-evaluation launch state (tail table in the kernel arguments, the regime flags) never outlives this call, whichever
     // return is taken: a later dne_act / dne_debug_activations must not decode members from a stale table
-    struct ClearOnExit { dne_handle *h; ~ClearOnExit() { h->tt_on = false; h->sub_now = false; } } clear_on_exit{h};
+    struct ClearOnExit { dne_handle *h; ~ClearOnExit() { h->tt_on = false; h->sub_now = false; h->ring_now = false; } } clear_on_exit{h};
     if (n % gsize) return h->fail("member count %d not a multiple of the group size %d", n, gsize);
     if (tslimit <= 0) return h->fail("timestep limit must be positive");
     if (bc_out && !h->bc) return h->fail("behaviour characterisations requested but the engine was created with record_bc = 0");
@@ -1826,6 +1829,10 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     // the profiled ("full") launches are one kernel: k_fc2 when this evaluation starts wide enough to use it, else k_fc
     const bool fc2_eval = h->fc_pairs == 2 && gsize == 2 && h->L.kind == DNE_KIND_ES && h->uniform_base && groups >= h->fc2_min_total;
     const bool duo_eval = !h->large && h->fc_duo && (h->L.kind == DNE_KIND_ES ? gsize == 2 : (gsize == 1 && h->fc_duo_ga)) && groups >= h->fc_duo_min;
+    // an evaluation that starts wide enough for k_fc_ring: its bracketed ("full") launches are that kernel's only -- one kernel per
+    // roofline line; the k_fc_duo launches of its thinner lock-steps (DNE_FC_DUO_MIN .. DNE_DUO_SOLO_BELOW pairs) are not bracketed
+    const bool ring_eval = duo_eval && h->L.kind == DNE_KIND_ES && gsize == 2 && h->theta_perm && h->uniform_base && h->duo_sweep &&
+                           (h->ring_on > 1 || groups >= h->duo_solo_below) && (groups >= h->duo_solo_below || h->duo_sweep > 1);
     while (total > 0 && t < tslimit) {
         const int burst = std::min(total <= h->fc_tail_max ? h->burst_tail : h->burst, tslimit - t);   // lock-steps until the next compaction
         const int nsub = pick_nsub(total);
@@ -1835,6 +1842,8 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
         h->duo_solo_now = total < h->duo_solo_below;
         h->sub_now = sub_regime(total);
         if (h->sub_now) h->duo_now = h->fc2_now = false;
+        h->ring_now = h->duo_now && h->L.kind == DNE_KIND_ES && gsize == 2 && h->theta_perm && h->uniform_base &&
+                      h->duo_sweep && (!h->duo_solo_now || h->duo_sweep > 1) && (h->ring_on > 1 || !h->duo_solo_now);
         if (h->duo_now)   // the list only changes at a compaction: rank each window's units by table address once per burst
             for (int s = 0; s < nsub; s++) {
                 const int lo = (int)((long long)total * s / nsub), cnt = (int)((long long)total * (s + 1) / nsub) - lo;
@@ -1859,7 +1868,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 // events only around full-width launches: in the latency-bound tail every event packet is a bubble
                 // (with k_fc2 enabled the profiled launches are exactly the k_fc2 ones: the roofline kernel of bench.py)
                 const bool duo_win = h->duo_now && cnt > h->fc_tail_max;
-                const bool pe = prof && (duo_eval ? duo_win : fc2_eval ? h->fc2_now : cnt > h->fc_tail_max);
+                const bool pe = prof && (ring_eval ? duo_win && h->ring_now : duo_eval ? duo_win : fc2_eval ? h->fc2_now : cnt > h->fc_tail_max);
                 if (pe) { e[0] = ne++; HCHECK(h, hipEventRecord(h->event(e[0]), sst)); }
                 // fused policy head + emulator (+ render): while all windows together still fit the chip one workgroup per member
                 const bool tail = !h->large && !h->sub_now && cnt <= h->fc_tail_max && total <= h->tail_fused_max;   // (the fused tail kernels are the small networks')
@@ -1898,7 +1907,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                     launch_sets++;
                     continue;
                 }
-                launch_forward(h, lst, cnt, gsize, true, sst);
+                launch_forward(h, lst, cnt, gsize, true, sst, h->ring_now && duo_win);
                 // optional: serialise the fc kernels of the windows (anti-phase); off by default, free-running measured faster
                 const bool chain = nsub > 1 && cnt >= h->fc_chain_min;
                 if (chain && last_fc) HCHECK(h, hipStreamWaitEvent(sst, last_fc, 0));
@@ -1975,7 +1984,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     P.env_steps = 0;
     for (int i = 0; i < n; i++) P.env_steps += lengths[i];
     P.fc_full_ms = P.fc_full_launches = P.fc_full_units = 0;
-    P.fc_full_kind = duo_eval ? 3 : fc2_eval ? 2 : sub_regime(groups) ? 4 : 1;   // (an evaluation that STARTS in the sub-slice fc's range: its bracketed launches are k_fc_sub's)
+    P.fc_full_kind = ring_eval ? 5 : duo_eval ? 3 : fc2_eval ? 2 : sub_regime(groups) ? 4 : 1;   // (an evaluation that STARTS in the sub-slice fc's range: its bracketed launches are k_fc_sub's)
     P.fc_full_union_ms = 0;
     if (prof) {
         HCHECK(h, hipEventElapsedTime(&ms, h->ev_pool[0], h->ev_pool[1]));

@@ -764,7 +764,7 @@ struct Conv12Lds {
 template <bool HAS_BN>
 __global__ __launch_bounds__(256, 2) void k_conv12(FwdArgs A, const int *__restrict__ list, int gsize,
                                                 const uint8_t *__restrict__ stacks, float *__restrict__ y1 /*may be null*/,
-                                                float *__restrict__ y2) {
+                                                float *__restrict__ y2, int act2 /* write relu(bn2(y2)) instead of y2: k_fc_ring's input */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char conv12_raw[];
     Conv12Lds &S = *reinterpret_cast<Conv12Lds *>(conv12_raw);
     const Item it = decode_item(A, blockIdx.x, list, gsize, 1, 0, stacks, nullptr, A.done);
@@ -897,12 +897,21 @@ __global__ __launch_bounds__(256, 2) void k_conv12(FwdArgs A, const int *__restr
         }
     }
     float *o = y2 + (size_t)it.row * 3872;
+    // k_fc_ring takes its activations as scalars and wants them finished: relu(fl(fl(y * scale) + shift)), the consumer's own operations
+    const bool act = HAS_BN && act2 != 0;
+    const float s2 = act ? bn[32 + nt * 16 + lp] : 1.0f, h2 = act ? bn[64 + nt * 16 + lp] : 0.0f;
 #pragma unroll
     for (int m = 0; m < 4; m++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int pos = (mt0 + m) * 16 + lk * 4 + r;
-            if (pos < 121) o[pos * 32 + nt * 16 + lp] = acc[m][r] + bias2;
+            float y = acc[m][r] + bias2;
+            if (act) {
+                y = y * s2;
+                y = y + h2;
+                y = y > 0.0f ? y : 0.0f;
+            }
+            if (pos < 121) o[pos * 32 + nt * 16 + lp] = y;
         }
 }
 
@@ -1374,6 +1383,7 @@ __global__ __launch_bounds__(256) void k_unit_order(const int64_t *__restrict__ 
 
 // One side (unit) of a duo: its streams, its activations, its accumulators.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
 template <int NV>
 struct DuoSide {
     const float *enext, *tnext;   // wave-uniform: the unit's next row block in the noise table / in the base vector
@@ -1825,18 +1835,39 @@ __global__ __launch_bounds__(256, FAT ? 1 : W == 8 ? 2 : 4) void k_fc_duo(FwdArg
 // alignment (two ds_read2st64_b32 per row) -- and the base rows come from a copy of the fc matrix whose rows are stored in that
 // order (k_theta_perm, once per evaluation), so that they stay one 16-byte load per lane and row.  Which lane holds which column
 // is not arithmetic: every output's chain still runs over k in order from zero (oracle fc_raw) -- same bits.
-constexpr int RING_SLOTS = 6, RING_SEG = 2048, RING_PD = 4;   // slots (+ one mirror of slot 0 behind the last), floats per segment, prefetch distance in ticks
+constexpr int RING_SLOTS = 7, RING_SEG = 2048, RING_PD = 5;   // slots (+ one mirror of slot 0 behind the last), floats per segment, prefetch distance in ticks
 
 __global__ __launch_bounds__(256) void k_theta_perm(const float *__restrict__ fcw /*[rows][256]*/, float *__restrict__ out /*[rows + 16][256]*/, int rows) {
     const int r = blockIdx.x, t = threadIdx.x;   // out[r][4 l + j] = in[r][l + 64 j]; the rows behind the matrix (over-fetched, never used) are zero
     out[(size_t)r * 256 + t] = r < rows ? fcw[(size_t)r * 256 + (t >> 2) + 64 * (t & 3)] : 0.0f;
 }
 
+// the same finishing touch for windows whose convolutions ran as other kernels (k_conv1 + k_conv2): y2 <- relu(bn2(y2)) in place
+__global__ __launch_bounds__(256) void k_y2_activate(FwdArgs A, const int *__restrict__ list, int gsize, float *__restrict__ y2) {
+    const int g = list ? list[blockIdx.x / gsize] : blockIdx.x / gsize, member = g * gsize + blockIdx.x % gsize;
+    if (A.done && A.done[member]) return;
+    const float *bn = A.bn + (size_t)member * 608;
+    float *y = y2 + (size_t)member * 3872;
+    for (int i = threadIdx.x; i < 3872; i += 256) {
+        float t = y[i] * bn[32 + (i & 31)];
+        t = t + bn[64 + (i & 31)];
+        y[i] = t > 0.0f ? t : 0.0f;
+    }
+}
+
 // 16 bytes per lane from global memory straight into LDS at lds_dst + lane * 16 (wave-uniform destination); counted by vmcnt like any
 // other vector load, visible to other waves' ds_reads after the issuing wave's counted wait and a barrier
+// Cache policy of the ring's DMAs.  A noise row passes an XCD's L2 once per workgroup (its re-use is in LDS now) while the 3.96 MB of
+// base rows every unit re-reads barely fit the 4 MB L2, so streaming the noise (-DDNE_RING_EPS_MOD='" nt"') looked right -- and does
+// what it should: L2 hit rate 68 -> 79 %, fabric reads 3.9 -> 2.6 GB per 2500-pair launch (profiles/r05_ring_nt_ab.json) -- but the
+// launch takes 0.882 instead of 0.873 ms and a generation 227.4 instead of 223.9 ms same-box: the kernel does not wait for L2 misses.
+// The plain form stays.
+#ifndef DNE_RING_EPS_MOD
+#define DNE_RING_EPS_MOD ""
+#endif
 __device__ __forceinline__ void glds16(const float *sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" DNE_RING_EPS_MOD "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 // row I of a unit's current block: floats vaddr/4 + 256 I + {0, 64, 128, 192} of the ring (the lane's four columns); lands asynchronously
@@ -1850,21 +1881,41 @@ __device__ __forceinline__ void ring_row(f32x2 &lo, f32x2 &hi, unsigned vaddr) {
 // VALU latency (one wave per SIMD issued a packed op every ~8 cycles: the first form of this kernel, two units per wave on four
 // waves, spent 0.93 us of wave time per 16 row-sides), and a wave's only loop with loads in flight is entered behind a full drain
 // and left into one -- no phase change carries registers that a load is still writing (the compiler places copies there).
+// row I's activations (x0, x1): every lane reads the same eight bytes (a broadcast, conflict-free); lands asynchronously
+template <int I>
+__device__ __forceinline__ void ring_x(f32x2 &x, unsigned vaddr) {   // (member 0's plane, member 1's 64 floats behind it)
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(x) : "v"(vaddr), "n"(I), "n"(64 + I));
+}
+
+// Round 5, third form: a LOADER wave.  Every version with the compute waves issuing their share of the DMAs ticked at >= 0.57 us
+// even with one unit streaming: vmcnt retires in order, so a DMA sits in the same queue as the base-row loads and the first counted
+// wait of the tick after next forces it out -- one tick after its issue, i.e. a tick can never be shorter than the HBM round trip of
+// the segment being fetched.  Wave NW (the ninth) now issues ALL of a tick's DMAs and waits for them with a budget of two full ticks;
+// the compute waves' counters see base rows and activations only.
+// At most four waves per SIMD (amdgpu_waves_per_eu: the register allocation is rounded up to 104 per lane): the workgroup's nine take
+// 2 / 2 / 2 / 3, a second workgroup of this kernel finds no SIMD for its third wave -- one per CU, k_fc_duo's FAT -- and a
+// 199-register k_conv12 wave still fits beside the three.  (A plain launch bound of (576, 1) makes the compiler pad to 129 registers,
+// three waves per SIMD: then nothing fits beside them.  An accumulation register named in an asm, k_fc_duo's way, splits the compiler's
+// budget 84 / 84 and it spills to AGPRs -- copying registers that loads are still writing.)
 template <bool FAT, int NW>
-__global__ __launch_bounds__(NW * 64, 1) void k_fc_ring(FwdArgs A, const int *__restrict__ order, int n_units, const float *__restrict__ y2,
+__global__ __launch_bounds__((NW + 1) * 64) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_fc_ring(FwdArgs A, const int *__restrict__ order, int n_units, const float *__restrict__ y2,
                                                      float *__restrict__ y3t, const float *__restrict__ theta_perm, int flags) {
     constexpr int NV = 2, W = 8, NBLK = 968 / W, BPC = 64 / W, R = RING_SLOTS, PD = RING_PD;
-    constexpr int QF = RING_SEG / NW;       // floats of a segment each wave requests per tick
-    constexpr int ND = QF / 256;            // = LDS-DMA instructions per wave and tick (1 KB each)
-    static_assert(RING_SEG == W * 256 && QF % 256 == 0, "one segment = one tick of the timeline, whole 1 KB pieces per wave");
-    // at most one workgroup per CU by register footprint: > 128 registers per lane with two of its waves per SIMD leaves
-    // room for a 199-register k_conv12 wave beside them and none for a second workgroup of this kernel
-    if constexpr (FAT) asm volatile("v_accvgpr_write_b32 a63, %0" : : "v"(0) : "a63");
-    __shared__ __attribute__((aligned(16))) float ring[(R + 1) * RING_SEG];
-    __shared__ long long sw_key[2][NW];     // the waves' units' table addresses (or -1), double-buffered by item parity
+    constexpr int ND = RING_SEG / 256;      // LDS-DMA instructions per segment (1 KB each), all issued by the loader wave
+    static_assert(RING_SEG == W * 256, "one segment = one tick of the timeline");
+    // ONE shared object, the ring first (LDS-DMA destinations are 16-bit offsets: the eight 8 KB slots end at 64 KB)
+    struct Lds {
+        float ring[(R + 1) * RING_SEG];
+        float xbuf[NW][2][2][64];        // per wave: two chunks of 64 rows of activations, one plane per member of the pair
+        long long key[2][NW];            // the waves' units' table addresses (or -1), double-buffered by item parity
+    };
+    __shared__ __attribute__((aligned(16))) Lds S;
+    float (&ring)[(R + 1) * RING_SEG] = S.ring;
+    long long (&sw_key)[2][NW] = S.key;
     const int tid = threadIdx.x, wv = uni(tid >> 6), lane = tid & 63;
+    const bool loader = wv == NW;
     const unsigned voff = lane * 16, vlane4 = lane * 4;
-    const unsigned lds_ring = (unsigned)(size_t)ring;
+    const unsigned lds_ring = (unsigned)(size_t)ring, lds_x = (unsigned)(size_t)&S.xbuf[loader ? 0 : wv][0][0][0];
     const Layout &L = A.L;
     {
         const int prio = (flags >> 9) & 3;
@@ -1880,7 +1931,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_fc_ring(FwdArgs A, const int *__
     const int tk_wg = blockIdx.x / 4;
 #endif
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-        int uu = item * NW + wv < n_units ? uni(order[item * NW + wv]) : -1;
+        int uu = !loader && item * NW + wv < n_units ? uni(order[item * NW + wv]) : -1;
         if (uu >= 0 && A.done) {   // units of finished pairs are dropped
             int all_done = 1;
 #pragma unroll
@@ -1890,7 +1941,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_fc_ring(FwdArgs A, const int *__
         const bool ok = uu >= 0;
         // absolute float index of the unit's first weight in the noise table
         const long long key = ok ? uni64(A.m_off[(size_t)(uu >> 2) * NV]) + (long long)L.fcw + (long long)(uu & 3) * SLICE_FLOATS : -1;
-        if (lane == 0) sw_key[par][wv] = key;
+        if (lane == 0 && !loader) sw_key[par][wv] = key;
         __syncthreads();
         long long K0 = 0x7fffffffffffffffll, kmax = -1;
 #pragma unroll
@@ -1903,27 +1954,26 @@ __global__ __launch_bounds__(NW * 64, 1) void k_fc_ring(FwdArgs A, const int *__
         if (kmax < 0) continue;                       // every unit of this item belongs to a finished pair (the same answer in every wave)
         K0 &= ~3ll;                                   // 16-byte-aligned DMA sources
         const int tmax = (int)((kmax - K0) >> 11) + NBLK;
-        const float *seg0 = A.noise + K0 + wv * QF;   // this wave's share of segment 0
+        const float *seg0 = A.noise + K0;             // segment 0
         int tau = 0, slot = 0;                        // the workgroup's time in ticks (= segments) and the ring slot of segment tau
-        // this wave's share of segment j (clamped to the last segment anybody reads: the number of DMAs per tick must not change, the
-        // counted waits below rely on it) into slot sj
+        // segment j (clamped to the last one anybody reads) into slot sj: the loader wave's eight 1 KB pieces
         auto dma_seg = [&](int j, int sj) {
             const float *src = seg0 + (size_t)min(j, tmax) * RING_SEG;
-            const unsigned dst = lds_ring + (unsigned)(sj * RING_SEG + wv * QF) * 4u;
+            const unsigned dst = lds_ring + (unsigned)(sj * RING_SEG) * 4u;
 #pragma unroll
             for (int d = 0; d < ND; d++) glds16(src + 256 * d, voff, dst + 1024 * d);
         };
-        // a block that starts in the last slot runs on into the mirror of slot 0 behind it
-        auto mirror_due = [&]() { int sj = slot + PD; if (sj >= R) sj -= R; return sj == 0; };
+        if (loader) {
 #pragma unroll
-        for (int j = 0; j < PD; j++) dma_seg(j, j);
-        dma_seg(0, R);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int j = 0; j < PD; j++) dma_seg(j, j);
+            dma_seg(0, R);   // a block that starts in the last slot runs on into the mirror of slot 0 behind it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         const int q = ok ? (int)((key - K0) >> 11) : 0;               // the unit's first row sits dlt floats into segment q
         const int dlt = ok ? (int)(key - K0) - q * RING_SEG : 0;
 #ifdef DNE_PHASE_CLOCK
-        tk_on = blockIdx.x % 4 == 0 && tk_wg < DUO_TICK_WGS && item == (int)(blockIdx.x + gridDim.x);
+        tk_on = !loader && blockIdx.x % 4 == 0 && tk_wg < DUO_TICK_WGS && item == (int)(blockIdx.x + gridDim.x);
         tk_i = 0;
         if (tk_on && lane == 0) {
             long long *pl = g_duo_plan[tk_wg][wv];
@@ -1931,19 +1981,25 @@ __global__ __launch_bounds__(NW * 64, 1) void k_fc_ring(FwdArgs A, const int *__
             pl[4] = (long long)__builtin_amdgcn_s_memtime(); pl[6] = (long long)wall_clock64();
         }
 #endif
-        // the end of a tick: segment tau + PD requested (an active wave has issued a due mirror copy in the middle of the tick), barrier
-        auto tick_end = [&](bool idle) {
-            int sj = slot + PD;
-            if (sj >= R) sj -= R;
-            dma_seg(tau + PD, sj);
-            if (idle && sj == 0) dma_seg(tau + PD, R);
+        // the end of a tick: the barrier.  The loader requests segment tau + PD first (and its mirror copy when it lands in slot 0) and
+        // lets the DMAs of this and the two previous ticks stay in flight: what it requested three ticks ago has landed when it arrives
+        // at the barrier, every wave can read it from the next tick on -- the tick of its first reader (PD = 5).
+        int mir_age = 0;   // ticks since the last mirror copy was requested (the prologue's: everything was waited for)
+        auto tick_end = [&]() {
 #ifdef DNE_PHASE_CLOCK
             long long tk_b = 0;
             if (tk_on) { __builtin_amdgcn_sched_barrier(0); tk_b = (long long)__builtin_amdgcn_s_memtime(); }
 #endif
-            if (idle) {   // nothing else retires an idle wave's DMAs: all but this tick's own (ND, or 2 ND with the mirror)
-                if (sj == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * ND) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ND) : "memory");
+            if (loader) {
+                int sj = slot + PD;
+                if (sj >= R) sj -= R;
+                dma_seg(tau + PD, sj);
+                const bool mir = sj == 0;
+                if (mir) { dma_seg(tau + PD, R); mir_age = 0; } else mir_age++;
+                // this tick's requests and those of the two ticks before stay in flight (a mirror copy among them: one more segment;
+                // R = 7: at most one); what was requested three ticks ago has landed at the barrier
+                if (mir_age < 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * ND) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * ND) : "memory");
             }
             __builtin_amdgcn_s_barrier();
 #ifdef DNE_PHASE_CLOCK
@@ -1957,108 +2013,105 @@ __global__ __launch_bounds__(NW * 64, 1) void k_fc_ring(FwdArgs A, const int *__
             tau++;
             slot = slot + 1 == R ? 0 : slot + 1;
         };
-        auto idle_until = [&](int T) { while (tau < T) tick_end(true); };
+        auto idle_until = [&](int T) { while (tau < T) tick_end(); };
         idle_until(q);
         if (ok) {
             const int g = uu >> 2, sl = uu & 3;
             const float *tnext = theta_perm + (size_t)sl * SLICE_FLOATS;   // (every member of an ES evaluation has base slot 0: the engine checks)
-            const int ch = (8 * sl + lane) & 31;   // bn2 channel of this lane's activation rows (968 = 8 mod 32)
             const int mem0 = g * NV;
             const float scale0 = A.m_scale[mem0];  // an antithetic pair: +sigma, -sigma exactly
-            float s2[NV], h2[NV], xv[NV], xn[NV];
-            const float *xs[NV];
             f32x2 acc[NV][2], fold[NV][2];
 #pragma unroll
-            for (int v = 0; v < NV; v++) {
-                s2[v] = A.bn[(size_t)(mem0 + v) * 608 + 32 + ch];
-                h2[v] = A.bn[(size_t)(mem0 + v) * 608 + 64 + ch];
-                xs[v] = y2 + (size_t)(mem0 + v) * 3872 + 968 * sl;
-                acc[v][0] = acc[v][1] = fold[v][0] = fold[v][1] = f32x2{0.0f, 0.0f};
-                xv[v] = xn[v] = 0.0f;
-            }
-            // activations: chunk c = rows 64 c .. 64 c + 63 of the unit's slice, one row per lane; the raw values of chunk c + 1 are requested
-            // when chunk c starts and turned into relu(bn2(.)) eight ticks later (loads complete in order: long landed)
-            auto request_x = [&](int c) {
-                if (c >= 16) return;
-                unsigned vo = voff;
+            for (int v = 0; v < NV; v++) acc[v][0] = acc[v][1] = fold[v][0] = fold[v][1] = f32x2{0.0f, 0.0f};
+            // activations: relu(bn2(y2)) as the convolution kernel left them (k_conv12's act2 / k_y2_activate).  A chunk of 64 rows (both
+            // members of the pair) is fetched one row per lane eight ticks ahead and parked in the wave's own corner of LDS; every row
+            // then reads its pair (x0, x1) back with ONE broadcast ds_read_b64 -- all lanes the same address -- and v_pk_fma takes either
+            // half for both of its lanes (op_sel): no v_readlane (a sixth of the row loop's vector instructions, its slowest ones), and
+            // unlike scalar loads these reads return in order with the noise rows', so the counted waits below stay exact.
+            const float *xg0 = y2 + (size_t)mem0 * 3872 + 968 * sl, *xg1 = xg0 + 3872;
+            auto request_x = [&](int c) {   // chunk c = rows 64 c .. 64 c + 63 (the last chunk has eight: the other lanes re-read its last row)
+                unsigned vo = vlane4;
                 asm volatile("" : "+v"(vo));
-                const unsigned xoff = c < 15 ? vo >> 2 : min(vo >> 2, 28u);
-#pragma unroll
-                for (int v = 0; v < NV; v++)
-                    asm volatile("global_load_dword %[d], %[vo], %[sb]" : [d] "=v"(xn[v]), "+v"(xv[v]) : [vo] "v"(xoff), [sb] "s"(xs[v] + 64 * c));
+                const unsigned xoff = c < 15 ? vo : min(vo, 28u);
+                const unsigned dst = lds_x + (unsigned)((c & 1) * 512);
+                unsigned keep;   // 4 bytes per lane into the chunk's two planes (no register in between: nothing for the compiler to copy early)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(xoff), "s"(xg0 + 64 * c), "s"(xg1 + 64 * c), "s"(dst), "s"(dst + 256) : "memory");
             };
-            auto take_x = [&](int c) {
-#pragma unroll
-                for (int v = 0; v < NV; v++) {
-                    asm volatile("" : "+v"(xn[v]));
-                    float t = xn[v];
-                    t = t * s2[v];
-                    t = t + h2[v];
-                    t = t > 0.0f ? t : 0.0f;
-                    xv[v] = (c < 15 || lane < 8) ? t : 0.0f;
-                }
-            };
+            request_x(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             f32x4 t[W];
-            f32x2 e[2][2];   // the noise values of the current / next row (two register sets), columns (l, l+64) and (l+128, l+192)
+            f32x2 e[4][2];   // the noise values of four consecutive rows (two pairs: one being computed, one on its way), columns (l, l+64) and (l+128, l+192)
 #pragma unroll
             for (int i = 0; i < W; i++) t[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 2; i++) e[i][0] = e[i][1] = f32x2{0.f, 0.f};
+            for (int i = 0; i < 4; i++) e[i][0] = e[i][1] = f32x2{0.f, 0.f};
             auto refill = [&](auto ii) {   // row I of the next block of base rows, into the registers of the row just consumed
                 constexpr int I = decltype(ii)::value;
                 gload4_theta_after<(I % 4) * 1024>(t[I], voff, tnext + (I / 4) * 1024, acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
             };
-            // the first block of base rows and the first two chunks of activations: everything landed before the loop is entered (the
-            // compiler may copy registers at the loop's entry; it must not copy one that a load is still writing)
-            request_x(0);
+            // the first block of base rows: landed before the loop is entered (the compiler may copy registers at the loop's entry; it
+            // must not copy one that a load is still writing)
             static_for<W>(refill);
             tnext += W * 256;
 #pragma unroll
             for (int i = 0; i < W; i++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[i]));
-            take_x(0);
-            request_x(1);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn[0]), "+v"(xn[1]));
-            // before row i is read, the loads issued after its own are the (W - 1) other rows and the ND DMAs of the tick's end (a lower
-            // bound: mirror copies and activation loads only make the wait stricter)
-            constexpr int PENDING = (W - 1) + ND;
+            // before the later row of a pair is read, the loads issued after its own are the W - 2 rows of the other pairs (a lower
+            // bound: a chunk of activations only makes the wait stricter)
+            constexpr int PENDING2 = W - 2;   // ... counted from the later row of a pair
             int nb = FC_SUB0 / W;   // row block at which the current sub-slice ends
+            f32x2 xr[4];   // (x0, x1) of four consecutive rows: a row's pair is still needed by its stage B when the read two rows ahead goes out
+#pragma unroll
+            for (int i = 0; i < 4; i++) xr[i] = f32x2{0.f, 0.f};
             for (int lb = 0; lb < NBLK; lb++) {
-                const int li = (lb % BPC) * W;
                 const unsigned va = vlane4 + (lds_ring + (unsigned)(slot * RING_SEG + dlt) * 4u);
-                const bool mir = mirror_due();
-                ring_row<0>(e[0][0], e[0][1], va);
-                static_for<W>([&](auto ii) {
+                const unsigned vx = lds_x + (unsigned)(((lb >> 3) & 1) * 512 + (lb & 7) * 32);   // this tick's eight rows of the current chunk, member 0's plane (every lane the same address)
+                if ((lb & 7) == 0 && lb + 8 < NBLK) request_x((lb >> 3) + 1);   // the next chunk, eight ticks ahead
+                auto reads = [&](auto ii) {   // row I's noise values and activations
                     constexpr int I = decltype(ii)::value;
-                    asm volatile("s_waitcnt vmcnt(%[n]) lgkmcnt(0)" : "+v"(t[I]), "+v"(e[I & 1][0]), "+v"(e[I & 1][1]) : [n] "n"(PENDING));
-                    if constexpr (I + 1 < W) {   // the next row's noise values are on their way while this row is computed
-                        ring_row<I + 1>(e[(I + 1) & 1][0], e[(I + 1) & 1][1], va);
+                    ring_row<I>(e[I % 4][0], e[I % 4][1], va);
+                    ring_x<I>(xr[I % 4], vx);
+                };
+                reads(std::integral_constant<int, 0>{});
+                reads(std::integral_constant<int, 1>{});
+                // Two rows per step: both rows' operands waited for at once, the next pair's LDS reads sent out, then the two rows' arithmetic
+                // in one scheduling region -- two independent multiply -> add chains ahead of the fmas instead of one (a wave alone on its
+                // SIMD cycle otherwise sits out that latency row after row: 0.17 us per row on the tick clock of the first 8-wave form) --
+                // and each row's registers refilled right behind the step that consumed them, as before: a schedule in which the refill
+                // ran ahead of or behind its row made the register allocator rotate the base-row registers at the loop's back edge (copies
+                // of registers that loads were still writing: a memory fault on the box).
+                static_for<W / 2>([&](auto kk) {
+                    constexpr int K = decltype(kk)::value, I0 = 2 * K, I1 = 2 * K + 1, S0 = I0 % 4, S1 = I1 % 4;
+                    // this pair's LDS reads went out behind the previous step's wait and had that pair's arithmetic to land
+                    asm volatile("s_waitcnt vmcnt(%[n]) lgkmcnt(0)" : "+v"(t[I0]), "+v"(t[I1]), "+v"(e[S0][0]), "+v"(e[S0][1]), "+v"(e[S1][0]), "+v"(e[S1][1]), "+v"(xr[S0]), "+v"(xr[S1]) : [n] "n"(PENDING2));
+                    if constexpr (I1 + 2 < W) {   // the next pair is on its way while this one is computed
+                        reads(std::integral_constant<int, I0 + 2>{});
+                        reads(std::integral_constant<int, I1 + 2>{});
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     {
-                        const f32x2 tlo = {t[I][0], t[I][1]}, thi = {t[I][2], t[I][3]};
-                        // fl(-sigma eps) = -fl(sigma eps): the second member's weight is base - p with the first member's p (es.py:415, 419)
                         const f32x2 sc = {scale0, scale0};
-                        const f32x2 pl = sc * e[I & 1][0], ph = sc * e[I & 1][1];
-                        const float x0 = lane_bcast(xv[0], li + I), x1 = lane_bcast(xv[1], li + I);
-                        const f32x2 xx0 = {x0, x0}, xx1 = {x1, x1};
-                        const f32x2 wl0 = tlo + pl, wh0 = thi + ph, wl1 = tlo - pl, wh1 = thi - ph;
-                        acc[0][0] = __builtin_elementwise_fma(xx0, wl0, acc[0][0]);
-                        acc[0][1] = __builtin_elementwise_fma(xx0, wh0, acc[0][1]);
-                        acc[1][0] = __builtin_elementwise_fma(xx1, wl1, acc[1][0]);
-                        acc[1][1] = __builtin_elementwise_fma(xx1, wh1, acc[1][1]);
+                        // fl(-sigma eps) = -fl(sigma eps): the second member's weight is base - p with the first member's p (es.py:415, 419)
+                        const f32x2 tl0 = {t[I0][0], t[I0][1]}, th0 = {t[I0][2], t[I0][3]}, tl1 = {t[I1][0], t[I1][1]}, th1 = {t[I1][2], t[I1][3]};
+                        const f32x2 pl0 = sc * e[S0][0], ph0 = sc * e[S0][1], pl1 = sc * e[S1][0], ph1 = sc * e[S1][1];
+                        const f32x2 a0 = tl0 + pl0, a1 = th0 + ph0, a2 = tl0 - pl0, a3 = th0 - ph0;
+                        const f32x2 b0 = tl1 + pl1, b1 = th1 + ph1, b2 = tl1 - pl1, b3 = th1 - ph1;
+                        const f32x2 xa0 = {xr[S0][0], xr[S0][0]}, xa1 = {xr[S0][1], xr[S0][1]}, xb0 = {xr[S1][0], xr[S1][0]}, xb1 = {xr[S1][1], xr[S1][1]};
+                        acc[0][0] = __builtin_elementwise_fma(xa0, a0, acc[0][0]);
+                        acc[0][1] = __builtin_elementwise_fma(xa0, a1, acc[0][1]);
+                        acc[1][0] = __builtin_elementwise_fma(xa1, a2, acc[1][0]);
+                        acc[1][1] = __builtin_elementwise_fma(xa1, a3, acc[1][1]);
+                        acc[0][0] = __builtin_elementwise_fma(xb0, b0, acc[0][0]);
+                        acc[0][1] = __builtin_elementwise_fma(xb0, b1, acc[0][1]);
+                        acc[1][0] = __builtin_elementwise_fma(xb1, b2, acc[1][0]);
+                        acc[1][1] = __builtin_elementwise_fma(xb1, b3, acc[1][1]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    refill(ii);
-                    if constexpr (I == 3) {   // a due mirror copy goes out in the middle of the tick: behind the tick's end it would be the
-                        if (mir) dma_seg(tau + PD, R);   // first thing the next tick's counted waits retire, a fresh HBM round trip
-                    }
+                    refill(std::integral_constant<int, I0>{});
+                    refill(std::integral_constant<int, I1>{});
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 tnext += W * 256;
-                if (lb % BPC == BPC - 1 && lb + 1 < NBLK) {
-                    take_x(lb / BPC + 1);
-                    request_x(lb / BPC + 2);
-                }
                 if (lb + 1 == nb) {   // end of a sub-slice (oracle fc_raw): the chain joins the quarter's left fold and starts again from 0
                     const bool first = nb == FC_SUB0 / W;
 #pragma unroll
@@ -2070,7 +2123,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_fc_ring(FwdArgs A, const int *__
                         }
                     nb += FC_SUBN / W;
                 }
-                tick_end(false);
+                tick_end();
             }
 #pragma unroll
             for (int i = 0; i < W; i++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[i]));   // the over-fetched block, the last DMAs
@@ -2081,7 +2134,7 @@ __global__ __launch_bounds__(NW * 64, 1) void k_fc_ring(FwdArgs A, const int *__
             }
         }
         idle_until(tmax);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last ticks' DMAs (nobody reads them): not into the next item's ring
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loader's last DMAs (nobody reads them): not into the next item's ring
 #ifdef DNE_PHASE_CLOCK
         if (tk_on && lane == 0) {
             long long *pl = g_duo_plan[tk_wg][wv];

@@ -259,13 +259,14 @@ class RelayClient:
             p.subscribe(**{TASK_CHANNEL: lambda msg: handler(msg['data'])})
             p.run_in_thread(sleep_time=0.001)
         self._declare_task_local(*retry_get(self.master_redis, (TASK_ID_KEY, TASK_DATA_KEY)))
-        # forward worker results to the master in batches (dist.py:127-133): block for the first result, then keep draining for
-        # one millisecond past it, so that a burst of workers finishing together costs the master one RPUSH instead of many
+        # forward worker results to the master in batches (dist.py:127-133 collects for a millisecond): block for one result, then take
+        # what has queued up behind it in the meantime -- a burst of workers finishing together costs the master one RPUSH, a lone
+        # result is forwarded at once, and the loop never sits in a blocking pop with results in hand (this relay is the local
+        # list's only consumer, so LLEN is exact)
         batches = 0
         while max_batches is None or batches < max_batches:
             batch = [self.local_redis.blpop(RESULTS_KEY)[1]]
-            deadline = time.time() + 0.001
-            while time.time() < deadline:
+            for _ in range(min(int(self.local_redis.llen(RESULTS_KEY)), 4096)):
                 batch.append(self.local_redis.blpop(RESULTS_KEY)[1])
             self.master_redis.rpush(RESULTS_KEY, *batch)
             self.results_published += len(batch)

@@ -66,7 +66,7 @@ typedef struct { /* filled by dne_get_profile; times from HIP events on the engi
     double fc_full_ms;
     double fc_full_launches;
     double fc_full_units; /* env-steps (member-steps actually taken) processed by those launches */
-    double fc_full_kind;  /* which kernel those launches were: 4 = k_fc_sub (one wave per sub-slice chain), 3 = k_fc_duo (table-ordered units), 2 = k_fc2 (two pairs per work item), 1 = k_fc */
+    double fc_full_kind;  /* which kernel those launches were: 5 = k_fc_ring (the workgroup's noise rows through an LDS ring), 4 = k_fc_sub (one wave per sub-slice chain), 3 = k_fc_duo (table-ordered units), 2 = k_fc2 (two pairs per work item), 1 = k_fc */
     double fc_full_union_ms; /* time during which at least one of those launches was running (windows run them concurrently) */
     double reserved[1];
 } dne_profile;

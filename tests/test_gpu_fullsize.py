@@ -133,7 +133,7 @@ def test_bench_config_soak(full):
             assert p["env_steps"] == rec["len"].sum()
             assert 0 < p["fc_full_units"] <= p["env_steps"]                        # profiled launches cover a subset of the steps
             assert 0 < p["fc_full_union_ms"] <= p["eval_ms"] * 1.001 and p["fc_full_union_ms"] <= p["fc_full_ms"] * 1.001
-            assert 0 < p["ref_ms"] < p["eval_ms"] and p["fc_full_kind"] == 3      # the table-ordered streaming kernel (k_fc_duo)
+            assert 0 < p["ref_ms"] < p["eval_ms"] and p["fc_full_kind"] == 5      # the table-ordered streaming kernel (k_fc_ring)
             assert p["fc_full_launches"] >= 3 and np.isfinite(ratio) and ratio > 0
             if first is None:
                 first = rec.copy()

@@ -1,5 +1,5 @@
 #!/bin/bash
-# What k_fc_duo waits for: the vector-memory path's own counters -- TA (address unit), TCP (per-CU L1),
+# What the streaming fc (k_fc_ring; DNE_FC_RING=0: k_fc_duo) waits for: the vector-memory path's own counters -- TA (address unit), TCP (per-CU L1),
 # TCC (per-XCD L2) and the L2's fabric side -- one rocprofv3 --pmc pass per group (kernel trace only), over
 #   alone:  the kernel with the chip to itself, 2500 pairs in one window (tools/kbench.py, DNE_NSUB=1: six launches of 5000 member-steps)
 #   mix:    every k_fc_duo dispatch of bench.py's own launch mix (--steps 3 --warmup 1; counter collection serialises the dispatches)
@@ -48,18 +48,23 @@ PY
 }
 groups() {  # prefix command...
   local pre=$1; shift
-  pass $pre.TA   "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum GRBM_GUI_ACTIVE" "$@"
+  pass $pre.TAa  "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" "$@"
+  pass $pre.TAb  "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" "$@"
+  pass $pre.GUI  "GRBM_GUI_ACTIVE" "$@"
+  pass $pre.SQa  "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES" "$@"
+  pass $pre.SQb  "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "$@"
+  pass $pre.SQl  "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "$@"
   pass $pre.TCPa "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" "$@"
   pass $pre.TCPb "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum" "$@"
-  pass $pre.TCPc "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum TCP_TOTAL_READ_sum" "$@"
+  if [ "${FULL:-1}" = "1" ]; then pass $pre.TCPc "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum TCP_TOTAL_READ_sum" "$@"; fi
   pass $pre.TCCa "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "$@"
   pass $pre.TCCb "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum TCC_TAG_STALL_sum" "$@"
   pass $pre.TCCc "TCC_BUSY_sum TCC_CYCLE_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum" "$@"
-  pass $pre.SQm  "SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "$@"
 }
 DNE_NSUB=1 groups alone $ALONE
 if [ "${MIX:-1}" = "1" ]; then
-  pass mix.TA   "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum GRBM_GUI_ACTIVE" $BENCH
+  pass mix.TAa  "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" $BENCH
+  pass mix.GUI  "GRBM_GUI_ACTIVE" $BENCH
   pass mix.TCPa "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" $BENCH
   pass mix.TCPb "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum" $BENCH
   pass mix.TCCa "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" $BENCH

@@ -7,7 +7,7 @@
 import csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 D, PFX = sys.argv[1], sys.argv[2]
-TAG = "k_fc_duo"
+TAG = os.environ.get("KTAG", "k_fc_ring")   # the roofline kernel of the run (KTAG=k_fc_duo for a DNE_FC_RING=0 collection)
 
 
 def table(name):

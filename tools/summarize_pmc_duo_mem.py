@@ -12,7 +12,7 @@ ratios that say where the kernel waits:
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 D, PFX = sys.argv[1], sys.argv[2]
-TAG = "k_fc_duo"
+TAG = os.environ.get("KTAG", "k_fc_ring")   # the streaming fc kernel of the run (KTAG=k_fc_duo for DNE_FC_RING=0 collections)
 N_CU, N_TCC = 256, 128   # address units / L1s; L2 channels (16 per XCD)
 
 
@@ -102,15 +102,17 @@ for prefix in ("alone", "mix"):
         if S("TCC_EA0_RDREQ_DRAM_sum") is not None:
             d["fabric_reads_to_dram_frac"] = S("TCC_EA0_RDREQ_DRAM_sum") / max(S("TCC_EA0_RDREQ_sum"), 1.0)
     if S("SQ_WAVE_CYCLES"):
-        for k in ("SQ_ACTIVE_INST_VMEM", "SQ_WAIT_INST_LDS", "SQ_INST_LEVEL_VMEM"):
+        for k in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS"):
             if S(k) is not None:
                 d[k + "_over_wave_cycles"] = S(k) / S("SQ_WAVE_CYCLES")
-        for k in ("SQ_INSTS_VMEM_RD", "SQ_INSTS_SMEM"):
+        for k in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT"):
             if S(k) is not None and units:
                 d[k + "_per_unit"] = S(k) / units
+        if S("SQ_ACTIVE_INST_VALU") is not None and gui:
+            d["valu_busy_frac_of_simd_time"] = S("SQ_ACTIVE_INST_VALU") * 4.0 / (1024.0 * gui)
     r["derived"] = d
     doc[prefix] = r
-out = os.path.join(ROOT, "profiles", "%s_pmc_fc_duo_mem.json" % PFX)
+out = os.path.join(ROOT, "profiles", "%s_pmc_%s_mem.json" % (PFX, TAG.replace("k_", "")))
 json.dump(doc, open(out, "w"), indent=1)
 print(json.dumps({k: v.get("derived") for k, v in doc.items() if isinstance(v, dict)}, indent=1))
 print("wrote", out)

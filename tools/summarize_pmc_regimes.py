@@ -14,7 +14,7 @@ P, FCW, FC_FLOATS, NOISE = 1009058, 12432, 3872 * 256, 250_000_000
 
 
 def fc_kernel(path):
-    rows = [r for r in csv.DictReader(open(path)) if 'k_fc_duo' in r['kernel'] or 'k_fc2' in r['kernel'] or r['kernel'].startswith('dne::k_fc<')]
+    rows = [r for r in csv.DictReader(open(path)) if 'k_fc_ring' in r['kernel'] or 'k_fc_duo' in r['kernel'] or 'k_fc2' in r['kernel'] or r['kernel'].startswith('dne::k_fc<')]
     return max(rows, key=lambda r: float(r['avg_counter_KB']) * int(r['dispatches']))      # the streaming kernel of this regime
 
 
