@@ -85,11 +85,26 @@ __device__ __forceinline__ void ram_store(const Emu &e, uint8_t *row) {
 
 // MaxAndSkipEnv (atari_wrappers.py:88-107): 4 raw frames, rewards summed, early stop on game over;
 // prev / cur are the RAM before / after the last executed frame.
+#ifdef DNE_PHASE_CLOCK
+// Profiling build only (DNE_ENV_BURN): what the headline would do if a raw frame cost what a 6507 + TIA
+// interpreter costs -- every lane that steps an emulator spends this many extra lane-instructions per raw frame on a dependent integer
+// chain (four per iteration) whose result nobody reads.  The fixture's own frame is ~60; results are unchanged.
+__device__ int g_env_burn = 0;
+#endif
 __device__ inline int skip4(Emu &prev, Emu &cur, int action, int *over) {
     int tot = 0;
     *over = 0;
     for (int i = 0; i < 4; i++) {
         prev = cur;
+#ifdef DNE_PHASE_CLOCK
+        {
+            unsigned x = cur.rng + (unsigned)i;
+            for (int b = g_env_burn >> 2; b > 0; b--) {
+                x = x * 1664525u + 1013904223u;
+                asm volatile("" : "+v"(x));
+            }
+        }
+#endif
         tot += emu_frame(cur, action);
         if (cur.over) { *over = 1; break; }
     }
@@ -566,7 +581,7 @@ struct dne_handle {
     int duo_rounds = 1;              // DNE_DUO_ROUNDS: duos per wave and work item of the sweep (1-4)
     int duo_sync = 1;                // DNE_DUO_SYNC: row blocks per barrier of the sweep (1-8)
     int burst = 32, burst_tail = 16; // DNE_BURST / DNE_BURST_TAIL: lock-steps between two compactions of the active list (a host round trip each), at large / with at most fc_tail_max groups alive (round 4: 32 at large, 16 before; 24 / 32 / 48 measured -0.5 .. -0.9 %, 8 +2.3 %, 64 +0.2 %; the tail indifferent)
-    int ring_on = 1;                 // DNE_FC_RING (round 5): k_fc_ring instead of k_fc_duo -- the workgroup's noise rows through an LDS ring filled by LDS-DMA, the base rows from a column-permuted copy of the fc matrix; 1: where two units share a wave (>= DNE_DUO_SOLO_BELOW active pairs), 2: in the whole k_fc_duo range
+    int ring_on = 1;                 // DNE_FC_RING (round 5): k_fc_ring instead of k_fc_duo -- the workgroup's noise rows through an LDS ring filled by LDS-DMA, the base rows from a column-permuted copy of the fc matrix; 1: from DNE_DUO_SOLO_BELOW active pairs (1500) upwards, 2: in the whole k_fc_duo range (measured slower in the sparse part: 239 vs 233 ms), 0: k_fc_duo everywhere
     float *theta_perm = nullptr;     // [3872 + 16][256]: base slot 0's fc matrix, every row stored as columns l, l+64, l+128, l+192 per lane (k_theta_perm, once per evaluation)
     int duo_fat = 1;                 // DNE_DUO_FAT: k_fc_duo with a register footprint past 256 per lane = at most one of its workgroups per CU (it streams as fast from one), so the other windows' kernels always find room beside it
     int duo_w = 8;                   // DNE_DUO_W: rows in flight per stream of k_fc_duo (8: two waves per SIMD; 4: four)
@@ -634,10 +649,7 @@ struct dne_handle {
     float *y1r[2] = {nullptr, nullptr}, *y2r[2] = {nullptr, nullptr}, *y3pr[2] = {nullptr, nullptr};   // reference pass scratch, two ways
     float *fr1[2] = {nullptr, nullptr}, *fr2[2] = {nullptr, nullptr};   // per-frame batch-norm moments of conv1 / conv2 ([rows][2][C])
     hipEvent_t ev_ref[2] = {nullptr, nullptr};
-    // DNE_REF_OVERLAP (round 5): the reference pass runs chunk by chunk on two streams of its own and a window starts its lock-steps
-    // as soon as the chunks of ITS members are through (policies.py:399: the pass precedes that member's first step -- unchanged),
-    // so the first windows stream their noise slices while the later chunks keep the matrix cores busy
-    int ref_overlap = 0;
+    int ref_overlap = 0;             // DNE_REF_OVERLAP (round 5): the reference pass runs chunk by chunk on two streams of its own and a window starts its lock-steps as soon as the chunks of ITS members are through (policies.py:399: the pass still precedes that member's first step); measured slower (238.6 vs 233.5 ms per generation), off
     int ref_prio = 1;                // DNE_REF_PRIO: 1 = the reference pass's own streams at the lowest priority (the windows' short kernels go first)
     hipStream_t ref_streams[2] = {nullptr, nullptr};
     std::vector<hipEvent_t> ev_chunk;   // recorded behind the last kernel of reference chunk c
@@ -971,6 +983,13 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_TAILK_MAX", 0, 1 << 20, &h->fc_tailk_max);
     env_int("DNE_DEBUG_SKIP", 0, 7, &h->dbg_skip);
     env_int("DNE_DEBUG_IMMORTAL", 0, 1, &h->dbg_immortal);
+#ifdef DNE_PHASE_CLOCK
+    {
+        int burn = 0;
+        env_int("DNE_ENV_BURN", 0, 1 << 20, &burn);
+        CH(hipMemcpyToSymbol(HIP_SYMBOL(g_env_burn), &burn, sizeof(int)));
+    }
+#endif
     env_int("DNE_TAIL_TABLE", 0, 1, &h->tt_enable);
     env_int("DNE_HEAD_THREADS", 256, 320, &h->head_threads); h->head_threads = h->head_threads >= 320 ? 320 : 256;
     env_int("DNE_RENDER_THREADS", 256, 1024, &h->render_threads); h->render_threads = wg_size(h->render_threads);

@@ -13,6 +13,18 @@ for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "deep-neuroevolution_
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU test")
+    config.addinivalue_line("markers", "variants: a kernel / schedule no default path launches (the A/B library): -m 'gpu and variants' or DNE_TEST_VARIANTS=1")
+
+
+def pytest_collection_modifyitems(config, items):
+    """The default GPU suite covers the product path; the kernels kept only as same-box A/B references (forward_variants.h and the
+    non-default schedules) run when asked for by name."""
+    if os.environ.get("DNE_TEST_VARIANTS") == "1" or "variants" in (config.getoption("-m") or ""):
+        return
+    skip = pytest.mark.skip(reason="non-default kernel variant: run with -m 'gpu and variants' or DNE_TEST_VARIANTS=1")
+    for it in items:
+        if "variants" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -141,7 +141,20 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
             assert l == ln[i, s] and nov[2 * i + s] == oracle.novelty(arch, bc, 2)
 
 
-@pytest.mark.parametrize("knobs", [
+# Settings that put a kernel or schedule NO default path launches onto the test population (the A/B library of DESIGN.md section 4):
+# they run with `-m "gpu and variants"` (or DNE_TEST_VARIANTS=1) only; everything else forces a DEFAULT-path kernel onto a population
+# small enough for the oracle and stays in the default GPU suite.
+_VARIANT_KEYS = {"DNE_FC2_MIN", "DNE_DUO_LAG", "DNE_DUO_HEAD_FUSED", "DNE_DUO_SWEEP", "DNE_DUO_ROUNDS", "DNE_DUO_SYNC", "DNE_DUO_W", "DNE_FC_DUO",
+                 "DNE_FC_PAIRS", "DNE_FC_RB", "DNE_HEAD_THREADS", "DNE_TAIL_TABLE", "DNE_SPEC_CONV1", "DNE_SPEC_BANDS", "DNE_TAIL_FUSED_MAX",
+                 "DNE_CONV1_FPW", "DNE_CONV1_SHARED", "DNE_BAND_THREADS", "DNE_FC_SUB_SPW", "DNE_FC_SUB_NSUB", "DNE_DUO_FAT", "DNE_GA_MATERIALIZE",
+                 "DNE_FC_DUO_GA"}
+
+
+def _knob_params(knob_list):
+    return [pytest.param(k, marks=pytest.mark.variants) if _VARIANT_KEYS & set(k) else k for k in knob_list]
+
+
+_ES_STEP_KNOBS = [
     {"DNE_FC2_MIN": "2", "DNE_FC_TAIL_MAX": "1"},                       # k_fc2 (two pairs per work item; odd count: repeated pair)
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1"},                    # table-ordered units: k_unit_order + k_fc_duo (one unit per wave below 1500 pairs) + k_out
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_LAG": "3"},   # ... two units per wave, the second trailing further (a schedule, not arithmetic)
@@ -197,7 +210,10 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
     {"DNE_RENDER_BANDS": "2"},                                          # two render workgroups per member
     {"DNE_CONV_FUSED_MIN": "1"},                                        # conv1 + conv2 in one kernel (k_conv12) at every count
     {"DNE_CONV_FUSED": "0", "DNE_CONV_SPLIT_MAX": "0"},                 # never: separate k_conv1 / k_conv2 launches
-])
+]
+
+
+@pytest.mark.parametrize("knobs", _knob_params(_ES_STEP_KNOBS))
 def test_every_step_kernel_variant_is_bit_exact(knobs, oracle, small_noise, monkeypatch):
     """the engine picks its lock-step kernels by active count; the tuning knobs force each variant onto a population small
     enough for the oracle (5 pairs = odd count, episodes of different lengths so that the active list shrinks)"""
@@ -365,7 +381,7 @@ def test_reference_pass_under_the_first_lock_steps(knobs, oracle, small_noise, m
         e.close()
 
 
-@pytest.mark.parametrize("knobs", [
+_GA_STEP_KNOBS = [
     {"DNE_FC_DUO_GA": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1"},                              # table-ordered fc for single members, one unit per wave
     {"DNE_FC_DUO_GA": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0"},   # ... two units per wave
     {"DNE_SPEC_MAX": "0"},                                                                            # GA tail without speculation
@@ -381,7 +397,10 @@ def test_reference_pass_under_the_first_lock_steps(knobs, oracle, small_noise, m
     {"DNE_FC_SUB_MIN": "2"},                                                                          # the mid range's sub-slice fc (k_fc_sub<1, false, false> on written-out children) at every count
     {"DNE_FC_SUB_MIN": "2", "DNE_FC_SUB_SPW": "4", "DNE_FC_SUB_NSUB": "3"},                           # ... four chains per wave, three windows
     {"DNE_FC_SUB": "0"},                                                                              # ... and switched off
-])
+]
+
+
+@pytest.mark.parametrize("knobs", _knob_params(_GA_STEP_KNOBS))
 def test_ga_step_kernel_variants_are_bit_exact(knobs, oracle, small_noise, monkeypatch):
     """the GA evaluation (single members, one base vector per parent, final-RAM behaviour characterisation) through the kernel
     variants the ES test above cannot reach"""

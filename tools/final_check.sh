@@ -1,6 +1,6 @@
 #!/bin/bash
 # what the driver runs at round end: the GPU suite, smoke(), the bench with the driver's flags -- on the final tree
-TAG=${1:-r04s}
+TAG=${1:-r05s}
 O=$PWD/gpurun_out/$TAG; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -x -q --durations=8 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -16 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log
