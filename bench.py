@@ -475,6 +475,20 @@ def run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, t
             r["traffic_GBps"] = out[name]["value"] * per_unit / 1e9
             r["traffic_source"] = "counted bytes of the ES streaming kernel at this leg's env-steps/s (%s, %s)" % (src, (regime or "").split(":")[0])
             r["frac_counter"] = out[name]["value"] * per_unit / (HBM_PEAK * world)
+    # the GA legs: every dispatch of tools/ga_bench.py (--large) counted, per env-step of that run (tools/summarize_pmc_ga.py)
+    for rel in ("profiles/r05_pmc_ga.json",):
+        try:
+            gd = json.load(open(os.path.join(ROOT, rel)))
+        except Exception:
+            continue
+        for name in ("ga", "ga_large"):
+            r = out.get(name, {}).get("roofline") if isinstance(out.get(name), dict) else None
+            if r and name in gd:
+                r["traffic"] = None
+                r["traffic_bytes_per_unit"] = gd[name]["bytes_per_unit"]
+                r["traffic_GBps"] = out[name]["value"] * gd[name]["bytes_per_unit"] / 1e9
+                r["traffic_source"] = "%s: FETCH_SIZE x2 + WRITE_SIZE over every dispatch of tools/ga_bench.py%s, per env-step of that run" % (rel, " --large" if name == "ga_large" else "")
+                r["frac_counter"] = out[name]["value"] * gd[name]["bytes_per_unit"] / (HBM_PEAK * world)
     for name in out:   # an algorithmic fraction above 1 says the denominator counts bytes the kernels share, not that a roofline was beaten
         r = out[name].get("roofline") if isinstance(out[name], dict) else None
         if r and isinstance(r.get("frac"), (int, float)) and r["frac"] > 1.0:

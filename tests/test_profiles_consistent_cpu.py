@@ -25,7 +25,8 @@ def test_bench_profile_quotes_the_committed_pmc_summary():
     d = json.loads(open(path).read().strip().splitlines()[-1])
     r = d["roofline"]
     rnd = os.path.basename(path)[:3]
-    per_unit, src, regime = bench._pmc_traffic(3, r["units_per_launch"])            # 3 = k_fc_duo (dne_profile.fc_full_kind)
+    kind = 5 if "k_fc_ring" in r["kernel"] else 3                                    # dne_profile.fc_full_kind: k_fc_ring (round 5) / k_fc_duo
+    per_unit, src, regime = bench._pmc_traffic(kind, r["units_per_launch"])
     assert src == os.path.join("profiles", "%s_pmc.json" % rnd), (src, rnd)          # the same round's counters, not an older file
     assert regime == r["traffic_regime"] and regime.startswith("bench_mix")          # measured on the bench's own launch mix
     assert r["traffic"] == pytest.approx(per_unit * r["units_per_launch"], rel=1e-9)
@@ -39,6 +40,9 @@ def test_bench_profile_quotes_the_committed_pmc_summary():
     pmc = json.load(open(os.path.join(ROOT, src)))
     mix = [x for x in pmc["regimes"] if x["regime"].startswith("bench_mix")][0]
     assert mix["dispatches_match_bench"] and mix["hbm_bytes_per_unit"] == pytest.approx(per_unit)
+    assert r.get("traffic_bytes_per_unit", per_unit) == pytest.approx(per_unit)
+    if r["frac"] > 1.0:                                                             # an algorithmic fraction above 1 carries its flag
+        assert r.get("denominator_exceeds_peak") is True and "frac_pair_sharing" in r["whole_job"]
     # cpu baseline: states the host it ran on and a best-of-sweep wall-clock rate
     c = d["cpu_baseline"]
     assert c["value"] == pytest.approx(max(x["rate_wall"] for x in c["sweep"])) and c["host"]["usable_cpus"] <= c["host"]["os_cpu_count"]

@@ -26,8 +26,9 @@ with open(sys.argv[2], 'w') as f:
         f.write('"%s",%s,%d,%.1f\n' % (k[0], k[1], len(disp[k]), tot[k]))
 PY
 }
-pass() {  # name "counters" command...
+pass() {  # name "counters" command...   (SKIP="TAb SQa ..." leaves groups out)
   local name=$1 ctr=$2; shift 2
+  if echo " ${SKIP:-} " | grep -q " ${name#*.} "; then return; fi
   timeout 240 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$O/$name.d" -o p -- "$@" > "$O/$name.json" 2> "$O/$name.err"
   f=$(find "$O/$name.d" -name '*counter_collection.csv' | head -1)
   if [ -n "$f" ]; then reduce "$f" "$O/$name.csv"; else echo "no counter file for $name" >> "$O/errors.log"; tail -5 "$O/$name.err" >> "$O/errors.log"; fi

@@ -4,10 +4,10 @@ k_fc_duo (TA / TCP / TCC / fabric side), alone at 2500 pairs in one window and o
 ratios that say where the kernel waits:
   ta_busy_frac             TA_TA_BUSY summed over the 256 CUs' address units / (256 x the kernel's GRBM_GUI_ACTIVE cycles)
   tcp_*_stall_frac         the L1's stall cycles over the same denominator
-  l1_hit_frac              1 - TCP_TCC_READ_REQ x 64 B (L2 read requests are 64-byte) / bytes the waves asked for (TA_FLAT_READ_WAVEFRONTS x 1 KiB)
+  l1_hit_frac              1 - TCP_TCC_READ_REQ x 128 B / bytes the waves asked for (TA_FLAT_READ_WAVEFRONTS x 1 KiB)
   l2_hit_frac              TCC_HIT / (TCC_HIT + TCC_MISS)
   l2_read_req_latency_cyc  TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ (cycles an L2 read request of the L1 is outstanding)
-  fabric_bytes             TCC_EA0_RDREQ_32B x 32 + (TCC_EA0_RDREQ - TCC_EA0_RDREQ_32B) x 64
+  fabric_bytes             TCC_EA0_RDREQ_32B x 32 + (TCC_EA0_RDREQ - TCC_EA0_RDREQ_32B) x 128
     python tools/summarize_pmc_duo_mem.py gpurun_out/<tag>/pmc_duo_mem r05"""
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -72,7 +72,7 @@ for prefix in ("alone", "mix"):
     d = {}
     gui = S("GRBM_GUI_ACTIVE")
     if gui:
-        cyc = gui   # summed over the dispatches, chip-level cycles
+        cyc = gui / 8.0   # GRBM_GUI_ACTIVE is reported per XCD and summed over the eight: shader cycles of the dispatches
         d["cycles_per_dispatch"] = cyc / n
         for k, name, inst in (("TA_TA_BUSY_sum", "ta_busy_frac", N_CU), ("TA_ADDR_STALLED_BY_TC_CYCLES_sum", "ta_addr_stalled_by_tc_frac", N_CU),
                               ("TA_DATA_STALLED_BY_TC_CYCLES_sum", "ta_data_stalled_by_tc_frac", N_CU),
@@ -86,9 +86,11 @@ for prefix in ("alone", "mix"):
     if S("TA_FLAT_READ_WAVEFRONTS_sum"):
         asked = S("TA_FLAT_READ_WAVEFRONTS_sum") * 1024.0   # nearly all of the kernel's vector loads are 16 bytes per lane
         d["bytes_asked_per_unit"] = asked / units if units else None
-        if S("TCP_TCC_READ_REQ_sum"):
-            d["l2_read_req_bytes_per_unit_at_64B"] = S("TCP_TCC_READ_REQ_sum") * 64.0 / units if units else None
-            d["l1_hit_frac_at_64B_requests"] = 1.0 - S("TCP_TCC_READ_REQ_sum") * 64.0 / asked
+        if S("TCP_TCC_READ_REQ_sum"):   # an L2 request of the L1 is a 128-byte line (TCC_EA0_RDREQ x 128 B reproduces FETCH_SIZE x 2)
+            d["l2_read_req_bytes_per_unit"] = S("TCP_TCC_READ_REQ_sum") * 128.0 / units if units else None
+            d["l1_hit_frac"] = 1.0 - S("TCP_TCC_READ_REQ_sum") * 128.0 / asked
+        if S("TA_TA_BUSY_sum") and gui:
+            d["ta_busy_cycles_per_wave_load"] = S("TA_TA_BUSY_sum") / S("TA_FLAT_READ_WAVEFRONTS_sum")
     if S("TCP_TCC_READ_REQ_sum") and S("TCP_TCC_READ_REQ_LATENCY_sum"):
         d["l2_read_req_latency_cyc"] = S("TCP_TCC_READ_REQ_LATENCY_sum") / S("TCP_TCC_READ_REQ_sum")
     if S("TCP_TOTAL_CACHE_ACCESSES_sum") and S("TCP_TCP_LATENCY_sum"):
@@ -98,7 +100,7 @@ for prefix in ("alone", "mix"):
         d["l2_requests_per_unit"] = S("TCC_REQ_sum") / units if S("TCC_REQ_sum") and units else None
     if S("TCC_EA0_RDREQ_sum") is not None:
         b32 = S("TCC_EA0_RDREQ_32B_sum") or 0.0
-        d["fabric_read_bytes_per_unit"] = (b32 * 32.0 + (S("TCC_EA0_RDREQ_sum") - b32) * 64.0) / units if units else None
+        d["fabric_read_bytes_per_unit"] = (b32 * 32.0 + (S("TCC_EA0_RDREQ_sum") - b32) * 128.0) / units if units else None   # (x 128 B: the gfx950 correction of MI355X_MICROARCH.md)
         if S("TCC_EA0_RDREQ_DRAM_sum") is not None:
             d["fabric_reads_to_dram_frac"] = S("TCC_EA0_RDREQ_DRAM_sum") / max(S("TCC_EA0_RDREQ_sum"), 1.0)
     if S("SQ_WAVE_CYCLES"):
@@ -109,7 +111,7 @@ for prefix in ("alone", "mix"):
             if S(k) is not None and units:
                 d[k + "_per_unit"] = S(k) / units
         if S("SQ_ACTIVE_INST_VALU") is not None and gui:
-            d["valu_busy_frac_of_simd_time"] = S("SQ_ACTIVE_INST_VALU") * 4.0 / (1024.0 * gui)
+            d["valu_busy_frac_of_simd_time"] = S("SQ_ACTIVE_INST_VALU") * 4.0 / (1024.0 * gui / 8.0)
     r["derived"] = d
     doc[prefix] = r
 out = os.path.join(ROOT, "profiles", "%s_pmc_%s_mem.json" % (PFX, TAG.replace("k_", "")))
