@@ -1823,18 +1823,29 @@ __global__ __launch_bounds__(256, FAT ? 1 : W == 8 ? 2 : 4) void k_fc_duo(FwdArg
 }
 
 // ------------------------------------------------------- k_fc_ring (round 5): the workgroup's noise rows through an LDS ring
-// What k_fc_duo waits for (profiles/r05_duo_tick_clock.json, r05_pmc_fc_duo_mem.json): a tick of its table timeline costs
-// 0.45 us + 0.12 us per streaming unit -- a fixed HBM round trip (every row is consumed exactly one tick after it was requested, and
-// the unit at the front of the timeline misses every cache) plus the CU's vector-memory path at ~56 B/clk for the 16 KB each unit
-// pulls through it, although the eight units of a workgroup read the SAME 4096-float window of the table within a tick.
-// Here the window lives in LDS: a ring of 2048-float segments (one tick of the timeline each) that the four waves fill by LDS-DMA
-// (global_load_lds_dwordx4: no register round trip) RING_PD ticks ahead -- every table row passes the vector-memory path once per
-// workgroup instead of once per unit (72 KB per full tick instead of 128 KB), and its HBM latency is hidden by the prefetch distance
-// instead of being paid every tick.  A unit's row starts at an arbitrary float of the table (es.py:67 draws any integer), so the LDS
-// reads cannot be 16-byte reads; lane l takes columns l, l+64, l+128, l+192 instead -- consecutive lanes read consecutive banks at any
-// alignment (two ds_read2st64_b32 per row) -- and the base rows come from a copy of the fc matrix whose rows are stored in that
-// order (k_theta_perm, once per evaluation), so that they stay one 16-byte load per lane and row.  Which lane holds which column
-// is not arithmetic: every output's chain still runs over k in order from zero (oracle fc_raw) -- same bits.
+// What k_fc_duo waits for (profiles/r05_duo_tick_clock.json, r05_pmc_fc_duo_mem.json): a tick of its table
+// timeline costs 0.45 us + 0.12 us per streaming unit -- a fixed HBM round trip (every row is consumed exactly one tick after it was
+// requested, and the unit at the front of the timeline misses every cache) plus the CU's vector-memory path at ~56 B/clk for the 16 KB
+// each unit pulls through it, although the eight units of a workgroup read the SAME 4096-float window of the table within a tick.
+//
+// Here the window lives in LDS: a ring of RING_SLOTS segments of 2048 floats (one tick of the timeline each; a mirror of slot 0 behind
+// the last slot: a block that starts in the last slot runs on into it).  One workgroup = NW compute waves = NW units that follow each
+// other in table order, ONE unit per wave (two waves per SIMD hide each other's issue latency; a wave's only loop with loads in flight
+// is entered behind a full drain and left into one), plus a LOADER wave that fills the ring by LDS-DMA (global_load_lds_dwordx4: no
+// register round trip) RING_PD ticks ahead with three ticks of vmcnt budget of its own -- vmcnt retires in order, so a DMA issued by
+// a wave that also streams base rows is forced out one tick later and a tick could never be shorter than the HBM round trip of the
+// segment being fetched (the first two forms of this kernel ticked at >= 0.57 us with a single unit streaming).  Every table row
+// passes the vector-memory path once per workgroup instead of once per unit (72 KB per full tick instead of 128 KB).
+//
+// A unit's row starts at an arbitrary float of the table (es.py:67 draws any integer), so the LDS reads cannot be 16-byte reads; lane
+// l takes columns l, l+64, l+128, l+192 instead -- consecutive lanes read consecutive banks at any alignment (two ds_read2st64_b32
+// per row) -- and the base rows come from a copy of the fc matrix whose rows are stored in that order (k_theta_perm, once per
+// evaluation), so that they stay one 16-byte load per lane and row.  Activations arrive finished (relu(bn2(y2)): k_conv12's act2 /
+// k_y2_activate), a chunk of 64 rows goes to the wave's own corner of LDS by LDS-DMA eight ticks ahead and a row reads its pair
+// (x0, x1) back as one broadcast ds_read2_b32: v_pk_fma takes either half for both lanes (op_sel) -- no v_readlane, and unlike
+// scalar loads (s_load shares lgkmcnt with ds_read and returns out of order) these reads keep the counted waits exact.
+// Which lane holds which column, which wave fetches what: a schedule.  Every output's chain still runs over k in order from zero, the
+// sub-slices fold left, k_out combines the slices (oracle fc_raw) -- same bits.
 constexpr int RING_SLOTS = 7, RING_SEG = 2048, RING_PD = 5;   // slots (+ one mirror of slot 0 behind the last), floats per segment, prefetch distance in ticks
 
 __global__ __launch_bounds__(256) void k_theta_perm(const float *__restrict__ fcw /*[rows][256]*/, float *__restrict__ out /*[rows + 16][256]*/, int rows) {
@@ -1877,21 +1888,12 @@ __device__ __forceinline__ void ring_row(f32x2 &lo, f32x2 &hi, unsigned vaddr) {
                  : "=v"(lo), "=v"(hi) : "v"(vaddr), "n"(4 * I), "n"(4 * I + 1), "n"(4 * I + 2), "n"(4 * I + 3));
 }
 
-// One workgroup = NW waves = NW units that follow each other in table order, ONE unit per wave: two waves per SIMD hide each other's
-// VALU latency (one wave per SIMD issued a packed op every ~8 cycles: the first form of this kernel, two units per wave on four
-// waves, spent 0.93 us of wave time per 16 row-sides), and a wave's only loop with loads in flight is entered behind a full drain
-// and left into one -- no phase change carries registers that a load is still writing (the compiler places copies there).
 // row I's activations (x0, x1): every lane reads the same eight bytes (a broadcast, conflict-free); lands asynchronously
 template <int I>
 __device__ __forceinline__ void ring_x(f32x2 &x, unsigned vaddr) {   // (member 0's plane, member 1's 64 floats behind it)
     asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(x) : "v"(vaddr), "n"(I), "n"(64 + I));
 }
 
-// Round 5, third form: a LOADER wave.  Every version with the compute waves issuing their share of the DMAs ticked at >= 0.57 us
-// even with one unit streaming: vmcnt retires in order, so a DMA sits in the same queue as the base-row loads and the first counted
-// wait of the tick after next forces it out -- one tick after its issue, i.e. a tick can never be shorter than the HBM round trip of
-// the segment being fetched.  Wave NW (the ninth) now issues ALL of a tick's DMAs and waits for them with a budget of two full ticks;
-// the compute waves' counters see base rows and activations only.
 // At most four waves per SIMD (amdgpu_waves_per_eu: the register allocation is rounded up to 104 per lane): the workgroup's nine take
 // 2 / 2 / 2 / 3, a second workgroup of this kernel finds no SIMD for its third wave -- one per CU, k_fc_duo's FAT -- and a
 // 199-register k_conv12 wave still fits beside the three.  (A plain launch bound of (576, 1) makes the compiler pad to 129 registers,
@@ -2023,11 +2025,7 @@ __global__ __launch_bounds__((NW + 1) * 64) __attribute__((amdgpu_waves_per_eu(3
             f32x2 acc[NV][2], fold[NV][2];
 #pragma unroll
             for (int v = 0; v < NV; v++) acc[v][0] = acc[v][1] = fold[v][0] = fold[v][1] = f32x2{0.0f, 0.0f};
-            // activations: relu(bn2(y2)) as the convolution kernel left them (k_conv12's act2 / k_y2_activate).  A chunk of 64 rows (both
-            // members of the pair) is fetched one row per lane eight ticks ahead and parked in the wave's own corner of LDS; every row
-            // then reads its pair (x0, x1) back with ONE broadcast ds_read_b64 -- all lanes the same address -- and v_pk_fma takes either
-            // half for both of its lanes (op_sel): no v_readlane (a sixth of the row loop's vector instructions, its slowest ones), and
-            // unlike scalar loads these reads return in order with the noise rows', so the counted waits below stay exact.
+            // activations (the header above): chunk c of 64 rows, both members' planes, into buffer c & 1 of the wave's corner of LDS
             const float *xg0 = y2 + (size_t)mem0 * 3872 + 968 * sl, *xg1 = xg0 + 3872;
             auto request_x = [&](int c) {   // chunk c = rows 64 c .. 64 c + 63 (the last chunk has eight: the other lanes re-read its last row)
                 unsigned vo = vlane4;
