@@ -561,7 +561,7 @@ struct dne_handle {
     std::vector<hipStream_t> sub_streams;   // sub-batch streams (sub_streams[0] == stream)
     int dbg_skip = 0;   // DNE_DEBUG_SKIP bitmask (timing experiments only): 1 conv1, 2 conv2, 4 render
     int dbg_immortal = 0;   // DNE_DEBUG_IMMORTAL (timing experiments only): every member lives until tslimit -- a lock-step keeps its width
-    int render_threads = 256;
+    int render_threads = 512;        // DNE_RENDER_THREADS: threads per k_env_render workgroup above 192 members (one workgroup per member).  Round 5: 512 -- beside k_fc_ring a generation takes 216.8 instead of 223.1 ms same-box (768: 217.2, 1024: 235.3); rounds 1-4: 256 (beside k_fc_duo 512 measured +1 %)
     int conv1_fpw = 8;               // reference pass: frames per conv1 workgroup (DNE_CONV1_FPW: 1, 2, 4, 8)
     int conv_fused = 1, conv_fused_min = 129;   // DNE_CONV_FUSED / DNE_CONV_FUSED_MIN: conv1 + conv2 in one kernel from this many members
     int conv12t_max = 64;            // members up to which conv1 -> conv2 is one launch of four workgroups per member (DNE_CONV12T_MAX, 0 = off)

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Rewrite DESIGN.md section 9 (round 5's results table) from the files under profiles/r05_*: every figure there is one of these
+files' numbers.   python tools/design_results_r05.py"""
+import csv, json, os, re
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = lambda f: os.path.join(ROOT, "profiles", f)
+last = lambda p: json.loads([l for l in open(p) if l.startswith("{")][-1])
+d = last(P("r05_bench_steps20_warmup5.json")); r = d["roofline"]; dd = last(P("r05_bench_default.json"))
+shares = [json.loads(l) for l in open(P("r05_population_shares.jsonl"))]
+burn = [json.loads(l) for l in open(P("r05_env_burn.jsonl"))]
+pmc = json.load(open(P("r05_pmc.json"))); mem = json.load(open(P("r05_pmc_fc_ring_mem.json")))["alone"]["derived"]
+ga = json.load(open(P("r05_pmc_ga.json")))
+c = d["cpu_baseline"]; e = d["extra"]
+mix = [x for x in pmc["regimes"] if x["regime"].startswith("bench_mix")][0]
+fixed = {x["regime"].split(":")[0]: x for x in pmc["regimes"] if not x["regime"].startswith("bench_mix")}
+sq = pmc["sq"]["k_fc_ring"]["wave_cycles_split"]
+ks = {row["Name"].split("(")[0].replace("void ", ""): row for row in csv.DictReader(open(P("r05_bench_kernel_stats.csv")))}
+kp = lambda tag: next(v for k, v in ks.items() if tag in k)
+ref_pct = sum(float(kp(t)["Percentage"]) for t in ("k_conv1_ref_shared", "k_conv2_ref", "k_fc_ref"))
+res = f'''## 9. Results of round 5 (1×MI355X box, 2× EPYC 9575F host of which the container gets 16 CPUs; everything on the SynthAtari fixture; `profiles/r05_*`)
+
+The counters are from ONE run of `bash tools/collect_profiles_r05.sh r05z` (the PMC passes first, summarised on the box, so that the bench lines quote the committed
+`profiles/r05_pmc.json`); the bench lines, kernel stats and shares were taken again on the final tree (`tools/calls/m12.sh`, run r05y: the renderer's workgroups went
+from 256 to 512 threads in between, a schedule, after the GPU suite of the same call had passed).  Rows marked "same-box A/B" are `tools/ab_inproc.py` (one process,
+one noise table, one engine per setting, settings round-robin).  Boxes differ by ±2 %.
+
+| what | value | source |
+|---|---|---|
+| ES pop 5000, the driver's command (`--steps 20 --warmup 5`) | **{d['value']/1e6:.3f} M env-steps/s** ({d['ms_per_step']:.1f} ms per generation over generations 5–24; round 4: 2.331 M, 332.2 ms on the driver's box; the same command before the renderer change: 2.497–2.505 M).  Same-box A/Bs of this round (ms per generation, generations 3–10): `k_fc_duo` 251.1–255.7 → **`k_fc_ring` 223.9–233.2** (−9 … −11 %) → **216.8 with 512-thread render workgroups** (223.1 with 256, 217.2 with 768, 235.3 with 1024); ring in the sparse regime too 239.3 vs 233.2; reference pass under the first lock-steps 238.6 vs 233.5; non-temporal ring DMAs 227.4 vs 223.9; 3 windows / ring waves at priority 0 or 1 / ring from 1100 or 1900 pairs / ring grid 256 / bursts of 48: 223.4–225.7 vs 223.9–225.4 (noise); head + emulator in one launch behind the ring 236.9, bursts of 64 228.5, split convolutions 229.4 | `profiles/r05_bench_steps20_warmup5.json`, `profiles/r05_ab_ring.json`, `profiles/r05_ring_nt_ab.json`, `gpurun_out/r05k`, `r05m`, `r05n`, `r05o` |
+| ES pop 5000, defaults (generations 1–2) | {dd['value']/1e6:.3f} M env-steps/s ({dd['ms_per_step']:.1f} ms per generation) | `profiles/r05_bench_default.json` |
+| roofline kernel `k_fc_ring<true, 8>` | {r['avg_launch_ms']:.3f} ms per ≈ {r['units_per_launch']:.0f}-unit launch, {r['launches']} launches (every window with ≥ 1500 active pairs on the rank); `frac` = `frac_algorithmic` {r['frac']:.3f} (`denominator_exceeds_peak`: SURVEY §8d's bytes count every member's weights once per env-step, the kernel shares them); `frac_counter` {r['frac_counter']:.3f} at the bytes measured on the bench's own launch mix; over the union of the concurrent launches {r['concurrent_launches']['frac']:.2f} / **{r['concurrent_launches']['frac_counter']:.3f}** ({r['concurrent_launches']['busy_ms_per_generation']:.0f} ms of a generation's {d['ms_per_step']:.0f} have at least one such launch running); whole job {r['whole_job']['frac']:.2f} algorithmic, **{r['whole_job']['frac_pair_sharing']:.2f} at the pair-sharing bytes** (2 010 688 B per unit) | bench line |
+| HBM-side traffic (`FETCH_SIZE`×2 + `WRITE_SIZE`, separate `--pmc` passes) | **bench mix: {mix['hbm_bytes_per_unit']/1e6:.3f} MB per member-step** ({mix['dispatches']} launches of `bench.py --steps 3 --warmup 1`, dispatch count = the bench's launch count: {mix['dispatches_match_bench']}; round 4's `k_fc_duo`: 0.855); 2500 pairs in one window {fixed['full_1window']['hbm_bytes_per_unit']/1e6:.2f} MB, in four {fixed['full_4windows']['hbm_bytes_per_unit']/1e6:.2f} MB; every distinct row once 0.20 MB, every pair's slice once 2.01 MB, §8d figure 4.06 MB | `profiles/r05_pmc.json` |
+| `k_fc_ring` alone (2500 pairs, one window): the vector-memory path | 0.867 ms per launch; the waves ask for {mem['bytes_asked_per_unit']/1e6:.2f} MB per member-step (`k_fc_duo`: 4.08), {mem['l2_read_req_bytes_per_unit']/1e6:.2f} MB of it from L2 (2.92), L2 hit rate {100*mem['l2_hit_frac']:.0f} %, {mem['fabric_read_bytes_per_unit']/1e6:.2f} MB from the fabric (0.80); an L2 request is out {mem['l2_read_req_latency_cyc']:.0f} cycles; **address units busy {100*mem['ta_busy_frac']:.0f} % of the launch** ({mem['ta_busy_cycles_per_wave_load']:.1f} cycles per 1 KB wave-load: 0.54 ms if they never idled — the nearest ceiling), L1 stalled on pending data {100*mem['tcp_pending_stall_frac']:.0f} %, LDS bank conflicts 0; per wave: issuing {100*sq['SQ_ACTIVE_INST_ANY']:.0f} % (VALU {100*sq['SQ_ACTIVE_INST_VALU']:.0f} %), parked {100*sq['SQ_WAIT_ANY']:.0f} % (the timeline's idle ticks and barriers), issue-stalled {100*sq['SQ_WAIT_INST_ANY']:.0f} % of its cycles; {pmc['sq']['k_fc_ring']['SQ_INSTS_VALU_per_unit']/2/968:.1f} VALU instructions per row | `profiles/r05_pmc_fc_ring_mem.json`, `profiles/r05_pmc.json` (`sq`) |
+| what `k_fc_duo` waited for (round 4's kernel; section 4a) | a tick of its timeline: 0.55 µs with one unit streaming … 1.42 µs with eight (0.45 µs + 0.12 µs per unit); L2 request latency 349 cycles, fabric read 866; `k_fc_ring`: 0.53 … 0.94 µs | `profiles/r05_duo_tick_clock.json`, `profiles/r05_pmc_fc_duo_mem.json` |
+| kernel time of the default command (rocprofv3 `--kernel-trace --stats`) | `k_fc_ring` {float(kp('k_fc_ring')['Percentage']):.1f} % ({float(kp('k_fc_ring')['AverageNs'])/1e3:.0f} µs per launch; the profiled run's own line: {last(P('r05_bench_under_rocprofv3.json'))['roofline']['avg_launch_ms']*1e3:.0f} µs over its timed launches), `k_conv12<true>` {float(kp('k_conv12<')['Percentage']):.1f} % ({float(kp('k_conv12<')['AverageNs'])/1e3:.0f} µs), `k_env_render` {float(kp('k_env_render')['Percentage']):.1f} %, `k_out` {float(kp('k_out')['Percentage']):.1f} %, the reference pass's three kernels {ref_pct:.1f} %, `k_fc_duo` (451 … 1499 pairs) {float(kp('k_fc_duo')['Percentage']):.1f} % | `profiles/r05_bench_kernel_stats.csv` |
+| reference pass | {d['roofline_ref_pass']['ms_per_generation']:.1f} ms per generation inside the bench = {d['roofline_ref_pass']['frac']:.2f} of the fp32 MFMA peak at 2.4 GHz (unchanged: round 5 did not touch its kernels beyond the `wsum` race) | bench line |
+| CPU baseline (oracle, single-threaded worker processes, best wall-clock rate of a worker-count sweep) | **{c['value']/1e3:.1f} k env-steps/s with {c['cores']} workers**; GPU / CPU = **{c['gpu_over_cpu']:.0f}× against the 16 CPUs this container gets**, ≈ {d['value']/(c['rate_per_cpu_second']*128):.0f}× against the box's 128 physical cores at the same per-CPU rate | bench line |
+| population shares on one GPU (what a rank sees at N = 2 / 4 / 8): 1250 / 625 / 312 pairs | **{shares[0]['ms_per_step']:.1f} / {shares[1]['ms_per_step']:.1f} / {shares[2]['ms_per_step']:.1f} ms** per generation (round 4: 201.9 / 101.3 / 54.7; `k_fc_ring` only runs from 1500 pairs) ⇒ expected strong-scaling efficiency before the all-gather {d['ms_per_step']/(2*shares[0]['ms_per_step']):.2f} / {d['ms_per_step']/(4*shares[1]['ms_per_step']):.2f} / {d['ms_per_step']/(8*shares[2]['ms_per_step']):.2f} — a prediction, not a measurement (lower than round 4's 0.83 / 0.83 / 0.77 because the full population got faster and the shares did not) | `profiles/r05_population_shares.jsonl` |
+| GA (config 3), 1000 children, top-20 | {e['ga']['value']/1e6:.2f} M env-steps/s; counted traffic {ga['ga']['bytes_per_unit']/1e6:.2f} MB per env-step (algorithmic 4.06): `frac_counter` {e['ga']['roofline']['frac_counter']:.2f} whole-job | `extra.ga`, `profiles/r05_pmc_ga.json` |
+| GA, LargeModel, 1000 children | {e['ga_large']['value']/1e6:.3f} M env-steps/s; counted traffic {ga['ga_large']['bytes_per_unit']/1e6:.1f} MB per env-step (algorithmic 16.24): `frac_counter` {e['ga_large']['roofline']['frac_counter']:.2f} | `extra.ga_large`, `profiles/r05_pmc_ga.json` |
+| NS-ES (config 4), pop 5000 | {e['nses']['value']/1e6:.2f} M env-steps/s per iteration incl. novelty, exchange, blend, update, parent selection (round 4: 1.67) | `extra.nses` |
+| six-game sweep (config 5) | {e['sweep']['value']/1e6:.2f} M env-steps/s over the six games (round 4: 2.31) | `extra.sweep` |
+| emulator-cost sensitivity (`DNE_ENV_BURN`, profiling build: extra lane-instructions per raw frame on every lane that steps an emulator; run r05z) | 0 / 2 k / 8 k / 20 k ⇒ **{burn[0]['value']/1e6:.2f} / {burn[1]['value']/1e6:.2f} / {burn[2]['value']/1e6:.2f} / {burn[3]['value']/1e6:.2f} M env-steps/s** (6 generations after 2 warm-up) | `profiles/r05_env_burn.jsonl` |
+| GPU suite | 100 passed, 39 skipped (kernel variants: `-m "gpu and variants"`), 362 s on the box, incl. `test_generations_past_zero_bit_exact` (generations 0, 1, 2 and 5 value by value, θ and Adam's m, v, t); smoke | `gpurun_out/r05y` (`tools/calls/m12.sh`) |
+
+Not measured: N = 2 / 4 / 8 GPUs (a gpurun box has one; section 8).  Against VERDICT round 4's targets: the streaming kernel alone ≤ 0.95 ms — reached (0.87 ms);
+full-width lock-step ≤ 1.40 ms — 1.36–1.47 ms depending on the box (before the renderer change); headline ≥ 2.65 M — **{d['value']/1e6:.2f} M on the driver's command, {dd['value']/1e6:.2f} M over
+generations 1–2**: the other kernels of a lock-step (0.66 ms alone) still overlap the streaming fc only partially (section 4c).
+
+'''
+p = os.path.join(ROOT, "DESIGN.md"); s = open(p).read()
+a = s.index("## 9. Results of round 5"); b = s.index("## 9a. Results of round 4")
+open(p, "w").write(s[:a] + res + s[b:])
+print("section 9 rewritten: %.3f M env-steps/s, frac_counter %.3f" % (d["value"] / 1e6, r["frac_counter"]))
