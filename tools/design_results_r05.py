@@ -26,7 +26,7 @@ one noise table, one engine per setting, settings round-robin).  Boxes differ by
 
 | what | value | source |
 |---|---|---|
-| ES pop 5000, the driver's command (`--steps 20 --warmup 5`) | **{d['value']/1e6:.3f} M env-steps/s** ({d['ms_per_step']:.1f} ms per generation over generations 5–24; round 4: 2.331 M, 332.2 ms on the driver's box; the same command before the renderer change: 2.497–2.505 M).  Same-box A/Bs of this round (ms per generation, generations 3–10): `k_fc_duo` 251.1–255.7 → **`k_fc_ring` 223.9–233.2** (−9 … −11 %) → **216.8 with 512-thread render workgroups** (223.1 with 256, 217.2 with 768, 235.3 with 1024); ring in the sparse regime too 239.3 vs 233.2; reference pass under the first lock-steps 238.6 vs 233.5; non-temporal ring DMAs 227.4 vs 223.9; 3 windows / ring waves at priority 0 or 1 / ring from 1100 or 1900 pairs / ring grid 256 / bursts of 48: 223.4–225.7 vs 223.9–225.4 (noise); head + emulator in one launch behind the ring 236.9, bursts of 64 228.5, split convolutions 229.4 | `profiles/r05_bench_steps20_warmup5.json`, `profiles/r05_ab_ring.json`, `profiles/r05_ring_nt_ab.json`, `gpurun_out/r05k`, `r05m`, `r05n`, `r05o` |
+| ES pop 5000, the driver's command (`--steps 20 --warmup 5`) | **{d['value']/1e6:.3f} M env-steps/s** ({d['ms_per_step']:.1f} ms per generation over generations 5–24; round 4: 2.331 M, 332.2 ms on the driver's box; the same command before the renderer change: 2.497–2.505 M).  Same-box A/Bs of this round (ms per generation, generations 3–10): `k_fc_duo` 251.1–255.7 → **`k_fc_ring` 223.9–233.2** (−9 … −11 %) → **216.8 with 512-thread render workgroups** (223.1 with 256, 217.2 with 768, 235.3 with 1024); ring in the sparse regime too 239.3 vs 233.2; reference pass under the first lock-steps 238.6 vs 233.5; non-temporal ring DMAs 227.4 vs 223.9; 3 windows / ring waves at priority 0 or 1 / ring from 1100 or 1900 pairs / ring grid 256 / bursts of 48: 223.4–225.7 vs 223.9–225.4 (noise); head + emulator in one launch behind the ring 236.9, bursts of 64 228.5, split convolutions 229.4; with the 512-thread renderer: `k_out` LDS reservation 32 / 64 KB 218.2 / 220.3, 640-thread renderer 218.1 vs 218.0 | `profiles/r05_bench_steps20_warmup5.json`, `profiles/r05_ab_ring.json`, `profiles/r05_ring_nt_ab.json`, `gpurun_out/r05k`, `r05m`, `r05n`, `r05o`, `r05p` |
 | ES pop 5000, defaults (generations 1–2) | {dd['value']/1e6:.3f} M env-steps/s ({dd['ms_per_step']:.1f} ms per generation) | `profiles/r05_bench_default.json` |
 | roofline kernel `k_fc_ring<true, 8>` | {r['avg_launch_ms']:.3f} ms per ≈ {r['units_per_launch']:.0f}-unit launch, {r['launches']} launches (every window with ≥ 1500 active pairs on the rank); `frac` = `frac_algorithmic` {r['frac']:.3f} (`denominator_exceeds_peak`: SURVEY §8d's bytes count every member's weights once per env-step, the kernel shares them); `frac_counter` {r['frac_counter']:.3f} at the bytes measured on the bench's own launch mix; over the union of the concurrent launches {r['concurrent_launches']['frac']:.2f} / **{r['concurrent_launches']['frac_counter']:.3f}** ({r['concurrent_launches']['busy_ms_per_generation']:.0f} ms of a generation's {d['ms_per_step']:.0f} have at least one such launch running); whole job {r['whole_job']['frac']:.2f} algorithmic, **{r['whole_job']['frac_pair_sharing']:.2f} at the pair-sharing bytes** (2 010 688 B per unit) | bench line |
 | HBM-side traffic (`FETCH_SIZE`×2 + `WRITE_SIZE`, separate `--pmc` passes) | **bench mix: {mix['hbm_bytes_per_unit']/1e6:.3f} MB per member-step** ({mix['dispatches']} launches of `bench.py --steps 3 --warmup 1`, dispatch count = the bench's launch count: {mix['dispatches_match_bench']}; round 4's `k_fc_duo`: 0.855); 2500 pairs in one window {fixed['full_1window']['hbm_bytes_per_unit']/1e6:.2f} MB, in four {fixed['full_4windows']['hbm_bytes_per_unit']/1e6:.2f} MB; every distinct row once 0.20 MB, every pair's slice once 2.01 MB, §8d figure 4.06 MB | `profiles/r05_pmc.json` |
