@@ -21,13 +21,18 @@ for st in starts:
     wi = [i for i, l in enumerate(lines) if re.search(r"s_waitcnt vmcnt\(\d+\) lgkmcnt\(0\)", l)]
     if not wi:
         sys.exit("audit: %s has no counted wait -- the row loop was not found" % lines[0].split(":")[0])
-    lo = wi[0]
-    while lo > 0 and not re.match(r"\.LBB\d+_\d+:", lines[lo]):
-        lo -= 1
-    label = lines[lo].split(":")[0]
-    hi = wi[-1]
-    while hi < len(lines) - 1 and not (("s_cbranch" in lines[hi] or "s_branch" in lines[hi]) and label in lines[hi]):
-        hi += 1
+    # the row loop = the SMALLEST loop (a label and a later branch back to it) that holds at least four of the counted waits
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"(\.LBB\d+_\d+):", l)] if m}
+    loops = []
+    for i, l in enumerate(lines):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            lo_, hi_ = labels[m.group(1)], i
+            if sum(1 for w in wi if lo_ <= w <= hi_) >= 4:
+                loops.append((hi_ - lo_, lo_, hi_, m.group(1)))
+    if not loops:
+        sys.exit("audit: no loop around the counted waits of %s" % lines[0].split(":")[0])
+    _, lo, hi, label = min(loops)
     body = lines[lo:hi + 1]
     dst = set()
     for l in body:
