@@ -20,7 +20,7 @@ ref_pct = sum(float(kp(t)["Percentage"]) for t in ("k_conv1_ref_shared", "k_conv
 res = f'''## 9. Results of round 5 (1×MI355X box, 2× EPYC 9575F host of which the container gets 16 CPUs; everything on the SynthAtari fixture; `profiles/r05_*`)
 
 The counters are from ONE run of `bash tools/collect_profiles_r05.sh r05z` (the PMC passes first, summarised on the box, so that the bench lines quote the committed
-`profiles/r05_pmc.json`); the bench lines, kernel stats and shares were taken again on the final tree (`tools/calls/m12.sh`, run r05y: the renderer's workgroups went
+`profiles/r05_pmc.json`); the bench lines, kernel stats and shares were taken again on the final tree (`tools/calls/final_tree.sh`, run r05y: the renderer's workgroups went
 from 256 to 512 threads in between, a schedule, after the GPU suite of the same call had passed).  Rows marked "same-box A/B" are `tools/ab_inproc.py` (one process,
 one noise table, one engine per setting, settings round-robin).  Boxes differ by ±2 %.
 
@@ -41,7 +41,7 @@ one noise table, one engine per setting, settings round-robin).  Boxes differ by
 | NS-ES (config 4), pop 5000 | {e['nses']['value']/1e6:.2f} M env-steps/s per iteration incl. novelty, exchange, blend, update, parent selection (round 4: 1.67) | `extra.nses` |
 | six-game sweep (config 5) | {e['sweep']['value']/1e6:.2f} M env-steps/s over the six games (round 4: 2.31) | `extra.sweep` |
 | emulator-cost sensitivity (`DNE_ENV_BURN`, profiling build: extra lane-instructions per raw frame on every lane that steps an emulator; run r05z) | 0 / 2 k / 8 k / 20 k ⇒ **{burn[0]['value']/1e6:.2f} / {burn[1]['value']/1e6:.2f} / {burn[2]['value']/1e6:.2f} / {burn[3]['value']/1e6:.2f} M env-steps/s** (6 generations after 2 warm-up) | `profiles/r05_env_burn.jsonl` |
-| GPU suite | 100 passed, 39 skipped (kernel variants: `-m "gpu and variants"`), 362 s on the box, incl. `test_generations_past_zero_bit_exact` (generations 0, 1, 2 and 5 value by value, θ and Adam's m, v, t); smoke | `gpurun_out/r05y` (`tools/calls/m12.sh`) |
+| GPU suite | 100 passed, 39 skipped (kernel variants: `-m "gpu and variants"`), 362 s on the box, incl. `test_generations_past_zero_bit_exact` (generations 0, 1, 2 and 5 value by value, θ and Adam's m, v, t); smoke | `gpurun_out/r05y` (`tools/calls/final_tree.sh`) |
 
 Not measured: N = 2 / 4 / 8 GPUs (a gpurun box has one; section 8).  Against VERDICT round 4's targets: the streaming kernel alone ≤ 0.95 ms — reached (0.87 ms);
 full-width lock-step ≤ 1.40 ms — 1.36–1.47 ms depending on the box (before the renderer change); headline ≥ 2.65 M — **{d['value']/1e6:.2f} M on the driver's command, {dd['value']/1e6:.2f} M over
