@@ -90,11 +90,6 @@ def test_file_rendezvous_of_an_external_launcher(tmp_path, monkeypatch):
     """torch.distributed.run's ranks: id and votes through files in a private directory; stale files are ignored"""
     sys.path.insert(0, ROOT)
     import bench
-    monkeypatch.setenv("DNE_RDV_DIR", str(tmp_path / "rdv"))
-    os.makedirs(tmp_path / "rdv")
-    stale = tmp_path / "rdv" / "uid"
-    stale.write_text(json.dumps({"uid": "00" * 128, "err": None}))
-    os.utime(stale, (1, 1))                                          # a leftover from long ago
     world, res = 3, {}
 
     def rank_fn(r, fail):
@@ -102,9 +97,16 @@ def test_file_rendezvous_of_an_external_launcher(tmp_path, monkeypatch):
         uid, err = rdv.exchange_uid(r, bytes(range(128)) if r == 0 else None, None)
         res[r] = (uid, rdv.vote(r, world, not (fail and r == 2), "boom" if fail and r == 2 else None))
     for fail in (False, True):
-        for f in os.listdir(tmp_path / "rdv"):
-            if f.startswith("vote"):
-                os.unlink(tmp_path / "rdv" / f)
+        # every launch has a directory of its own (keyed on the launcher's pid, start time and restart count): a second "launch" into the
+        # first one's directory would let a rank read the FIRST launch's still-fresh id before rank 0 has cleared it -- a race this test
+        # used to lose now and then, and one a real launch cannot have
+        d = tmp_path / ("rdv%d" % int(fail))
+        os.makedirs(d)
+        monkeypatch.setenv("DNE_RDV_DIR", str(d))
+        stale = d / "uid"
+        stale.write_text(json.dumps({"uid": "00" * 128, "err": None}))
+        os.utime(stale, (1, 1))                                          # a leftover from long ago
+        res.clear()
         ts = [threading.Thread(target=rank_fn, args=(r, fail)) for r in range(world)]
         [t.start() for t in ts]
         [t.join(60) for t in ts]
