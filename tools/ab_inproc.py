@@ -6,7 +6,7 @@ settings run round-robin `--rounds` times so that drift shows.  Per setting:
   gen_ms         ms per generation of the driver's workload (generations g0 .. g0+n-1 after `--warmup`, theta evolving)
     python tools/ab_inproc.py "X=0" "DNE_DUO_W=4" "DNE_DUO_W=4 DNE_DUO_SYNC=2"
 """
-import argparse, json, os, sys, time
+import argparse, hashlib, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "deep-neuroevolution_amd"))
@@ -83,7 +83,8 @@ for rnd in range(a.rounds):
                 steps += int(rec["len"].sum())
             e.barrier(); wall = time.time() - t
             r["gen_ms"].append(round(1e3 * wall / a.gens, 2)); r["steps_per_s"].append(round(steps / wall))
+            r.setdefault("theta_sha", []).append(hashlib.sha256(e.get_theta().tobytes()).hexdigest()[:16])   # settings that only change a schedule end on the same bits
         e.close()
         noise._engines[:] = []
         print(json.dumps({"round": rnd, "setting": s, **{k: v[-1] for k, v in r.items() if v}}), flush=True)
-print(json.dumps({"summary": {s: {k: (min(v) if v else None) for k, v in r.items()} for s, r in res.items()}}))
+print(json.dumps({"summary": {s: {k: (min(v) if v and k != "theta_sha" else sorted(set(v)) if v else None) for k, v in r.items()} for s, r in res.items()}}))
