@@ -72,7 +72,9 @@ for rnd in range(a.rounds):
             e.close()
         e = engine(env)
         if "lockstep" not in skip:
-            r["lockstep_ms"].append(round(fixed_width(e)["step_wall_ms"], 4))
+            fw = fixed_width(e)
+            r["lockstep_ms"].append(round(fw["step_wall_ms"], 4))
+            r.setdefault("lockstep_fc_ms_per_launch", []).append(round(fw["fc_ms"], 4)); r.setdefault("lockstep_conv_ms_per_launch", []).append(round(fw["conv_ms"], 4))
         if "gen" not in skip:
             e.set_theta(policies.xavier_flat(18, 0)); e.optimizer_reset()
             for g in range(a.warmup):
