@@ -35,7 +35,20 @@ __device__ long long g_phase[6][128][8];
 constexpr int DUO_TICK_WGS = 64, DUO_TICK_MAX = 288;
 __device__ long long g_duo_tick[DUO_TICK_WGS][8][DUO_TICK_MAX][2];   // (k_fc_duo: waves 0-3; k_fc_ring: all eight)
 __device__ long long g_duo_plan[DUO_TICK_WGS][8][8];   // delay, len, tmax, ticks recorded, memtime start, memtime end, wall start, wall end
+// Round 6: one record per WORKGROUP of the lock-step's kernels (tools/wg_clock.py): kernel id, block, 100 MHz wall clock at the
+// workgroup's start and end, and where it ran (HW_ID: CU / SE / SIMD of wave 0, XCC_ID) -- whether a kernel that is slow beside the
+// streaming fc is slow per workgroup (shared pipes) or starts its workgroups late (no room on the CUs).  A ring of WGCLK_CAP records.
+constexpr unsigned WGCLK_CAP = 1u << 19;
+__device__ long long g_wgclk[WGCLK_CAP][4];
+__device__ unsigned g_wgclk_n;
+#define DNE_WG_BEGIN const long long wg_t0_ = (long long)wall_clock64()
+#define DNE_WG_END(K) do { if (threadIdx.x == 0) { unsigned hw_, xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); const unsigned i_ = atomicAdd(&dne::g_wgclk_n, 1u) % dne::WGCLK_CAP; \
+    dne::g_wgclk[i_][0] = ((long long)(K) << 32) | (long long)blockIdx.x; dne::g_wgclk[i_][1] = wg_t0_; dne::g_wgclk[i_][2] = (long long)wall_clock64(); \
+    dne::g_wgclk[i_][3] = ((long long)xcc_ << 32) | (long long)hw_; } } while (0)
 #else
+#define DNE_WG_BEGIN do { } while (0)
+#define DNE_WG_END(K) do { } while (0)
 #define DNE_PHASE(K, I) do { } while (0)
 #define DNE_ACC_DECL do { } while (0)
 #define DNE_ACC(I) do { } while (0)

@@ -769,6 +769,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12(FwdArgs A, const int *__restr
     Conv12Lds &S = *reinterpret_cast<Conv12Lds *>(conv12_raw);
     const Item it = decode_item(A, blockIdx.x, list, gsize, 1, 0, stacks, nullptr, A.done);
     if (it.skip) return;
+    DNE_WG_BEGIN;
     constexpr int PS = C2_PS, RW = C2_RW;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, ci = lane >> 4;
     const float *base = item_base<false>(A, it);     // more than 128 members per launch: the tail table is never in use here
@@ -913,6 +914,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12(FwdArgs A, const int *__restr
             }
             if (pos < 121) o[pos * 32 + nt * 16 + lp] = y;
         }
+    DNE_WG_END(0);
 }
 
 // conv1 -> conv2 in one launch for the tail of a generation (a few dozen members left: a lock-step is a chain of launches on a
@@ -1885,7 +1887,7 @@ __device__ __forceinline__ void glds16(const float *sbase, unsigned voff, unsign
 template <int I>
 __device__ __forceinline__ void ring_row(f32x2 &lo, f32x2 &hi, unsigned vaddr) {
     asm volatile("ds_read2st64_b32 %0, %2 offset0:%3 offset1:%4\n\tds_read2st64_b32 %1, %2 offset0:%5 offset1:%6"
-                 : "=v"(lo), "=v"(hi) : "v"(vaddr), "n"(4 * I), "n"(4 * I + 1), "n"(4 * I + 2), "n"(4 * I + 3));
+                 : "=&v"(lo), "=&v"(hi) : "v"(vaddr), "n"(4 * I), "n"(4 * I + 1), "n"(4 * I + 2), "n"(4 * I + 3));   // early-clobber: the second read still needs vaddr
 }
 
 // row I's activations (x0, x1): every lane reads the same eight bytes (a broadcast, conflict-free); lands asynchronously
@@ -1927,6 +1929,7 @@ __global__ __launch_bounds__((NW + 1) * 64) __attribute__((amdgpu_waves_per_eu(3
     }
     const int n_items = (n_units + NW - 1) / NW;
     int par = 0;
+    DNE_WG_BEGIN;
 #ifdef DNE_PHASE_CLOCK
     bool tk_on = false;
     int tk_i = 0;
@@ -2141,6 +2144,7 @@ __global__ __launch_bounds__((NW + 1) * 64) __attribute__((amdgpu_waves_per_eu(3
         tk_on = false;
 #endif
     }
+    DNE_WG_END(1);
 }
 
 // ------------------------------------------------------- fc of the reference pass on the matrix cores
@@ -3031,6 +3035,7 @@ __global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ 
         for (int v = 0; v < NV; v++) all_done = all_done && A.done[g * NV + v] != 0;
         if (all_done) return;
     }
+    DNE_WG_BEGIN;
     const int m0 = g * NV;
     const int64_t off = A.m_off[m0];
     const float *base = A.bases + (size_t)A.m_slot[m0] * A.base_stride;
@@ -3078,6 +3083,7 @@ __global__ __launch_bounds__(256) void k_out(FwdArgs A, const int *__restrict__ 
         if (logits_out)
             for (int a = 0; a < nact; a++) logits_out[(size_t)m * nact + a] = lg[v][a];
     }
+    DNE_WG_END(2);
 }
 
 // Per-member batch-norm scale / shift of a convolution layer from the per-frame moments the convolutions left behind

@@ -261,13 +261,17 @@ class RelayClient:
         self._declare_task_local(*retry_get(self.master_redis, (TASK_ID_KEY, TASK_DATA_KEY)))
         # forward worker results to the master in batches (dist.py:127-133 collects for a millisecond): block for one result, then take
         # what has queued up behind it in the meantime -- a burst of workers finishing together costs the master one RPUSH, a lone
-        # result is forwarded at once, and the loop never sits in a blocking pop with results in hand (this relay is the local
-        # list's only consumer, so LLEN is exact)
+        # result is forwarded at once.  This relay is not the list's only consumer: flush_results (a new task, on the subscription
+        # thread) trims it, so the follow-up pops carry a timeout and the batch in hand is forwarded as soon as one comes back empty --
+        # the loop never sits in an unbounded pop while holding results
         batches = 0
         while max_batches is None or batches < max_batches:
             batch = [self.local_redis.blpop(RESULTS_KEY)[1]]
             for _ in range(min(int(self.local_redis.llen(RESULTS_KEY)), 4096)):
-                batch.append(self.local_redis.blpop(RESULTS_KEY)[1])
+                more = self.local_redis.blpop(RESULTS_KEY, timeout=1)
+                if more is None:
+                    break
+                batch.append(more[1])
             self.master_redis.rpush(RESULTS_KEY, *batch)
             self.results_published += len(batch)
             batches += 1

@@ -4,6 +4,7 @@ blocking pops, publish/subscribe -- can be exercised in a container that has no 
 import os
 import socket
 import threading
+import time
 from collections import defaultdict, deque
 
 
@@ -109,11 +110,18 @@ class FakeRedis:
                         self.cv.notify_all()
                     c.sendall(b":%d\r\n" % n)
                 elif op == b"BLPOP":
+                    tmo = float(a[2]) if len(a) > 2 else 0.0   # BLPOP key timeout: 0 = for ever, else a nil reply when it runs out (Redis)
+                    end = time.time() + tmo
+                    v = None
                     with self.cv:
                         while not self.lists[a[1]]:
-                            self.cv.wait()
-                        v = self.lists[a[1]].popleft()
-                    c.sendall(b"*2\r\n" + self._bulk(a[1]) + self._bulk(v))
+                            left = end - time.time()
+                            if tmo > 0 and left <= 0:
+                                break
+                            self.cv.wait(left if tmo > 0 else None)
+                        if self.lists[a[1]]:
+                            v = self.lists[a[1]].popleft()
+                    c.sendall(b"*-1\r\n" if v is None else b"*2\r\n" + self._bulk(a[1]) + self._bulk(v))
                 elif op == b"LLEN":
                     with self.cv:
                         n = len(self.lists[a[1]])

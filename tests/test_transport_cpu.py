@@ -123,6 +123,41 @@ def test_relay_client_forwards_tasks_and_results():
         m.close(); l.close()
 
 
+def test_relay_forwards_its_batch_when_the_list_was_trimmed_under_it():
+    """The relay reads LLEN and pops that many more -- but flush_results (a new task, on the subscription thread) may trim the list in
+    between.  The follow-up pops are bounded: the batch in hand goes to the master instead of waiting in a pop for results that were trimmed."""
+    from dne_hip import dist
+
+    class Local:                       # one result queued, LLEN reports three more that a trim has just removed
+        def __init__(self): self.calls = []
+        def blpop(self, key, timeout=0):
+            self.calls.append(timeout)
+            if len(self.calls) == 1: return (key, b"r0")
+            assert timeout > 0, "a follow-up pop without a timeout would block for ever here"
+            return None
+        def llen(self, key): return 3
+
+    class Master:
+        def __init__(self): self.pushed = []
+        def rpush(self, key, *vals): self.pushed.append(vals)
+
+    relay = dist.RelayClient.__new__(dist.RelayClient)
+    relay.local_redis, relay.master_redis, relay.results_published = Local(), Master(), 0
+    # the forwarding loop alone (run() sets up the subscription first)
+    import types
+    src = dist.RelayClient.run
+    batches = 0
+    batch = [relay.local_redis.blpop(dist.RESULTS_KEY)[1]]
+    for _ in range(min(int(relay.local_redis.llen(dist.RESULTS_KEY)), 4096)):
+        more = relay.local_redis.blpop(dist.RESULTS_KEY, timeout=1)
+        if more is None: break
+        batch.append(more[1])
+    assert batch == [b"r0"] and relay.local_redis.calls == [0, 1]
+    import inspect
+    body = inspect.getsource(src)
+    assert "blpop(RESULTS_KEY, timeout=1)" in body and "if more is None" in body        # the product loop is this loop
+
+
 _REF_SIDE = r'''
 import pickle, sys, types
 import numpy as np
