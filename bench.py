@@ -73,7 +73,7 @@ FC_KERNELS = {   # the kernel behind the profiled ("full") fc launches of one ev
        "pairs; the rank's share is too small for k_fc2)",
 }
 PMC_PROFILES = tuple(os.path.join("profiles", "r0%d_pmc.json" % r) for r in (5, 4, 3, 2, 1))
-EXTRAS = ("ga", "ga_large", "nses", "sweep", "config1")
+EXTRAS = ("ga", "ga_large", "nses", "sweep", "config1", "predicted")
 EXTRAS_MULTI = ("ga", "nses", "sweep")         # default at N > 1: BASELINE configs 4 / 5 are DEFINED on 4 / 8 GPUs (ga_large, config1: one rank)
 SIMDS, SHADER_HZ = 1024, 2.4e9                 # MI355X: 256 CUs x 4 SIMDs; nominal shader clock
 
@@ -435,7 +435,8 @@ def launch_ranks(args, child_argv=None, check_devices=True):
 
 
 # ------------------------------------------------------------------------------------------------ the extra workloads
-def run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, transport_records, tslimit, want_cpu, small, cpu_ref=None):
+def run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, transport_records, tslimit, want_cpu, small, cpu_ref=None,
+               steps=2, warmup=1, pop=5000, headline=None):
     """BASELINE configs 1, 3, 4, 5 (tools/workloads.py), each timed on its own; a failure of one is reported in its slot.
     small (--extra-small, the tests): the same code paths at a population of 96 / 48 children / two games."""
     import workloads as W
@@ -446,7 +447,7 @@ def run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, t
     sw_kw = dict(pop=96, games=["frostbite", "asteroids"]) if small else {}
 
     def leg(name, fn):
-        if name not in which:
+        if name not in which and not (name.startswith("predicted_n") and "predicted" in which):
             return
         crumb("extra: %s" % name)
         t0 = time.time()
@@ -460,6 +461,22 @@ def run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, t
         leg("ga_large", lambda: W.ga_large(noise, device_id=local_rank, tslimit=tslimit, **ga_kw))
     leg("nses", lambda: W.nses(noise, transport=transport_bytes, **shared, **ns_kw))
     leg("sweep", lambda: W.six_games(noise, transport=transport_records, **shared, **sw_kw))
+    if world == 1 and "predicted" in which:
+        # an N = 2 / 4 / 8 launch rehearsed on this one GPU, same generations as the headline region
+        # (tools/workloads.py:simulate_ranks); shares = what ONE rank of such a launch spends per generation, beside the headline's own
+        shares = {}
+        if headline:
+            shares["pairs_%d" % (pop // 2)] = {"ms_per_generation": round(headline["ms_per_step"], 2), "env_steps_per_s": round(headline["value"]), "source": "the headline region"}
+        for n in ((2,) if small else (2, 4, 8)):
+            leg("predicted_n%d" % n, lambda n=n: W.simulate_ranks(noise, n, steps=steps, warmup=warmup, pop=pop, tslimit=tslimit, device_id=local_rank,
+                                                                   verify_generations=1 if small else 2))
+            r = out.get("predicted_n%d" % n, {})
+            if "error" not in r and r:
+                shares["pairs_%d" % r["pairs_per_rank"]] = {"ms_per_generation": r["rank0_share_ms_per_generation"], "ms_per_generation_slowest_rank_plus_update": round(r["ms_per_step"], 2),
+                                                            "source": "extra.predicted_n%d (rank 0's shard: evaluation + records_pack)" % n}
+                if headline:
+                    r["predicted_speedup_over_this_run"] = r["value"] / headline["value"]
+        out["shares"] = shares
     ns_in = out.get("nses", {}).pop("_cpu_inputs", None)      # arrays for the CPU leg, not part of the report
     # the legs that run the ES network stream through the same kernel as the headline: price their whole-job rate at the bytes per
     # member-step the committed PMC summary holds for it (bench_mix regime) -- the streaming kernel's counted traffic, not the whole job's
@@ -677,7 +694,9 @@ def run_rank(args):
     extra = None
     if which:
         extra = run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, transport, args.tslimit,
-                           not args.no_cpu_baseline and world == 1, args.extra_small, cpu_ref=cpu)   # CPU legs: rank 0 at N = 1 only
+                           not args.no_cpu_baseline and world == 1, args.extra_small, cpu_ref=cpu,   # CPU legs: rank 0 at N = 1 only
+                           steps=args.steps, warmup=args.warmup, pop=96 if args.extra_small else args.pop,
+                           headline={"value": total_steps / wall, "ms_per_step": 1e3 * wall / max(args.steps, 1)})
 
     if rank == 0:
         value = total_steps / wall
@@ -715,11 +734,12 @@ def run_rank(args):
                 "units_per_launch": units_per_launch, "avg_launch_ms": avg_ms, "launches": int(fc_launches),
                 "all_generations": {"units": int(all_units), "launches": int(all_launches)},
                 "floors": floors,
-                "note": "frac = frac_algorithmic = SURVEY 8d bytes (every member's weights once per env-step) / launch time / 8 TB/s; "
-                        "an antithetic pair shares one read of its noise slice and (k_fc_ring / k_fc_duo) neighbouring units share table rows, so "
-                        "the bytes the memory system actually moves (frac_counter) are well below that -- frac_counter is the honest "
-                        "distance to the HBM roofline, and it falls when the kernel avoids traffic; floors = what bounds the kernel "
-                        "now: its distinct table rows once at 8 TB/s and its own VALU issue time (SQ counters), per launch",
+                "note": "frac / achieved = COUNTED bytes (traffic_bytes_per_unit x units) over the union of the concurrent launches; "
+                        "frac_algorithmic / achieved_algorithmic = SURVEY 8d bytes (every member's weights once per env-step) / average launch "
+                        "time / 8 TB/s -- above the peak because an antithetic pair shares one read of its noise slice and (k_fc_ring / k_fc_duo) "
+                        "neighbouring units share table rows: an invalid denominator, not skipped work (the bit-exact generation tests prove the "
+                        "work); frac_counter = counted bytes per launch / average launch time; floors = what bounds the kernel now: its distinct "
+                        "table rows once at 8 TB/s and its own VALU issue time (SQ counters), per launch",
             }
             # SURVEY 8d also asks for the whole-job figure: every env-step of the generation (reference pass, tail and
             # update included in the time) priced at the same algorithmic bytes
@@ -735,9 +755,26 @@ def run_rank(args):
                 out["roofline"]["concurrent_launches"] = {"achieved": uni / 1e9, "unit": "GB/s", "frac": uni / HBM_PEAK,
                                                           "frac_counter": (uni / ALG_BYTES_PER_ENV_STEP * per_unit / HBM_PEAK) if per_unit else None,
                                                           "busy_ms_per_generation": fc_union_ms / args.steps}
-            for o in (out["roofline"], out["roofline"]["whole_job"], out["roofline"].get("concurrent_launches", {})):
+            for o in (out["roofline"]["whole_job"], out["roofline"].get("concurrent_launches", {})):
                 if o.get("frac", 0) > 1.0:   # the SURVEY 8d denominator counts shared bytes once per member: not a roofline beaten
                     o["denominator_exceeds_peak"] = True
+            if out["roofline"]["frac_algorithmic"] > 1.0:
+                out["roofline"]["algorithmic_denominator_exceeds_peak"] = True
+            # The headline fraction: COUNTED bytes of the kernel (FETCH_SIZE x2 + WRITE_SIZE per unit from the
+            # committed --pmc passes over this very command) x the units this run's launches processed / the time during which at least
+            # one such launch was running (the windows launch it concurrently: per-launch durations overlap) / 8 TB/s.  The SURVEY 8d
+            # figure stays beside it as frac_algorithmic / achieved_algorithmic with its flag.
+            cl = out["roofline"].get("concurrent_launches", {})
+            if cl.get("frac_counter") is not None:
+                out["roofline"]["frac"] = cl["frac_counter"]
+                out["roofline"]["frac_basis"] = "counted HBM bytes per unit x units / union of the kernel's concurrent launches / 8 TB/s"
+            elif out["roofline"]["frac_counter"] is not None:
+                out["roofline"]["frac"] = out["roofline"]["frac_counter"]
+                out["roofline"]["frac_basis"] = "counted HBM bytes per unit x units per launch / average launch duration / 8 TB/s"
+            else:
+                out["roofline"]["frac_basis"] = "algorithmic bytes (no committed counter profile for this kernel)"
+            out["roofline"]["achieved_algorithmic"] = out["roofline"]["achieved"]
+            out["roofline"]["achieved"] = out["roofline"]["frac"] * HBM_PEAK / 1e9
         else:
             # this rank's share never reaches the streaming kernels' range (e.g. 312 pairs at N = 8 run in windows of <= 96 pairs
             # on the column-split kernels, which are not bracketed by events): only the whole-job figure is available

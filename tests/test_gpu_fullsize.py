@@ -389,7 +389,12 @@ def test_extra_workloads_plumbing():
     small = ["--steps", "1", "--warmup", "0", "--pop", "96", "--tslimit", "40", "--noise-count", "8000000", "--extra-small"]
     d1, _ = _bench([sys.executable, b, "--extra", "all"] + small, timeout=1400)
     ex = d1["extra"]
-    assert sorted(ex) == ["config1", "ga", "ga_large", "nses", "sweep"], ex
+    assert sorted(ex) == ["config1", "ga", "ga_large", "nses", "predicted_n2", "shares", "sweep"], ex
+    # an N = 2 launch rehearsed on this GPU (tools/workloads.py:simulate_ranks): the sharded generations end on the theta of the one-rank
+    # evaluation of the same pairs, and rank 0's share sits in the line beside the headline's own
+    pn = ex["predicted_n2"]
+    assert "error" not in pn and pn["theta_matches_one_rank_evaluation"] is True and pn["verified_generations"] == 1 and pn["pairs_per_rank"] == 24, pn
+    assert pn["value"] > 0 and len(pn["rank_eval_ms_mean"]) == 2 and sorted(ex["shares"]) == ["pairs_24", "pairs_48"], (pn, ex["shares"])
     for k in ("ga", "ga_large", "nses", "sweep"):
         assert "error" not in ex[k] and ex[k]["value"] > 0 and 0 < ex[k]["roofline"]["frac"] < 2, (k, ex[k])
     assert ex["ga"]["cpu_baseline"]["value"] > 0 and ex["config1"]["cores"] == 2 and ex["config1"]["value"] > 0

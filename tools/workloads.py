@@ -257,6 +257,81 @@ def six_games(noise, generations=1, warmup=1, pop=5000, tslimit=5000, games=None
             "roofline": whole_job_roofline(sps, "es", world)}
 
 
+# ------------------------------------------------------------------------------------------------ N ranks rehearsed on one GPU
+def simulate_ranks(noise, world, steps=20, warmup=5, pop=5000, tslimit=5000, nact=18, device_id=0, verify_generations=2, exp=None):
+    """An N-GPU run of the headline workload rehearsed on ONE GPU: per generation the N round-robin shards
+    (es.shard_pairs, the index stream of rank r = RandomState(generation * N + r) exactly as an N-rank launch draws it) are evaluated one
+    after the other on one engine sized for a rank's share, each through dne_records_pack; the records are put back into global pair order
+    exactly as the exchange's receive side does (es.allgather_records / dne_allgather_results) and every "rank" would then run the same
+    redundant update (dne_es_update_gathered, once here).  Per generation the N-GPU wall time is predicted as the SLOWEST shard's
+    evaluation + the update (the all-gather of N x 32-byte records over xGMI is tens of microseconds and is not on this box to measure):
+        value = sum of all shards' env-steps / sum over timed generations of (max over ranks of eval seconds + update seconds).
+    What the rehearsal PROVES is the data path: for the first `verify_generations` a second engine evaluates the union of the shards' pairs
+    as ONE rank (same indices and seeds, in global pair order) and the theta digests must agree -- sharding, packing, un-sharding and the
+    gathered update change nothing.  The one thing an N-GPU box adds is ncclCommInitRank + the collective itself.
+    Reference: gpu_implementation/neuroevolution/concurrent_worker.py:128-142 (one worker per device), es_distributed/es.py:377-439."""
+    import hashlib
+    from dne_hip import es
+    n_pairs = pop // 2
+    exp = exp or {"config": {"calc_obstat_prob": 0.0, "episodes_per_batch": pop, "eval_prob": 0.0, "l2coeff": 0.005, "noise_stdev": 0.02,
+                             "snapshot_freq": 0, "timesteps_per_batch": 10000, "return_proc_mode": "centered_rank", "episode_cutoff_mode": 5000},
+                  "optimizer": {"args": {"stepsize": 0.01}, "type": "adam"}}
+    config = es.Config(**exp["config"])
+    opt = exp["optimizer"]
+    share = len(es.shard_pairs(n_pairs, 0, world))
+    e = _es_engine(noise, nact, share, 0, 1, device_id, 0, 0, 0, None, None)           # a rank's engine: max_members = 2 x its share
+    v = _es_engine(noise, nact, n_pairs, 0, 1, device_id, 0, 0, 0, None, None) if verify_generations > 0 else None
+    P = e.P
+    sha = lambda eng: hashlib.sha256(eng.get_theta().tobytes()).hexdigest()
+    agree = []
+    per_gen = []
+    rank_ms = np.zeros(world)
+    steps_total = 0
+    t_pred = 0.0
+    for g in range(warmup + steps):
+        full = np.zeros(n_pairs, es.RECORD)
+        idx_all = np.zeros(n_pairs, np.int64); seeds_all = np.zeros(2 * n_pairs, np.uint32)
+        evals, gsteps = [], 0
+        for r in range(world):
+            mine, idx, seeds = es.generation_inputs(noise.noise.size, P, n_pairs, g, r, world)
+            t0 = time.time()
+            e.es_eval(idx, config.noise_stdev, tslimit, seeds)
+            rec = e.records_pack(len(mine))
+            evals.append(time.time() - t0)
+            full[mine] = rec[:len(mine)]
+            idx_all[mine] = idx; seeds_all[2 * mine] = seeds[0::2]; seeds_all[2 * mine + 1] = seeds[1::2]
+            gsteps += int(e.profile()["env_steps"])
+        t0 = time.time()
+        e.records_set(full)
+        e.es_update_gathered(config.return_proc_mode, opt["type"], config.l2coeff, *es.optimizer_args(opt))
+        e.barrier()          # hipDeviceSynchronize (no communicator here)
+        upd = time.time() - t0
+        if v is not None and g < verify_generations:
+            v.es_eval(idx_all, config.noise_stdev, tslimit, seeds_all)
+            v.records_set(v.records_pack(n_pairs))
+            v.es_update_gathered(config.return_proc_mode, opt["type"], config.l2coeff, *es.optimizer_args(opt))
+            agree.append(sha(e) == sha(v))
+        if g >= warmup:
+            steps_total += gsteps
+            t_pred += max(evals) + upd
+            rank_ms += 1e3 * np.asarray(evals)
+            per_gen.append(round(1e3 * (max(evals) + upd), 2))
+    digest = sha(e)
+    e.close()
+    if v is not None:
+        v.close()
+    if agree and not all(agree):
+        raise RuntimeError("simulate_ranks(%d): theta after the sharded generations differs from the one-rank evaluation of the same pairs: %s" % (world, agree))
+    return {"workload": "the headline workload as %d round-robin shards of %d pairs evaluated one after the other on one GPU" % (world, share),
+            "metric": "env-steps/sec/generation (predicted for %d GPUs)" % world, "value": steps_total / t_pred, "unit": "env-steps/s",
+            "n_gpus_simulated": world, "pairs_per_rank": share, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * t_pred / steps, "rank_eval_ms_mean": [round(x / steps, 2) for x in rank_ms],
+            "rank0_share_ms_per_generation": round(rank_ms[0] / steps, 2), "update_included": True, "exchange_included": False,
+            "theta_matches_one_rank_evaluation": (all(agree) if agree else None), "verified_generations": len(agree), "theta_sha256": digest,
+            "basis": "max over the simulated ranks of (evaluation + dne_records_pack) + one gathered update, per generation; the RCCL all-gather "
+                     "itself (N x 32-byte records) is not executed"}
+
+
 # ------------------------------------------------------------------------------------------------ CPU legs (oracle = checker)
 _BASE = None
 
@@ -281,28 +356,40 @@ def _cpu_ga_child(i):
     return int(r[2]), time.time() - t0, time.process_time() - c0
 
 
+def _pool_warm(_):
+    os.environ["OMP_NUM_THREADS"] = "1"
+    import oracle as O
+    O.lib()
+    time.sleep(0.02)    # long enough that the start-up tasks spread over all workers
+    return os.getpid()
+
+
 def _pool_rate(fn, n, procs):
     """n work items over `procs` forked single-threaded workers -> (env-steps, CPU seconds the workers consumed
-    [time.process_time inside each item: what the cores really delivered], wall seconds incl. start-up and stragglers)"""
+    [time.process_time inside each item: what the cores really delivered], wall seconds of the items alone: the pool is started and
+    every worker has loaded the oracle BEFORE the clock starts -- the reference's workers are long-lived processes (es.py:366), their
+    start-up is not part of a generation; stragglers at the end are)"""
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     O.lib()
-    t0 = time.time()
     with mp.get_context("fork").Pool(procs) as pool:
+        pool.map(_pool_warm, range(4 * procs), chunksize=1)
+        t0 = time.time()
         res = pool.map(fn, range(n), chunksize=1)
-    wall = time.time() - t0
+        wall = time.time() - t0
     return int(sum(r[0] for r in res)), float(sum(r[2] for r in res)), wall
 
 
 def _sweep_counts(procs):
-    """worker counts to try: the reference runs one worker per core it is given (launch.py:117), so which count is best is a
-    property of the host -- 2 (config 1), 16, 64, 128, 256, what the cgroup / affinity mask admits, and os.cpu_count()"""
+    """worker counts to try: the reference runs one worker per core it is given (launch.py:117) -- what the cgroup / affinity mask
+    admits -- and twice that (whether oversubscribing the granted CPUs pays is a property of the host)"""
     from hostinfo import usable_cpus
     if procs:
         return [int(procs)]
     top = os.cpu_count() or 1
-    return sorted({w for w in (2, 16, 64, 128, 256, usable_cpus(), top) if 1 <= w <= top})
+    u = max(1, min(usable_cpus(), top))
+    return sorted({w for w in (u, 2 * u) if 1 <= w <= max(top, u)})
 
 
 def _cpu_sweep(fn, counts, n_total, items_for):
@@ -328,12 +415,14 @@ def cpu_es(noise, theta, ref, sigma, tslimit, nact, n_pairs_total=2500, procs=No
     from hostinfo import host_facts
     _, idx, seeds = es.generation_inputs(noise.size, theta.size, n_pairs_total, generation, 0, 1)
     _BASE = (noise, theta, ref, sigma, tslimit, nact, idx, seeds)
-    items = (lambda w: sample_pairs) if sample_pairs else (lambda w: min(max(2 * w, 16), 256))
+    # >= 20 pairs per worker (about 5 s of wall at ~1.2 k env-steps per CPU-second and ~270 env-steps per pair), never fewer than 256
+    # pairs: round 5's 32-pair, 0.6-second sample moved by 24 % from box to box
+    items = (lambda w: sample_pairs) if sample_pairs else (lambda w: min(max(20 * w, 256), 640))
     rows, best = _cpu_sweep(_cpu_es_pair, _sweep_counts(procs), n_pairs_total, items)
     return {"value": best["rate_wall"], "unit": "env-steps/s", "cores": best["workers"], "kind": "port",
             "cpus_delivered": best["cpus_delivered"], "rate_per_cpu_second": best["rate_per_cpu_second"],
             "sample": "first %d antithetic pairs of generation %d (%d full episodes, %d env-steps) over %d single-threaded worker "
-                      "processes: %.1f s wall, %.1f CPU-seconds; value = env-steps / wall of the best worker count of the sweep"
+                      "processes started (oracle loaded) before the clock: %.1f s wall, %.1f CPU-seconds; value = env-steps / wall of the best worker count of the sweep"
                       % (best["items"], generation, 2 * best["items"], best["env_steps"], best["workers"], best["wall_s"], best["cpu_s"]),
             "sweep": rows, "host": host_facts()}
 
