@@ -844,6 +844,7 @@ static void pil_coeffs(int in_size, int out_size, int ksize, int *bounds, double
         int xmax = (int)(center + support + 0.5);
         if (xmax > in_size) xmax = in_size;
         xmax -= xmin;
+        if (xmax > ksize) { fprintf(stderr, "dne: a resize window of %d taps does not fit the table's %d\n", xmax, ksize); abort(); }
         double ww = 0.0;
         double *k = kk + xx * ksize;
         for (int x = 0; x < ksize; x++) k[x] = 0.0;
@@ -866,22 +867,22 @@ static const uint8_t kPalette[16][3] = {
     {92, 186, 92},   {74, 74, 74},    {252, 144, 144}, {0, 44, 160}};
 
 static void make_tables(ResizeLds *T) {
-    // Fixed 5 / 7 taps per output pixel: windows that would leave the frame are shifted back inside and their
-    // weights shifted with them, zero weights filling the rest (0 + x*0.0 and acc + x*0.0 are exact no-ops).
-    double kh[84 * 5], kv[84 * 7];
+    // Fixed RS_KH / RS_KV taps per output pixel (the widest window PIL builds for these two scales): windows that would leave the frame are
+    // shifted back inside and their weights shifted with them, zero weights filling the rest (0 + x*0.0 and acc + x*0.0 are exact no-ops).
+    double kh[84 * RS_KH], kv[84 * RS_KV];
     int bh[84 * 2], bv[84 * 2];
-    pil_coeffs(160, 84, 5, bh, kh);
-    pil_coeffs(210, 84, 7, bv, kv);
+    pil_coeffs(160, 84, RS_KH, bh, kh);
+    pil_coeffs(210, 84, RS_KV, bv, kv);
     memset(T, 0, sizeof(*T));
     for (int xx = 0; xx < 84; xx++) {
-        const int x0 = bh[2 * xx], d = x0 + 5 > 160 ? x0 + 5 - 160 : 0;
+        const int x0 = bh[2 * xx], d = x0 + RS_KH > 160 ? x0 + RS_KH - 160 : 0;
         T->xmin[xx] = (uint8_t)(x0 - d);
-        for (int t = 0; t < 5; t++) T->kh[xx * 5 + t] = t >= d ? kh[xx * 5 + t - d] : 0.0;
+        for (int t = 0; t < RS_KH; t++) T->kh[xx * RS_KH + t] = t >= d ? kh[xx * RS_KH + t - d] : 0.0;
     }
     for (int yy = 0; yy < 84; yy++) {
-        const int y0 = bv[2 * yy], d = y0 + 7 > 210 ? y0 + 7 - 210 : 0;
+        const int y0 = bv[2 * yy], d = y0 + RS_KV > 210 ? y0 + RS_KV - 210 : 0;
         T->ymin[yy] = (uint8_t)(y0 - d);
-        for (int t = 0; t < 7; t++) T->kv[yy * 7 + t] = t >= d ? kv[yy * 7 + t - d] : 0.0;
+        for (int t = 0; t < RS_KV; t++) T->kv[yy * RS_KV + t] = t >= d ? kv[yy * RS_KV + t - d] : 0.0;
     }
     for (int a = 0; a < 16; a++)
         for (int b = 0; b < 16; b++) {   // MaxAndSkip max (atari_wrappers.py:105) then WarpFrame gray (:139)

@@ -360,9 +360,14 @@ __device__ __forceinline__ int synth_row_pixel(int x, int bg, int p_off, int p_l
 // through the row -> slot map.  Identical rows give bit-identical results, so this is exact.
 constexpr int ENV_MAX_ROWS = 80;   // 45 classes + at most 3 extra keys for each of the <= 10 classes a sprite touches
 
-struct ResizeLds {      // PIL tables padded to a fixed tap count with zero weights (x + y*0.0 is exact)
-    double kh[84 * 5];
-    double kv[84 * 7];
+// PIL's BILINEAR windows for 160 -> 84 hold 3 or 4 source pixels and those for 210 -> 84 hold 4 or 5 (support = the scale, 1.905 / 2.5): the
+// tables carry exactly RS_KH / RS_KV taps per output pixel, shorter windows padded with zero weights (acc + x * 0.0 == acc for the finite,
+// non-negative x here: a padded tap is an exact no-op, so are the two / two always-zero taps rounds 1-5 carried at 5 / 7 per pixel and dropped in
+// round 6 -- same bits, 20 % / 29 % fewer f64 multiply-adds in the renderer, which is bound by its own VALU stream: profiles/r06_pmc_lockstep_kernels.json)
+constexpr int RS_KH = 4, RS_KV = 5;
+struct ResizeLds {
+    double kh[84 * RS_KH];
+    double kv[84 * RS_KV];
     uint8_t xmin[84];
     uint8_t ymin[84];
     float gray2[256];
@@ -372,7 +377,7 @@ struct EnvLds {
     ResizeLds R;
     uint8_t ram_prev[128];
     uint8_t ram_cur[128];
-    uint8_t slot_of_y[212];
+    uint16_t off_of_y[212];                 // screen row -> byte offset of its unique row in tmp (slot * 336), premultiplied: one add per tap
     int slot_of_key[192];
     int rep_y[ENV_MAX_ROWS];
     uint8_t img[ENV_MAX_ROWS * 160];        // colour pair (prev<<4 | cur) per pixel of each unique row
@@ -417,7 +422,7 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     // member's frame is split over several workgroups = several CUs).  It needs screen rows [ylo, yhi) only.
     const int tid = threadIdx.x, nthr = blockDim.x;   // 256 threads normally, 1024 when few members remain
     const int yy0 = band * 84 / nbands, yy1 = (band + 1) * 84 / nbands;
-    const int ylo = s.R.ymin[yy0], yhi = s.R.ymin[yy1 - 1] + 7;
+    const int ylo = s.R.ymin[yy0], yhi = s.R.ymin[yy1 - 1] + RS_KV;
     const int out0 = yy0 * 84, nout = (yy1 - yy0) * 84;
     constexpr int VP = 7;
     uint32_t old[VP] = {};
@@ -445,7 +450,7 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
         }
     }
     __syncthreads();
-    if (myrow) s.slot_of_y[tid] = (uint8_t)s.slot_of_key[key];
+    if (myrow) s.off_of_y[tid] = (uint16_t)(s.slot_of_key[key] * (84 * 4));
     const int nu = min(s.misc[2], ENV_MAX_ROWS);
     // one wave per unique row: the row number and the RAM-derived state are wave-uniform, so each row of each frame is
     // first reduced (on the scalar unit) to a background colour + one periodic pattern + one span + the player sprite,
@@ -468,10 +473,10 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     for (int i = tid; i < nu * 84; i += nthr) {   // horizontal pass over the unique rows
         const int u = i / 84, xx = i % 84;
         const uint8_t *px = s.img + u * 160 + s.R.xmin[xx];
-        const double *k = s.R.kh + xx * 5;
+        const double *k = s.R.kh + xx * RS_KH;
         double acc = 0.0;
 #pragma unroll
-        for (int t = 0; t < 5; t++) acc = acc + (double)s.R.gray2[px[t]] * k[t];
+        for (int t = 0; t < RS_KH; t++) acc = acc + (double)s.R.gray2[px[t]] * k[t];
         s.tmp[i] = (float)acc;
     }
     __syncthreads();
@@ -492,11 +497,12 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
             const int i = base + tid + j * nthr;
             if (i < nout) {
                 const int yy = yy0 + i / 84, xx = i % 84;
-                const uint8_t *sl = s.slot_of_y + s.R.ymin[yy];
-                const double *k = s.R.kv + yy * 7;
+                const uint16_t *sl = s.off_of_y + s.R.ymin[yy];
+                const double *k = s.R.kv + yy * RS_KV;
+                const char *col = (const char *)(s.tmp + xx);
                 double acc = 0.0;
 #pragma unroll
-                for (int t = 0; t < 7; t++) acc = acc + (double)s.tmp[sl[t] * 84 + xx] * k[t];
+                for (int t = 0; t < RS_KV; t++) acc = acc + (double)*(const float *)(col + sl[t]) * k[t];
                 const uint32_t pix = (uint32_t)(uint8_t)(float)acc;
                 stack[out0 + i] = fill ? pix * 0x01010101u : ((old[j] >> 8) | (pix << 24));
             }

@@ -258,7 +258,7 @@ def six_games(noise, generations=1, warmup=1, pop=5000, tslimit=5000, games=None
 
 
 # ------------------------------------------------------------------------------------------------ N ranks rehearsed on one GPU
-def simulate_ranks(noise, world, steps=20, warmup=5, pop=5000, tslimit=5000, nact=18, device_id=0, verify_generations=2, exp=None):
+def simulate_ranks(noise, world, steps=20, warmup=5, pop=5000, tslimit=5000, nact=18, device_id=0, verify_generations=2, exp=None, shard=None):
     """An N-GPU run of the headline workload rehearsed on ONE GPU: per generation the N round-robin shards
     (es.shard_pairs, the index stream of rank r = RandomState(generation * N + r) exactly as an N-rank launch draws it) are evaluated one
     after the other on one engine sized for a rank's share, each through dne_records_pack; the records are put back into global pair order
@@ -293,7 +293,7 @@ def simulate_ranks(noise, world, steps=20, warmup=5, pop=5000, tslimit=5000, nac
         idx_all = np.zeros(n_pairs, np.int64); seeds_all = np.zeros(2 * n_pairs, np.uint32)
         evals, gsteps = [], 0
         for r in range(world):
-            mine, idx, seeds = es.generation_inputs(noise.noise.size, P, n_pairs, g, r, world)
+            mine, idx, seeds = es.generation_inputs(noise.noise.size, P, n_pairs, g, r, world, shard=shard)
             t0 = time.time()
             e.es_eval(idx, config.noise_stdev, tslimit, seeds)
             rec = e.records_pack(len(mine))
@@ -324,7 +324,7 @@ def simulate_ranks(noise, world, steps=20, warmup=5, pop=5000, tslimit=5000, nac
         raise RuntimeError("simulate_ranks(%d): theta after the sharded generations differs from the one-rank evaluation of the same pairs: %s" % (world, agree))
     return {"workload": "the headline workload as %d round-robin shards of %d pairs evaluated one after the other on one GPU" % (world, share),
             "metric": "env-steps/sec/generation (predicted for %d GPUs)" % world, "value": steps_total / t_pred, "unit": "env-steps/s",
-            "n_gpus_simulated": world, "pairs_per_rank": share, "steps": steps, "warmup": warmup,
+            "n_gpus_simulated": world, "pairs_per_rank": share, "shard": shard or es.shard_mode(), "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * t_pred / steps, "rank_eval_ms_mean": [round(x / steps, 2) for x in rank_ms],
             "rank0_share_ms_per_generation": round(rank_ms[0] / steps, 2), "update_included": True, "exchange_included": False,
             "theta_matches_one_rank_evaluation": (all(agree) if agree else None), "verified_generations": len(agree), "theta_sha256": digest,
