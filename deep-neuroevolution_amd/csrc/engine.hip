@@ -586,6 +586,10 @@ struct dne_handle {
     int duo_rounds = 1;              // DNE_DUO_ROUNDS: duos per wave and work item of the sweep (1-4)
     int duo_sync = 1;                // DNE_DUO_SYNC: row blocks per barrier of the sweep (1-8)
     int burst = 32, burst_tail = 16; // DNE_BURST / DNE_BURST_TAIL: lock-steps between two compactions of the active list (a host round trip each), at large / with at most fc_tail_max groups alive (round 4: 32 at large, 16 before; 24 / 32 / 48 measured -0.5 .. -0.9 %, 8 +2.3 %, 64 +0.2 %; the tail indifferent)
+    double dense_scale = 1.0;        // table length / the stretch of the table this evaluation's noise slices cover (dne_es_eval; 1 for every other caller): a rank that draws
+                                     // its indices from its own 1/N of the table (es.py shard 'table') holds pairs as dense as N times as many over the whole table
+    int ring_min = 1000;             // DNE_RING_MIN: k_fc_ring needs this many active pairs on the rank whatever their density (below, its workgroups -- eight units, one per CU --
+                                     // no longer fill the chip: a 625-pair share measured 61.6 ms per generation on the ring against 57.8 on k_fc_duo, profiles/r06_shard_ab.jsonl)
     int list_sort = 0;               // DNE_LIST_SORT: an ES evaluation's active list starts in noise-table order (eval_core)
     std::vector<int> host_list;
     int ring_on = 1;                 // DNE_FC_RING (round 5): k_fc_ring instead of k_fc_duo -- the workgroup's noise rows through an LDS ring filled by LDS-DMA, the base rows from a column-permuted copy of the fc matrix; 1: from DNE_DUO_SOLO_BELOW active pairs (1500) upwards, 2: in the whole k_fc_duo range (measured slower in the sparse part: 239 vs 233 ms), 0: k_fc_duo everywhere
@@ -1020,7 +1024,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_DUO_SWEEP", 0, 2, &h->duo_sweep);
     env_int("DNE_DUO_SYNC", 1, 8, &h->duo_sync);
     env_int("DNE_DUO_ROUNDS", 1, 4, &h->duo_rounds);
-    env_int("DNE_DUO_FAT", 0, 1, &h->duo_fat); env_int("DNE_FC_RING", 0, 2, &h->ring_on); env_int("DNE_LIST_SORT", 0, 1, &h->list_sort);
+    env_int("DNE_DUO_FAT", 0, 1, &h->duo_fat); env_int("DNE_FC_RING", 0, 2, &h->ring_on); env_int("DNE_LIST_SORT", 0, 1, &h->list_sort); env_int("DNE_RING_MIN", 0, 1 << 30, &h->ring_min);
     env_int("DNE_BURST", 1, 256, &h->burst);
     env_int("DNE_BURST_TAIL", 1, 256, &h->burst_tail);
     env_int("DNE_DUO_W", 4, 8, &h->duo_w);
@@ -1450,6 +1454,7 @@ extern "C" int dne_set_members(dne_handle *h, int n, const int32_t *slot, const 
     HCHECK(h, hipStreamSynchronize(h->stream));
     h->uniform_base = true;
     for (int i = 0; i < n; i++) h->uniform_base = h->uniform_base && slot[i] == slot[0];
+    h->dense_scale = 1.0;
     h->antithetic_slot0 = h->uniform_base && slot[0] == 0 && n % 2 == 0;
     for (int i = 0; i + 1 < n && h->antithetic_slot0; i += 2)
         h->antithetic_slot0 = off[i] == off[i + 1] && scale[i] == -scale[i + 1];
@@ -1891,8 +1896,11 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     const bool duo_eval = !h->large && h->fc_duo && (h->L.kind == DNE_KIND_ES ? gsize == 2 : (gsize == 1 && h->fc_duo_ga)) && groups >= h->fc_duo_min;
     // an evaluation that starts wide enough for k_fc_ring: its bracketed ("full") launches are that kernel's only -- one kernel per
     // roofline line; the k_fc_duo launches of its thinner lock-steps (DNE_FC_DUO_MIN .. DNE_DUO_SOLO_BELOW pairs) are not bracketed
+    // the ring's range: pairs as dense in their stretch of the table as DNE_DUO_SOLO_BELOW (1500) pairs over the whole table, and enough of them to
+    // fill the chip (DNE_RING_MIN) -- at one GPU "1500 of 2500 active", on a rank of two with its own half of the table "1000 of 1250"
+    auto ring_dense = [&](int t) { return (double)t * h->dense_scale >= (double)h->duo_solo_below && t >= h->ring_min; };
     const bool ring_eval = duo_eval && h->L.kind == DNE_KIND_ES && gsize == 2 && h->theta_perm && h->antithetic_slot0 && h->duo_sweep &&
-                           (h->ring_on > 1 || groups >= h->duo_solo_below) && (groups >= h->duo_solo_below || h->duo_sweep > 1);
+                           (h->ring_on > 1 || ring_dense(groups)) && (ring_dense(groups) || h->duo_sweep > 1);
     while (total > 0 && t < tslimit) {
         const int burst = std::min(total <= h->fc_tail_max ? h->burst_tail : h->burst, tslimit - t);   // lock-steps until the next compaction
         const int nsub = pick_nsub(total);
@@ -1903,7 +1911,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
         h->sub_now = sub_regime(total);
         if (h->sub_now) h->duo_now = h->fc2_now = false;
         h->ring_now = h->duo_now && h->L.kind == DNE_KIND_ES && gsize == 2 && h->theta_perm && h->antithetic_slot0 &&
-                      h->duo_sweep && (!h->duo_solo_now || h->duo_sweep > 1) && (h->ring_on > 1 || !h->duo_solo_now);
+                      h->duo_sweep && (ring_dense(total) || h->duo_sweep > 1) && (h->ring_on > 1 || ring_dense(total));
         if (h->duo_now)   // the list only changes at a compaction: rank each window's units by table address once per burst
             for (int s = 0; s < nsub; s++) {
                 const int lo = (int)((long long)total * s / nsub), cnt = (int)((long long)total * (s + 1) / nsub) - lo;
@@ -2087,6 +2095,12 @@ extern "C" int dne_es_eval(dne_handle *h, const int64_t *idx, int n, float sigma
         sc[2 * i + 1] = -sigma;   // es.py:419 params - v
     }
     if (dne_set_members(h, 2 * n, slot.data(), off.data(), sc.data())) return -1;
+    {   // how dense the pairs lie in the stretch of the table they cover (round 6: ranks that draw from their own stretch)
+        int64_t lo = idx[0], hi = idx[0];
+        for (int i = 1; i < n; i++) { lo = std::min(lo, idx[i]); hi = std::max(hi, idx[i]); }
+        const double span = (double)(hi - lo) + (double)h->L.P;
+        h->dense_scale = std::min(16.0, std::max(1.0, (double)h->noise_count / std::max(span, 1.0)));
+    }
     return eval_core(h, 2 * n, 2, tslimit, env_seed, returns_n2, signreturns_n2, lengths_n2, bc);
 }
 

@@ -91,37 +91,41 @@ def shard_pairs(n_pairs, rank, world):
 
 
 def shard_mode():
-    """How the ranks of a launch draw their noise indices (DNE_SHARD): 'table' = every rank draws from ITS OWN
-    1/world stretch of the table, 'uniform' (default) = every rank draws from the whole table like an es_distributed worker (es.py:412)."""
-    m = os.environ.get("DNE_SHARD", "uniform")
+    """How the ranks of a multi-GPU launch draw their noise indices (DNE_SHARD): 'table' (default) = every rank draws from ITS OWN
+    1/world stretch of the table; 'uniform' = every rank draws from the whole table like an es_distributed worker (es.py:412).
+    One rank: the two are the same thing."""
+    m = os.environ.get("DNE_SHARD", "table")
     if m not in ("table", "uniform"):
         raise ValueError("DNE_SHARD must be 'table' or 'uniform', not %r" % m)
     return m
+
+
+def index_range(noise_len, num_params, rank, world, shard=None):
+    """[lo, hi) of the legal slice starts rank `rank` draws from"""
+    hi = noise_len - num_params + 1
+    if world > 1 and (shard or shard_mode()) == "table":
+        return hi * rank // world, hi * (rank + 1) // world
+    return 0, hi
 
 
 def generation_inputs(noise_len, num_params, n_pairs, generation, rank, world, shard=None):
     """Seeded stand-ins for the reference's unseeded streams: the worker's index stream is
     RandomState(generation*world + rank) (es.py:372,412), per-episode env seeds are RandomState(1000 +
     generation) u32 draws indexed by global pair id.
-    shard (world > 1 only; default shard_mode()): 'uniform' -- every rank draws over the whole table, as a reference worker does;
-    'table' -- rank r draws over [r, r+1) / world of the legal start positions.  Each draw is still uniform over its stretch and the
-    stretches tile the table, so the population is a stratified sample of the same uniform distribution; what it buys on MI355X: a
-    rank's pairs are as DENSE in its stretch as the whole population is in the whole table (2500 pairs over 250 M floats = every row
-    under ~10 slices), so the table-ordered streaming kernel shares rows on a rank's share exactly as it does at one GPU, instead of
-    streaming 4 MB per pair and step from HBM."""
+    shard (matters for world > 1 only; default shard_mode()): 'uniform' -- every rank draws over the whole table, as a reference worker
+    does; 'table' -- rank r draws over the r-th of `world` equal stretches of the legal start positions.  Each draw is uniform over
+    its stretch and the stretches tile the table, so the population is a stratified sample of the same uniform distribution (every
+    slice of the table is as likely as before, the update es.py:274-301 builds from the records is indifferent to who drew what).
+    What it buys on MI355X: a rank's pairs lie as DENSE in its stretch as the whole population does in the whole table (2500 pairs
+    over 250 M floats: every table row under ~10 slices), so the table-ordered streaming kernels and the caches share rows on a rank's
+    share as they do at one GPU instead of pulling 4 MB per pair and step from HBM -- measured on one GPU, a rank of 2 / 4 / 8:
+    126.3 / 57.9 / 38.3 ms per generation against 135.7 / 74.3 / 49.3 (profiles/r06_shard_ab.jsonl)."""
     mine = shard_pairs(n_pairs, rank, world)
     rs = np.random.RandomState(generation * world + rank)
-    hi = noise_len - num_params + 1
-    if world > 1 and (shard or shard_mode()) == "table":
-        lo_r, hi_r = hi * rank // world, hi * (rank + 1) // world
-        idx = rs.randint(lo_r, hi_r, size=len(mine)).astype(np.int64)
-        idx.sort()
-        all_seeds = np.random.RandomState(1000 + generation).randint(0, 2 ** 32, size=2 * n_pairs, dtype=np.uint64).astype(np.uint32)
-        seeds = np.stack([all_seeds[2 * mine], all_seeds[2 * mine + 1]], axis=1).reshape(-1)
-        return mine, idx, seeds
+    lo, hi = index_range(noise_len, num_params, rank, world, shard)
     # one vectorised draw = the same values, in the same order, as len(mine) successive SharedNoiseTable.sample_index calls
     # (legacy RandomState.randint with fixed bounds; pinned by tests/test_host_cpu.py)
-    idx = rs.randint(0, hi, size=len(mine)).astype(np.int64)
+    idx = rs.randint(lo, hi, size=len(mine)).astype(np.int64)
     # ascending table order: which of a worker's draws is "pair k" is a label (the reference's master takes results in arrival
     # order, es.py:246-260), and neighbours in the list then read neighbouring -- largely the same -- rows of the noise table,
     # which the table-ordered fc kernel (k_fc_duo) and the Infinity Cache turn into fewer HBM bytes

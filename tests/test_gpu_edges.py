@@ -175,11 +175,11 @@ _ES_STEP_KNOBS = [
     {"DNE_FC_SUB": "2", "DNE_FC_SUB_MIN": "2", "DNE_FC_SUB_SPW": "8"},   # ... a whole quarter per wave
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_FAT": "1"},   # ... the form that the hardware places once per CU (register footprint past 256), two units per wave
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_FAT": "1", "DNE_NSUB": "2"},   # ... one unit per wave, two windows
-    {"DNE_FC_RING": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0"},   # k_fc_ring (round 5): the workgroup's noise rows through an LDS ring (LDS-DMA), base rows from the column-permuted copy; two units per wave
+    {"DNE_FC_RING": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_RING_MIN": "0"},   # k_fc_ring (round 5) through its DEFAULT gate (dense enough, enough pairs): the workgroup's noise rows through an LDS ring (LDS-DMA), base rows from the column-permuted copy; one unit per wave, eight per workgroup
     {"DNE_FC_RING": "2", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1"},   # ... in the sparse regime too (k_y2_activate behind the tail's convolution kernels)
     {"DNE_FC_RING": "2", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_CONV_FUSED_MIN": "1"},   # ... behind k_conv12, which leaves relu(bn2(y2)) itself
     {"DNE_FC_RING": "2", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_CONV_FUSED": "0", "DNE_CONV12T_MAX": "0"},   # ... behind k_conv1 + k_conv2
-    {"DNE_FC_RING": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_NSUB": "2", "DNE_DUO_FAT": "0"},   # ... two windows, two workgroups per CU
+    {"DNE_FC_RING": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_RING_MIN": "0", "DNE_NSUB": "2"},   # ... two windows, each with its own unit order
     {"DNE_BURST": "5", "DNE_BURST_TAIL": "40"},                         # compaction of the active list every 5 / 40 lock-steps instead of 16
     {"DNE_FC_DUO": "0", "DNE_FC2_MIN": "2", "DNE_FC_TAIL_MAX": "1"},    # the duo path switched off: k_fc2
     {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1"},                      # k_fc<2> streaming kernel

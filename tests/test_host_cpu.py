@@ -91,6 +91,17 @@ def test_noise_table_and_sharding(small_noise, golden):
     both = np.zeros(20, np.uint32); both[np.repeat(2 * m0, 2) + np.tile([0, 1], 5)] = s0; both[np.repeat(2 * m1, 2) + np.tile([0, 1], 5)] = s1
     assert np.array_equal(both, sa)                            # env seeds depend on the global pair id only
     assert es.RECORD.itemsize == 32
+    # world > 1: 'table' (default) = rank r draws inside the r-th of `world` stretches of the legal starts, 'uniform' = the whole table as a
+    # reference worker does (es.py:412); one rank: the same draw either way, and the legacy stream's values
+    hi = 4_000_000 - 1009058 + 1
+    assert es.shard_mode() == "table" and i0.max() < hi // 2 <= i1.min() and i1.max() < hi
+    for w in (2, 3, 8):
+        edges = [es.index_range(4_000_000, 1009058, r, w) for r in range(w)]
+        assert edges[0][0] == 0 and edges[-1][1] == hi and all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+    _, iu, su = es.generation_inputs(4_000_000, 1009058, 10, 3, 1, 2, shard="uniform")
+    assert iu.tolist() == sorted(np.random.RandomState(3 * 2 + 1).randint(0, hi, size=5).tolist()) and np.array_equal(su, s1)
+    assert np.array_equal(es.generation_inputs(4_000_000, 1009058, 10, 3, 0, 1, shard="uniform")[1], ia)
+    assert es.index_range(4_000_000, 1009058, 0, 1, "table") == (0, hi) == es.index_range(4_000_000, 1009058, 1, 2, "uniform")
     # the index draw of generation_inputs = successive sample_index calls on the same stream (es.py:412), in ascending order
     rs2 = np.random.RandomState(3 * 1 + 0)
     t4 = es.SharedNoiseTable(count=100_000, seed=123)

@@ -66,7 +66,9 @@ def test_cpu_legs_time_the_oracle_like_reference_workers(W, oracle):
     from dne_hip import policies
     th, ref = policies.xavier_flat(18, 0), oracle.get_ref_batch(seed=0, batch_size=4)
     s = W.cpu_es(noise, th, ref, 0.02, 6, 18, n_pairs_total=8, sample_pairs=2)
-    assert len(s["sweep"]) >= 2 and s["sweep"][0]["workers"] == 2 and all(r["cpu_s"] > 0 and r["wall_s"] > 0 for r in s["sweep"])
+    import hostinfo
+    u = min(hostinfo.usable_cpus(), os.cpu_count())     # one worker per granted CPU (launch.py:117), and twice that
+    assert [r["workers"] for r in s["sweep"]] == [u, 2 * u] and all(r["cpu_s"] > 0 and r["wall_s"] > 0 for r in s["sweep"])
     assert s["value"] == max(r["rate_wall"] for r in s["sweep"]) and s["cores"] in [r["workers"] for r in s["sweep"]]
     h = s["host"]
     assert h["usable_cpus"] <= h["os_cpu_count"] and h["sched_getaffinity"] >= 1 and "cgroup_cpu_max" in h and h["model"]

@@ -356,7 +356,7 @@ def _cpu_ga_child(i):
     return int(r[2]), time.time() - t0, time.process_time() - c0
 
 
-def _pool_warm(_):
+def _cpu_pool_warm(_):
     os.environ["OMP_NUM_THREADS"] = "1"
     import oracle as O
     O.lib()
@@ -374,7 +374,7 @@ def _pool_rate(fn, n, procs):
     import oracle as O
     O.lib()
     with mp.get_context("fork").Pool(procs) as pool:
-        pool.map(_pool_warm, range(4 * procs), chunksize=1)
+        pool.map(_cpu_pool_warm, range(4 * procs), chunksize=1)
         t0 = time.time()
         res = pool.map(fn, range(n), chunksize=1)
         wall = time.time() - t0
@@ -387,9 +387,8 @@ def _sweep_counts(procs):
     from hostinfo import usable_cpus
     if procs:
         return [int(procs)]
-    top = os.cpu_count() or 1
-    u = max(1, min(usable_cpus(), top))
-    return sorted({w for w in (u, 2 * u) if 1 <= w <= max(top, u)})
+    u = max(1, min(usable_cpus(), os.cpu_count() or 1))
+    return [u, 2 * u]
 
 
 def _cpu_sweep(fn, counts, n_total, items_for):
