@@ -581,21 +581,16 @@ struct dne_handle {
                                      // weights and ran best at two workgroups per CU = 64 KB; round 3's stages nothing)
     int duo_head_fused = 0;          // DNE_DUO_HEAD_FUSED: behind k_fc_duo the policy head and the emulator step share a launch (k_tail_step) instead of
                                      // k_out + k_env_logic; same-box A/B: 402.7 ms fused, 403.3 separate, 399.8 separate with k_out at two workgroups per CU -> off
-    int fc_duo_ga = 0;               // DNE_FC_DUO_GA: the table-ordered fc for GA evaluations too (single members, one base vector per parent); measured slower, off
     int conv2_ref_fpw = 8;           // DNE_CONV2_REF_FPW: reference frames per conv2 workgroup (8, 4, or 1 = the lock-step kernel)
-    int duo_rounds = 1;              // DNE_DUO_ROUNDS: duos per wave and work item of the sweep (1-4)
     int duo_sync = 1;                // DNE_DUO_SYNC: row blocks per barrier of the sweep (1-8)
     int burst = 32, burst_tail = 16; // DNE_BURST / DNE_BURST_TAIL: lock-steps between two compactions of the active list (a host round trip each), at large / with at most fc_tail_max groups alive (round 4: 32 at large, 16 before; 24 / 32 / 48 measured -0.5 .. -0.9 %, 8 +2.3 %, 64 +0.2 %; the tail indifferent)
     double dense_scale = 1.0;        // table length / the stretch of the table this evaluation's noise slices cover (dne_es_eval; 1 for every other caller): a rank that draws
                                      // its indices from its own 1/N of the table (es.py shard 'table') holds pairs as dense as N times as many over the whole table
     int ring_min = 1000;             // DNE_RING_MIN: k_fc_ring needs this many active pairs on the rank whatever their density (below, its workgroups -- eight units, one per CU --
                                      // no longer fill the chip: a 625-pair share measured 61.6 ms per generation on the ring against 57.8 on k_fc_duo, profiles/r06_shard_ab.jsonl)
-    int list_sort = 0;               // DNE_LIST_SORT: an ES evaluation's active list starts in noise-table order (eval_core)
-    std::vector<int> host_list;
     int ring_on = 1;                 // DNE_FC_RING (round 5): k_fc_ring instead of k_fc_duo -- the workgroup's noise rows through an LDS ring filled by LDS-DMA, the base rows from a column-permuted copy of the fc matrix; 1: from DNE_DUO_SOLO_BELOW active pairs (1500) upwards, 2: in the whole k_fc_duo range (measured slower in the sparse part: 239 vs 233 ms), 0: k_fc_duo everywhere
     float *theta_perm = nullptr;     // [3872 + 16][256]: base slot 0's fc matrix, every row stored as columns l, l+64, l+128, l+192 per lane (k_theta_perm, once per evaluation)
     int duo_fat = 1;                 // DNE_DUO_FAT: k_fc_duo with a register footprint past 256 per lane = at most one of its workgroups per CU (it streams as fast from one), so the other windows' kernels always find room beside it
-    int duo_w = 8;                   // DNE_DUO_W: rows in flight per stream of k_fc_duo (8: two waves per SIMD; 4: four)
     int fc_sub = 1;                  // DNE_FC_SUB (ES 2, GA 1): the sub-slice fc (k_fc_sub: one wave per 128 / 120-row chain) in the mid range -- 0 off, 1 GA children (materialised), 2 also ES pairs
     int fc_sub_min = 97, fc_sub_max = 320;   // DNE_FC_SUB_MIN / _MAX: active groups (all windows) between which it runs (max: 450 for ES pairs, 320 for GA children)
     int fc_sub_nsub = 2;             // DNE_FC_SUB_NSUB: windows of that regime (ES 3, GA 2)
@@ -605,7 +600,7 @@ struct dne_handle {
     int fc_sub_head = 1;             // DNE_FC_SUB_HEAD: policy head + emulator step in one launch (k_tail_step) behind k_fc_sub instead of k_out + k_env_logic
     bool sub_now = false;            // decided per burst by eval_core
     float *y3s = nullptr;            // [member][32][256]: the chain sums k_fc_sub leaves for k_out<.., SUB>
-    int duo_grid = 0;                // DNE_DUO_GRID: persistent grid of k_fc_duo (0 = fc_grid, doubled for DNE_DUO_W=4)
+    int duo_grid = 0;                // DNE_DUO_GRID: persistent grid of k_fc_duo (0 = fc_grid)
     int duo_sweep = 2;               // DNE_DUO_SWEEP (0 = off): the four waves of a k_fc_duo workgroup walk one table timeline (1: two units per wave only, 2: also one unit per wave)
     int fc_prio = 3;                 // DNE_FC_PRIO: s_setprio of k_fc_duo's waves (0-3)
     int duo_lag = 0;                 // DNE_DUO_LAG: extra row batches by which the second unit of a duo trails the first
@@ -662,11 +657,6 @@ struct dne_handle {
     float *y1r[2] = {nullptr, nullptr}, *y2r[2] = {nullptr, nullptr}, *y3pr[2] = {nullptr, nullptr};   // reference pass scratch, two ways
     float *fr1[2] = {nullptr, nullptr}, *fr2[2] = {nullptr, nullptr};   // per-frame batch-norm moments of conv1 / conv2 ([rows][2][C])
     hipEvent_t ev_ref[2] = {nullptr, nullptr};
-    int ref_overlap = 0;             // DNE_REF_OVERLAP (round 5): the reference pass runs chunk by chunk on two streams of its own and a window starts its lock-steps as soon as the chunks of ITS members are through (policies.py:399: the pass still precedes that member's first step); measured slower (238.6 vs 233.5 ms per generation), off
-    int ref_prio = 1;                // DNE_REF_PRIO: 1 = the reference pass's own streams at the lowest priority (the windows' short kernels go first)
-    hipStream_t ref_streams[2] = {nullptr, nullptr};
-    std::vector<hipEvent_t> ev_chunk;   // recorded behind the last kernel of reference chunk c
-    int ref_chunks_async = 0;        // chunks of the pass that is in flight beside the first burst (0: the pass has been joined)
     int *list_a = nullptr, *list_b = nullptr, *count_dev = nullptr;
     int *count_host = nullptr;       // pinned: the active count comes back once per burst (a pageable destination makes the copy a staged, synchronous one)
     uint8_t *bc = nullptr; size_t bc_bytes = 0;
@@ -990,7 +980,6 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     CH(hipFuncSetAttribute((const void *)k_out<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     env_int("DNE_NSUB", 1, 4, &h->nsub_fixed);
     env_int("DNE_NSUB_FULL", 1, 4, &h->nsub_full);
-    env_int("DNE_REF_OVERLAP", 0, 1, &h->ref_overlap); env_int("DNE_REF_PRIO", 0, 1, &h->ref_prio);
     env_int("DNE_NSUB_MID", 1, 4, &h->nsub_mid);
     env_int("DNE_FC_TAIL_MAX", 1, 1 << 20, &h->fc_tail_max);
     env_int("DNE_FC_QUAD_MAX", 0, 1 << 20, &h->fc_quad_max);
@@ -1023,12 +1012,9 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_PRIO", 0, 3, &h->fc_prio);
     env_int("DNE_DUO_SWEEP", 0, 2, &h->duo_sweep);
     env_int("DNE_DUO_SYNC", 1, 8, &h->duo_sync);
-    env_int("DNE_DUO_ROUNDS", 1, 4, &h->duo_rounds);
-    env_int("DNE_DUO_FAT", 0, 1, &h->duo_fat); env_int("DNE_FC_RING", 0, 2, &h->ring_on); env_int("DNE_LIST_SORT", 0, 1, &h->list_sort); env_int("DNE_RING_MIN", 0, 1 << 30, &h->ring_min);
+    env_int("DNE_DUO_FAT", 0, 1, &h->duo_fat); env_int("DNE_FC_RING", 0, 2, &h->ring_on); env_int("DNE_RING_MIN", 0, 1 << 30, &h->ring_min);
     env_int("DNE_BURST", 1, 256, &h->burst);
     env_int("DNE_BURST_TAIL", 1, 256, &h->burst_tail);
-    env_int("DNE_DUO_W", 4, 8, &h->duo_w);
-    if (h->duo_w != 4) h->duo_w = 8;
     env_int("DNE_DUO_GRID", 0, 1 << 16, &h->duo_grid);
     // measured (tools/ga_lockstep_profile.py, tools/ab_inproc.py --pairs 312 / 625): Deep-GA children 97 .. 320
     // alive, two windows, a grid of 512 workgroups at wave priority 3; ES pairs 97 .. 450 alive, three windows, the whole launch
@@ -1048,7 +1034,6 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_DUO_SOLO_BELOW", 0, 1 << 30, &h->duo_solo_below);
     env_int("DNE_DUO_HEAD_FUSED", 0, 1, &h->duo_head_fused);
     env_int("DNE_OUT_LDS_KB", 0, 64, &h->out_lds_kb);
-    env_int("DNE_FC_DUO_GA", 0, 1, &h->fc_duo_ga);
     env_int("DNE_FC_DUO_MIN", 2, 1 << 30, &h->fc_duo_min);
     env_int("DNE_RENDER_BANDS", 1, 84, &h->render_bands);
     env_int("DNE_RENDER_WG_MAX", 1, 1 << 20, &h->render_wg_max);
@@ -1117,9 +1102,6 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
             CH(h->alloc(&h->y1r[w], rr * 7056, "y1r[w]")); CH(h->alloc(&h->y2r[w], rr * Y2_PAD_ROW, "y2r[w]")); CH(h->alloc(&h->y3pr[w], rr * 4 * 256, "y3pr[w]"));
             CH(h->alloc(&h->fr1[w], rr * 2 * 16, "fr1[w]")); CH(h->alloc(&h->fr2[w], rr * 2 * 32, "fr2[w]"));
             CH(hipEventCreateWithFlags(&h->ev_ref[w], hipEventDisableTiming));
-            int lo = 0, hi = 0;
-            CH(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = the numerically largest = least urgent
-            CH(hipStreamCreateWithPriority(&h->ref_streams[w], hipStreamNonBlocking, h->ref_prio ? lo : 0));
         }
     }
     CH(h->alloc(&h->list_a, M, "list_a")); CH(h->alloc(&h->list_b, M, "list_b")); CH(h->alloc(&h->count_dev, 8 + TT_MAX, "count_dev"));
@@ -1191,8 +1173,6 @@ extern "C" void dne_destroy(dne_handle *h) {
     if (h->count_host) hipHostFree(h->count_host);
     for (hipEvent_t e : h->fc_ring) hipEventDestroy(e);
     for (hipEvent_t e : h->ev_ref) if (e) hipEventDestroy(e);
-    for (hipEvent_t e : h->ev_chunk) hipEventDestroy(e);
-    for (hipStream_t st : h->ref_streams) if (st) hipStreamDestroy(st);
     if (h->ev_a) hipEventDestroy(h->ev_a);
     if (h->ev_b) hipEventDestroy(h->ev_b);
     for (size_t s = 1; s < h->sub_streams.size(); s++) hipStreamDestroy(h->sub_streams[s]);
@@ -1464,8 +1444,7 @@ extern "C" int dne_set_members(dne_handle *h, int n, const int32_t *slot, const 
 }
 
 // policies.py:399: the reference batch through every member's perturbed network -> per-member BN scale/shift
-static int ref_pass(dne_handle *h, int n, bool async = false /* eval_core: leave the chunks in flight, ev_chunk[c] behind each */) {
-    h->ref_chunks_async = 0;
+static int ref_pass(dne_handle *h, int n) {
     if (h->L.kind != DNE_KIND_ES) return 0;
     if (!h->ref_set) return h->fail("reference batch not set (dne_set_ref_batch)");
     const int F = h->F;
@@ -1473,16 +1452,14 @@ static int ref_pass(dne_handle *h, int n, bool async = false /* eval_core: leave
     // chunks alternate between two streams with their own scratch: the statistics kernels (one workgroup per
     // member, latency-bound) of one chunk run under the MFMA convolutions of the next
     const int nways = n > h->ref_chunk ? 2 : 1;
-    async = async && nways > 1;
     if (nways > 1) {
         HCHECK(h, hipEventRecord(h->ev_ref[0], h->stream));
-        HCHECK(h, hipStreamWaitEvent(async ? h->ref_streams[1] : h->sub_streams[1], h->ev_ref[0], 0));
-        if (async) HCHECK(h, hipStreamWaitEvent(h->ref_streams[0], h->ev_ref[0], 0));
+        HCHECK(h, hipStreamWaitEvent(h->sub_streams[1], h->ev_ref[0], 0));
     }
     int c = 0;
     for (int m0 = 0; m0 < n; m0 += h->ref_chunk, c++) {
         const int nc = std::min(h->ref_chunk, n - m0), w = c % nways;
-        hipStream_t st = async ? h->ref_streams[w] : h->sub_streams[w];
+        hipStream_t st = h->sub_streams[w];
         float *y1 = h->y1r[w], *y2 = h->y2r[w], *y3p = h->y3pr[w];
         float *fr1 = h->fr1[w], *fr2 = h->fr2[w];
         const int fpw = h->conv1_fpw >= 8 ? 8 : h->conv1_fpw >= 4 ? 4 : h->conv1_fpw >= 2 ? 2 : 1;   // F is a multiple of 8
@@ -1521,17 +1498,8 @@ static int ref_pass(dne_handle *h, int n, bool async = false /* eval_core: leave
                                (float *)nullptr);
             hipLaunchKernelGGL(k_bn3_rows, dim3(nc), dim3(256), 0, st, A, m0, F, (const float *)y3p);
         }
-        if (async) {
-            while ((int)h->ev_chunk.size() <= c) {
-                hipEvent_t e;
-                HCHECK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                h->ev_chunk.push_back(e);
-            }
-            HCHECK(h, hipEventRecord(h->ev_chunk[c], st));
-        }
     }
-    if (async) h->ref_chunks_async = c;
-    else if (nways > 1) {
+    if (nways > 1) {
         HCHECK(h, hipEventRecord(h->ev_ref[1], h->sub_streams[1]));
         HCHECK(h, hipStreamWaitEvent(h->stream, h->ev_ref[1], 0));
     }
@@ -1705,29 +1673,24 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
 #undef FCT
         return;
     }
-    if (h->duo_now && !logits && order && (gsize == 2 ? es : !es)) {   // table-ordered units: adjacent (group, k-slice) units share their noise rows
+    if (h->duo_now && !logits && order && gsize == 2 && es) {   // table-ordered units: adjacent (pair, k-slice) units share their noise rows
         const bool solo = h->duo_solo_now;
         const bool sweep = h->duo_sweep && (!solo || h->duo_sweep > 1);
-        const int rounds = sweep ? h->duo_rounds : 1;   // duos a wave takes one after the other within a work item (sweep only)
-        const bool w4 = h->duo_w == 4 && es && sweep;
-        const int duo_grid = h->duo_grid ? h->duo_grid : (w4 ? 2 * h->fc_grid : h->fc_grid);
-        const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 4 * rounds - 1) / (4 * rounds), blocks = std::min(items, duo_grid);
+        const int duo_grid = h->duo_grid ? h->duo_grid : h->fc_grid;
+        const int n_units = 4 * count, items = ((solo ? n_units : (n_units + 1) / 2) + 3) / 4, blocks = std::min(items, duo_grid);
         const size_t out_lds = (size_t)h->out_lds_kb * 1024;   // an LDS reservation nobody uses: it only bounds k_out's workgroups per CU next to the streaming fc
+        const int flags = h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11);
         if (h->ring_now) {   // one unit per wave, eight units per workgroup whatever the regime
             const int ring_blocks = std::min((n_units + 7) / 8, duo_grid);
             if (h->duo_fat) hipLaunchKernelGGL((k_fc_ring<true, 8>), dim3(ring_blocks), dim3(576), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, (const float *)h->theta_perm, h->fc_prio << 9);
             else hipLaunchKernelGGL((k_fc_ring<false, 8>), dim3(ring_blocks), dim3(576), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, (const float *)h->theta_perm, h->fc_prio << 9);
         }
-        else if (w4) hipLaunchKernelGGL((k_fc_duo<2, true, true, 4>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
-        else if (es && sweep && h->duo_fat) hipLaunchKernelGGL((k_fc_duo<2, true, true, 8, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
-        else if (es && sweep) hipLaunchKernelGGL((k_fc_duo<2, true, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
-        else if (es) hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
-        else if (sweep) hipLaunchKernelGGL((k_fc_duo<1, false, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
-        else hipLaunchKernelGGL((k_fc_duo<1, false>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11) | ((rounds - 1) << 14));
+        else if (sweep && h->duo_fat) hipLaunchKernelGGL((k_fc_duo<2, true, true, 8, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, flags);
+        else if (sweep) hipLaunchKernelGGL((k_fc_duo<2, true, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, flags);
+        else hipLaunchKernelGGL((k_fc_duo<2, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, flags);
         if (after_stream_kernel) hipEventRecord(after_stream_kernel, st);
         if (out_fused) return;   // the caller runs k_tail_step: policy head + emulator step in one launch
-        if (es) hipLaunchKernelGGL((k_out<2, true>), dim3(count), dim3(256), out_lds, st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
-        else hipLaunchKernelGGL((k_out<1, false>), dim3(count), dim3(256), out_lds, st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
+        hipLaunchKernelGGL((k_out<2, true>), dim3(count), dim3(256), out_lds, st, A, list, (const float *)h->y3t, h->y3, h->action, (float *)nullptr);
         return;
     }
     if (gsize == 2 && es && h->uniform_base && h->fc2_now && !logits) {   // two pairs per work item share the base rows
@@ -1814,27 +1777,11 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     if (h->debug_sync) { HCHECK(h, hipStreamSynchronize(h->stream)); HCHECK(h, hipGetLastError()); }
     if (h->theta_perm && h->antithetic_slot0 && gsize == 2)   // k_fc_ring reads base slot 0's fc matrix in its own column order
         hipLaunchKernelGGL(k_theta_perm, dim3(3872 + 16), dim3(256), 0, h->stream, (const float *)(h->bases + h->L.fcw), h->theta_perm, 3872);
-    if (ref_pass(h, n, h->ref_overlap && !h->debug_sync)) return -1;
+    if (ref_pass(h, n)) return -1;
     if (h->debug_sync) { HCHECK(h, hipDeviceSynchronize()); HCHECK(h, hipGetLastError()); }
     h->trace("eval: reference pass %s", h->debug_sync ? "done" : "launched");
-    if (h->ref_chunks_async) {   // the pass is in flight on its own streams: its end, for the profile, is the later of their last chunks
-        const int last = h->ref_chunks_async - 1;
-        HCHECK(h, hipStreamWaitEvent(h->ref_streams[last & 1], h->ev_chunk[last - 1], 0));
-        HCHECK(h, hipEventRecord(h->event(1), h->ref_streams[last & 1]));
-    } else
     HCHECK(h, hipEventRecord(h->event(1), h->stream));
     const int groups = n / gsize;
-    // The active list starts in NOISE-TABLE order (round 5): the windows below are contiguous pieces of it, so window s then holds the
-    // pairs of the s-th stretch of the table and its units lie nsub times closer together -- eight table-neighbour units of a
-    // k_fc_ring workgroup span 205 ticks instead of 464 at four windows (the timeline fill of DESIGN 4a: 0.60 instead of 0.26).  Which
-    // window a pair is stepped in is a schedule: k_compact keeps the order, every result lands in the member's own slot.
-    if (h->list_sort && h->L.kind == DNE_KIND_ES && gsize == 2 && !h->large && groups >= h->fc_duo_min && (int)h->host_off.size() >= n && !h->ref_chunks_async) {
-        h->host_list.resize(groups);
-        for (int g = 0; g < groups; g++) h->host_list[g] = g;
-        const int64_t *off = h->host_off.data();
-        std::sort(h->host_list.begin(), h->host_list.end(), [off](int a, int b) { return off[2 * a] != off[2 * b] ? off[2 * a] < off[2 * b] : a < b; });
-        HCHECK(h, hipMemcpyAsync(h->list_a, h->host_list.data(), (size_t)groups * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    } else
     hipLaunchKernelGGL(k_iota, dim3((groups + 255) / 256), dim3(256), 0, h->stream, h->list_a, groups);
     HCHECK(h, hipStreamSynchronize(h->stream));
 
@@ -1893,7 +1840,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     size_t fc_ring_pos = 0;
     // the profiled ("full") launches are one kernel: k_fc2 when this evaluation starts wide enough to use it, else k_fc
     const bool fc2_eval = h->fc_pairs == 2 && gsize == 2 && h->L.kind == DNE_KIND_ES && h->uniform_base && groups >= h->fc2_min_total;
-    const bool duo_eval = !h->large && h->fc_duo && (h->L.kind == DNE_KIND_ES ? gsize == 2 : (gsize == 1 && h->fc_duo_ga)) && groups >= h->fc_duo_min;
+    const bool duo_eval = !h->large && h->fc_duo && (h->L.kind == DNE_KIND_ES && gsize == 2) && groups >= h->fc_duo_min;
     // an evaluation that starts wide enough for k_fc_ring: its bracketed ("full") launches are that kernel's only -- one kernel per
     // roofline line; the k_fc_duo launches of its thinner lock-steps (DNE_FC_DUO_MIN .. DNE_DUO_SOLO_BELOW pairs) are not bracketed
     // the ring's range: pairs as dense in their stretch of the table as DNE_DUO_SOLO_BELOW (1500) pairs over the whole table, and enough of them to
@@ -1905,7 +1852,7 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
         const int burst = std::min(total <= h->fc_tail_max ? h->burst_tail : h->burst, tslimit - t);   // lock-steps until the next compaction
         const int nsub = pick_nsub(total);
         h->fc2_now = h->fc_pairs == 2 && total >= h->fc2_min_total;
-        h->duo_now = !h->large && h->fc_duo && (h->L.kind == DNE_KIND_ES ? gsize == 2 : (gsize == 1 && h->fc_duo_ga)) && total >= h->fc_duo_min &&
+        h->duo_now = !h->large && h->fc_duo && (h->L.kind == DNE_KIND_ES && gsize == 2) && total >= h->fc_duo_min &&
                      (size_t)4 * ((total + nsub - 1) / nsub) * sizeof(long long) <= 160 * 1024;   // k_unit_order ranks a window's keys in LDS
         h->duo_solo_now = total < h->duo_solo_below;
         h->sub_now = sub_regime(total);
@@ -1925,13 +1872,6 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                 if (cnt == 0) continue;
                 hipStream_t sst = h->sub_streams[s];
                 const int *lst = cur + lo;
-                if (h->ref_chunks_async && t == 0 && st == 0) {
-                    // first lock-step of the evaluation: the list is 0, 1, 2, ... so the window's members are [lo * gsize, (lo + cnt) * gsize);
-                    // the chunks alternate between two streams, each in order: the window's last chunk and the one before it cover all
-                    const int c_hi = ((lo + cnt) * gsize - 1) / h->ref_chunk;
-                    HCHECK(h, hipStreamWaitEvent(sst, h->ev_chunk[c_hi], 0));
-                    if (c_hi > 0) HCHECK(h, hipStreamWaitEvent(sst, h->ev_chunk[c_hi - 1], 0));
-                }
                 std::array<size_t, 4> e{};
                 // events only around full-width launches: in the latency-bound tail every event packet is a bubble
                 // (with k_fc2 enabled the profiled launches are exactly the k_fc2 ones: the roofline kernel of bench.py)
@@ -2020,7 +1960,6 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
             }
         }
         t += burst;
-        h->ref_chunks_async = 0;   // every window has waited for its chunks and the windows cover the list: the pass is over with this burst
         for (int s = 1; s < nsub; s++) HCHECK(h, hipStreamSynchronize(h->sub_streams[s]));
         hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, (const int32_t *)h->done, gsize, (const int *)cur,
                            total, nxt, h->count_dev);

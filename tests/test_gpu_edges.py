@@ -144,10 +144,9 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
 # Settings that put a kernel or schedule NO default path launches onto the test population (the A/B library of DESIGN.md section 4):
 # they run with `-m "gpu and variants"` (or DNE_TEST_VARIANTS=1) only; everything else forces a DEFAULT-path kernel onto a population
 # small enough for the oracle and stays in the default GPU suite.
-_VARIANT_KEYS = {"DNE_FC2_MIN", "DNE_DUO_LAG", "DNE_DUO_HEAD_FUSED", "DNE_DUO_SWEEP", "DNE_DUO_ROUNDS", "DNE_DUO_SYNC", "DNE_DUO_W", "DNE_FC_DUO",
+_VARIANT_KEYS = {"DNE_FC2_MIN", "DNE_DUO_LAG", "DNE_DUO_HEAD_FUSED", "DNE_DUO_SWEEP", "DNE_DUO_SYNC", "DNE_FC_DUO",
                  "DNE_FC_PAIRS", "DNE_FC_RB", "DNE_HEAD_THREADS", "DNE_TAIL_TABLE", "DNE_SPEC_CONV1", "DNE_SPEC_BANDS", "DNE_TAIL_FUSED_MAX",
-                 "DNE_CONV1_FPW", "DNE_CONV1_SHARED", "DNE_BAND_THREADS", "DNE_FC_SUB_SPW", "DNE_FC_SUB_NSUB", "DNE_DUO_FAT", "DNE_GA_MATERIALIZE",
-                 "DNE_FC_DUO_GA"}
+                 "DNE_CONV1_FPW", "DNE_CONV1_SHARED", "DNE_BAND_THREADS", "DNE_FC_SUB_SPW", "DNE_FC_SUB_NSUB", "DNE_DUO_FAT", "DNE_GA_MATERIALIZE"}
 
 
 def _knob_params(knob_list):
@@ -164,12 +163,6 @@ _ES_STEP_KNOBS = [
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_SWEEP": "0"},   # ... without the workgroup's common table timeline (round 2's schedule: every wave starts its duo at once), two units per wave
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SWEEP": "0"},   # ... one unit per wave
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_SWEEP": "1"},   # ... the timeline only for two units per wave (default 2: also for one)
-    {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_ROUNDS": "2"},   # ... every wave takes two duos one after the other on the workgroup's timeline
-    {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_ROUNDS": "3", "DNE_DUO_SYNC": "2"},   # ... three single units, a barrier every second row block
-    {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_W": "4"},   # ... four rows in flight per stream instead of eight (four waves per SIMD; the fold in LDS), two units per wave
-    {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_W": "4"},   # ... one unit per wave
-    {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_W": "4", "DNE_DUO_SYNC": "2", "DNE_NSUB": "2"},   # ... a barrier every second row block, two windows
-    {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_W": "8"},   # ... and the eight-row form by name
     {"DNE_FC_SUB": "2", "DNE_FC_SUB_MIN": "2"},                         # the sub-slice fc (k_fc_sub: one wave per 128 / 120-row chain, folded by k_out<.., SUB>) for pairs, two windows
     {"DNE_FC_SUB": "2", "DNE_FC_SUB_MIN": "2", "DNE_FC_SUB_NSUB": "1", "DNE_FC_SUB_SPW": "2"},   # ... one window, two chains per wave
     {"DNE_FC_SUB": "2", "DNE_FC_SUB_MIN": "2", "DNE_FC_SUB_SPW": "8"},   # ... a whole quarter per wave
@@ -353,37 +346,7 @@ def test_reference_batch_sizes(nref, members, oracle, small_noise):
         e.close()
 
 
-@pytest.mark.parametrize("knobs", [{"DNE_REF_OVERLAP": "1", "DNE_NSUB": "3"}, {"DNE_REF_OVERLAP": "1", "DNE_NSUB": "2", "DNE_REF_PRIO": "0"},
-                                   {"DNE_REF_OVERLAP": "1", "DNE_NSUB": "4", "DNE_FC_RING": "2", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1"}])
-def test_reference_pass_under_the_first_lock_steps(knobs, oracle, small_noise, monkeypatch):
-    """DNE_REF_OVERLAP: the reference pass runs chunk by chunk on its own streams and a window starts stepping as soon as the
-    chunks of its own members are through (policies.py:399: the pass still precedes that member's first step) -- 7 chunks of 4
-    members under 2 .. 4 windows, every return / length against the oracle"""
-    from dne_hip import _lib
-    for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
-    e = _lib.Engine(_lib.KIND_ES, NACT, max_members=26, ref_count=NREF, ref_chunk=4)
-    try:
-        e.noise_upload(small_noise)
-        ref = oracle.get_ref_batch(seed=0, batch_size=NREF, nact=NACT)
-        e.set_ref_batch(ref)
-        L = oracle.layout(0, NACT)
-        th = oracle.es_init_theta(L, 0)
-        e.set_theta(th)
-        idx = np.array([11, 222_222, 2_900_001, 1_234_567, 42, 77_777, 2_000_000, 3, 1_500_123, 900_000, 2_950_000, 512, 300_300], np.int64)
-        seeds = (np.arange(26, dtype=np.uint32) * 2654435761).astype(np.uint32)
-        for _ in range(2):   # twice: the second evaluation re-uses the chunk events
-            ret, sg, ln = e.es_eval(idx, 0.02, 40, seeds)
-            oret, osg, oln = oracle.es_eval(L, th, small_noise, idx, 0.02, 40, ref, seeds)
-            assert np.array_equal(ln, oln) and np.array_equal(ret, oret) and np.array_equal(sg, osg), knobs
-        assert e.check_redzones() == 0
-    finally:
-        e.close()
-
-
 _GA_STEP_KNOBS = [
-    {"DNE_FC_DUO_GA": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1"},                              # table-ordered fc for single members, one unit per wave
-    {"DNE_FC_DUO_GA": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0"},   # ... two units per wave
     {"DNE_SPEC_MAX": "0"},                                                                            # GA tail without speculation
     {"DNE_SPEC_MAX": "64"},                                                                           # ... speculative from the first lock-step
     {"DNE_GA_MATERIALIZE": "0"},                                                                      # children NOT written out: parent row + noise row on the fly

@@ -4,7 +4,7 @@ settings run round-robin `--rounds` times so that drift shows.  Per setting:
   alone_fc_ms    the streaming fc kernel alone: 2500 pairs in ONE window, nobody dies for 6 lock-steps (HIP events per launch)
   lockstep_ms    a full-width lock-step of the default window count (wall / steps, reference pass subtracted)
   gen_ms         ms per generation of the driver's workload (generations g0 .. g0+n-1 after `--warmup`, theta evolving)
-    python tools/ab_inproc.py "X=0" "DNE_DUO_W=4" "DNE_DUO_W=4 DNE_DUO_SYNC=2"
+    python tools/ab_inproc.py "X=0" "DNE_DUO_SYNC=2" "DNE_DUO_SYNC=2 DNE_NSUB_FULL=3"
 """
 import argparse, hashlib, json, os, sys, time
 import numpy as np

@@ -4,7 +4,7 @@ TAG=${1:-r05tr}
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 i=0
-IFS=';' read -ra SET <<< "${SETTINGS:-X=0;DNE_LIST_SORT=1}"
+IFS=';' read -ra SET <<< "${SETTINGS:-X=0}"
 for s in "${SET[@]}"; do
   env $s timeout 200 rocprofv3 --kernel-trace --output-format csv -d $O/t$i.d -o t -- python $R/tools/kbench.py --pairs 2500 --reps 1 --tslimit 6 > $O/t$i.json 2> $O/t$i.err
   f=$(find $O/t$i.d -name '*kernel_trace.csv' | head -1)

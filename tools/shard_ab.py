@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """An N-rank launch rehearsed on one GPU (tools/workloads.py:simulate_ranks) under different index-sharding modes and engine knobs:
-    python tools/shard_ab.py --worlds 2,4,8 --gens 6 --warmup 3 "uniform" "table" "table DNE_FC_RING=2 DNE_LIST_SORT=1"
+    python tools/shard_ab.py --worlds 2,4,8 --gens 6 --warmup 3 "uniform" "table" "table DNE_FC_RING=2 DNE_RING_MIN=0"
 Each setting = a shard mode followed by DNE_* knobs (read at dne_create).  One JSON line per (world, setting)."""
 import argparse, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
