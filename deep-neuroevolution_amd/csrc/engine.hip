@@ -198,10 +198,10 @@ __device__ __forceinline__ void render_body(EnvLds &s, const EnvArgs &E, int m, 
         s.ram_cur[tid] = E.ram_cur[(size_t)m * 128 + tid];
     }
     __syncthreads();
-    synth_observe(s, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), fill, band, nbands);
+    synth_observe<1>(s, (uint32_t *)(E.stacks + (size_t)m * OB_BYTES), fill, band, nbands);
 }
 
-__global__ __launch_bounds__(1024) void k_env_render(EnvArgs E, const int *__restrict__ list, int gsize, int fill, int nbands) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_env_render(EnvArgs E, const int *__restrict__ list, int gsize, int fill, int nbands) {
     __shared__ __attribute__((aligned(16))) EnvLds s;
     const int b = blockIdx.x / nbands, band = blockIdx.x % nbands;
     DNE_PHASE(0, 0);

@@ -381,7 +381,7 @@ struct EnvLds {
     int slot_of_key[192];
     int rep_y[ENV_MAX_ROWS];
     uint8_t img[ENV_MAX_ROWS * 160];        // colour pair (prev<<4 | cur) per pixel of each unique row
-    float tmp[ENV_MAX_ROWS * 84];           // horizontally resized unique rows (float32 like PIL's temp image)
+    alignas(16) float tmp[ENV_MAX_ROWS * 84];   // horizontally resized unique rows (float32 like PIL's temp image)
     int misc[4];
 };
 
@@ -415,6 +415,9 @@ __device__ inline void synth_load_tables(EnvLds &s, const ResizeLds *__restrict_
 // synth_load_tables and after ram_prev / ram_cur are in LDS.
 // stack_in (optional): where the member's current frame stack is read when the shifted stack goes to another buffer
 // (speculative tail: one candidate stack per action); default = in place.
+// TAG: a copy of the function per caller class -- TAG 1 is k_env_render's own, so that kernel's register bound (six waves per SIMD = three 512-thread
+// workgroups per CU) reaches this code without binding the tail kernels that call TAG 0
+template <int TAG = 0>
 __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bool fill, int band = 0, int nbands = 1,
                                      const uint32_t *__restrict__ stack_in = nullptr) {
     if (!stack_in) stack_in = stack;
@@ -452,21 +455,52 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     __syncthreads();
     if (myrow) s.off_of_y[tid] = (uint16_t)(s.slot_of_key[key] * (84 * 4));
     const int nu = min(s.misc[2], ENV_MAX_ROWS);
-    // one wave per unique row: the row number and the RAM-derived state are wave-uniform, so each row of each frame is
-    // first reduced (on the scalar unit) to a background colour + one periodic pattern + one span + the player sprite,
-    // and the per-pixel work is a short branch-free select chain
+    // Row descriptions (round 6): one LANE per (unique row, frame) -- every row of each frame reduced to a background colour + one periodic
+    // pattern + one span + the player sprite by the straight-line selects of synth_row_desc, with the row number in a vector register: two
+    // waves describe all <= 80 rows of both frames at once (rounds 2-5: one WAVE per row on the scalar unit, 170 scalar instructions per row,
+    // 7.5 of a full-width workgroup's 19.3 us -- tools/render_phase_clock.py).  The 13 fields of a description lie in the part of LDS the
+    // horizontal pass will fill later (tmp: a barrier lies between), 12 ints per (row, frame): sprite flag and position share one.
     const PixState pp = synth_pix_uniform(synth_pix_state(s.ram_prev)), pc = synth_pix_uniform(synth_pix_state(s.ram_cur));
+    int *desc = (int *)s.tmp;
+    static_assert(ENV_MAX_ROWS * 2 * 12 <= ENV_MAX_ROWS * 84, "the row descriptions fit the region they borrow");
+    {
+        const int f = tid >> 7, u = tid & 127;          // threads 0..127: the previous frame's rows, 128..255: the current frame's
+        if (tid < 256 && u < nu) {
+            const int y = s.rep_y[u];
+            DNE_ROW_FIELDS(d_);
+            if (f == 0) synth_row_desc(pp, y, DNE_ROW_ARGS(d_));
+            else synth_row_desc(pc, y, DNE_ROW_ARGS(d_));
+            int4 *o = (int4 *)(desc + (u * 2 + f) * 12);
+            o[0] = make_int4(d_bg, d_p_off, d_p_len, d_p_period);
+            o[1] = make_int4(d_p_recip, d_p_width, d_p_col, (int)d_p_mask);
+            o[2] = make_int4(d_r_lo, d_r_len, d_r_col, d_s_on | (d_s_px << 1));
+        }
+    }
+    __syncthreads();
+    // one wave per unique row: the description is the same in every lane (a broadcast read), the per-pixel work a short branch-free select chain
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6, lane = tid & 63;
     for (int u = wave; u < nu; u += nwave) {
-        const int y = __builtin_amdgcn_readfirstlane(s.rep_y[u]);
-        DNE_ROW_FIELDS(a_);
-        DNE_ROW_FIELDS(b_);
-        synth_row_desc(pp, y, DNE_ROW_ARGS(a_));
-        synth_row_desc(pc, y, DNE_ROW_ARGS(b_));
+        const int4 *da = (const int4 *)(desc + u * 24);
+#define DNE_ROW_FROM(q0, q1, q2) q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, (uint32_t)q1.w, q2.x, q2.y, q2.z, q2.w & 1, q2.w >> 1
+        int c0, c1, c2;
+        {   // the previous frame's colours first, then the current frame's: one description live at a time (register footprint: three workgroups per CU)
+            const int4 a0 = da[0], a1 = da[1], a2 = da[2];
+            c0 = synth_row_pixel(lane, DNE_ROW_FROM(a0, a1, a2)) << 4;
+            c1 = synth_row_pixel(lane + 64, DNE_ROW_FROM(a0, a1, a2)) << 4;
+            c2 = synth_row_pixel(lane + 128, DNE_ROW_FROM(a0, a1, a2)) << 4;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int4 b0 = da[3], b1 = da[4], b2 = da[5];
+            c0 |= synth_row_pixel(lane, DNE_ROW_FROM(b0, b1, b2));
+            c1 |= synth_row_pixel(lane + 64, DNE_ROW_FROM(b0, b1, b2));
+            c2 |= synth_row_pixel(lane + 128, DNE_ROW_FROM(b0, b1, b2));
+        }
         uint8_t *row = s.img + u * 160;
-        row[lane] = (uint8_t)((synth_row_pixel(lane, DNE_ROW_ARGS(a_)) << 4) | synth_row_pixel(lane, DNE_ROW_ARGS(b_)));
-        row[lane + 64] = (uint8_t)((synth_row_pixel(lane + 64, DNE_ROW_ARGS(a_)) << 4) | synth_row_pixel(lane + 64, DNE_ROW_ARGS(b_)));
-        if (lane < 32) row[lane + 128] = (uint8_t)((synth_row_pixel(lane + 128, DNE_ROW_ARGS(a_)) << 4) | synth_row_pixel(lane + 128, DNE_ROW_ARGS(b_)));
+        row[lane] = (uint8_t)c0;
+        row[lane + 64] = (uint8_t)c1;
+        if (lane < 32) row[lane + 128] = (uint8_t)c2;
+#undef DNE_ROW_FROM
     }
     __syncthreads();
     DNE_PHASE(0, 2);
@@ -483,7 +517,8 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     DNE_PHASE(0, 3);
     // vertical pass + u8 truncation + stack shift.  The old stack words are fetched VP at a time (all of them before
     // the first barrier when the workgroup covers the stack in one go) so that the global-load latency is paid once
-    // per chunk, not once per pixel.
+    // per chunk, not once per pixel.  (A branch-free form -- threads past the end recompute the last pixel, only the store predicated, so that
+    // the VP outputs' LDS round trips overlap -- needs more than the 80 registers three workgroups per CU leave: it spills.  Not kept.)
     for (int base = 0; base < nout; base += nthr * VP) {
         if (!pre && !fill) {
 #pragma unroll
