@@ -72,7 +72,7 @@ FC_KERNELS = {   # the kernel behind the profiled ("full") fc launches of one ev
     1: "dne::k_fc<2, false, true, 4> (streaming fc + bn + out + argmax, one pair per work item: every window with > 96 active "
        "pairs; the rank's share is too small for k_fc2)",
 }
-PMC_PROFILES = tuple(os.path.join("profiles", "r0%d_pmc.json" % r) for r in (5, 4, 3, 2, 1))
+PMC_PROFILES = tuple(os.path.join("profiles", "r0%d_pmc.json" % r) for r in (6, 5, 4, 3, 2, 1))
 EXTRAS = ("ga", "ga_large", "nses", "sweep", "config1", "predicted")
 EXTRAS_MULTI = ("ga", "nses", "sweep")         # default at N > 1: BASELINE configs 4 / 5 are DEFINED on 4 / 8 GPUs (ga_large, config1: one rank)
 SIMDS, SHADER_HZ = 1024, 2.4e9                 # MI355X: 256 CUs x 4 SIMDs; nominal shader clock
@@ -493,7 +493,7 @@ def run_extras(which, noise, engine, rank, world, local_rank, transport_bytes, t
             r["traffic_source"] = "counted bytes of the ES streaming kernel at this leg's env-steps/s (%s, %s)" % (src, (regime or "").split(":")[0])
             r["frac_counter"] = out[name]["value"] * per_unit / (HBM_PEAK * world)
     # the GA legs: every dispatch of tools/ga_bench.py (--large) counted, per env-step of that run (tools/summarize_pmc_ga.py)
-    for rel in ("profiles/r05_pmc_ga.json",):
+    for rel in [r for r in ("profiles/r06_pmc_ga.json", "profiles/r05_pmc_ga.json") if os.path.exists(os.path.join(ROOT, r))][:1]:
         try:
             gd = json.load(open(os.path.join(ROOT, rel)))
         except Exception:
