@@ -586,6 +586,7 @@ struct dne_handle {
     int burst = 32, burst_tail = 16; // DNE_BURST / DNE_BURST_TAIL: lock-steps between two compactions of the active list (a host round trip each), at large / with at most fc_tail_max groups alive (round 4: 32 at large, 16 before; 24 / 32 / 48 measured -0.5 .. -0.9 %, 8 +2.3 %, 64 +0.2 %; the tail indifferent)
     double dense_scale = 1.0;        // table length / the stretch of the table this evaluation's noise slices cover (dne_es_eval; 1 for every other caller): a rank that draws
                                      // its indices from its own 1/N of the table (es.py shard 'table') holds pairs as dense as N times as many over the whole table
+    int sub_render_fused = 0;        // DNE_SUB_RENDER_FUSED (round 6): behind the sub-slice fc the policy head, the emulator AND the renderer in one launch (k_tail_step<.., true>, 1024 threads per member): three launches per window and lock-step instead of four
     int ring_min = 1000;             // DNE_RING_MIN: k_fc_ring needs this many active pairs on the rank whatever their density (below, its workgroups -- eight units, one per CU --
                                      // no longer fill the chip: a 625-pair share measured 61.6 ms per generation on the ring against 57.8 on k_fc_duo, profiles/r06_shard_ab.jsonl)
     int ring_on = 1;                 // DNE_FC_RING (round 5): k_fc_ring instead of k_fc_duo -- the workgroup's noise rows through an LDS ring filled by LDS-DMA, the base rows from a column-permuted copy of the fc matrix; 1: from DNE_DUO_SOLO_BELOW active pairs (1500) upwards, 2: in the whole k_fc_duo range (measured slower in the sparse part: 239 vs 233 ms), 0: k_fc_duo everywhere
@@ -1012,7 +1013,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_PRIO", 0, 3, &h->fc_prio);
     env_int("DNE_DUO_SWEEP", 0, 2, &h->duo_sweep);
     env_int("DNE_DUO_SYNC", 1, 8, &h->duo_sync);
-    env_int("DNE_DUO_FAT", 0, 1, &h->duo_fat); env_int("DNE_FC_RING", 0, 2, &h->ring_on); env_int("DNE_RING_MIN", 0, 1 << 30, &h->ring_min);
+    env_int("DNE_DUO_FAT", 0, 1, &h->duo_fat); env_int("DNE_FC_RING", 0, 2, &h->ring_on); env_int("DNE_RING_MIN", 0, 1 << 30, &h->ring_min); env_int("DNE_SUB_RENDER_FUSED", 0, 1, &h->sub_render_fused);
     env_int("DNE_BURST", 1, 256, &h->burst);
     env_int("DNE_BURST_TAIL", 1, 256, &h->burst_tail);
     env_int("DNE_DUO_GRID", 0, 1 << 16, &h->duo_grid);
@@ -1943,10 +1944,15 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
                     const FwdArgs A = h->fwd(false);
                     const int items = cnt * gsize;
                     const float *sums = h->sub_now ? h->y3s : h->y3t;
+                    if (h->sub_render_fused && h->sub_now && !(h->dbg_skip & 4)) {   // head + emulator + renderer in one launch
+                        if (h->L.kind == DNE_KIND_ES) hipLaunchKernelGGL((k_tail_step<true, true>), dim3(items), dim3(1024), 0, sst, A, E, lst, gsize, tslimit, sums, h->y3, h->action);
+                        else hipLaunchKernelGGL((k_tail_step<false, true>), dim3(items), dim3(1024), 0, sst, A, E, lst, gsize, tslimit, sums, h->y3, h->action);
+                    } else {
                     if (h->L.kind == DNE_KIND_ES) hipLaunchKernelGGL((k_tail_step<true, false>), dim3(items), dim3(h->head_threads), 0, sst, A, E, lst, gsize, tslimit, sums, h->y3, h->action);
                     else hipLaunchKernelGGL((k_tail_step<false, false>), dim3(items), dim3(h->head_threads), 0, sst, A, E, lst, gsize, tslimit, sums, h->y3, h->action);
                     if (!(h->dbg_skip & 4))
                         hipLaunchKernelGGL(k_env_render, dim3(items), dim3(items <= 192 ? 1024 : h->render_threads), 0, sst, E, lst, gsize, 0, 1);
+                    }
                 } else launch_env_step(h, E, lst, cnt, gsize, tslimit, sst);
                 if (pe) { e[3] = ne++; HCHECK(h, hipEventRecord(h->event(e[3]), sst)); evs.push_back(e); }
                 if (h->debug_sync) {

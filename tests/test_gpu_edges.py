@@ -146,7 +146,7 @@ def test_device_trajectories_after_longer_run(eng, oracle, small_noise):
 # small enough for the oracle and stays in the default GPU suite.
 _VARIANT_KEYS = {"DNE_FC2_MIN", "DNE_DUO_LAG", "DNE_DUO_HEAD_FUSED", "DNE_DUO_SWEEP", "DNE_DUO_SYNC", "DNE_FC_DUO",
                  "DNE_FC_PAIRS", "DNE_FC_RB", "DNE_HEAD_THREADS", "DNE_TAIL_TABLE", "DNE_SPEC_CONV1", "DNE_SPEC_BANDS", "DNE_TAIL_FUSED_MAX",
-                 "DNE_CONV1_FPW", "DNE_CONV1_SHARED", "DNE_BAND_THREADS", "DNE_FC_SUB_SPW", "DNE_FC_SUB_NSUB", "DNE_DUO_FAT", "DNE_GA_MATERIALIZE"}
+                 "DNE_CONV1_FPW", "DNE_CONV1_SHARED", "DNE_BAND_THREADS", "DNE_FC_SUB_SPW", "DNE_FC_SUB_NSUB", "DNE_DUO_FAT", "DNE_GA_MATERIALIZE", "DNE_SUB_RENDER_FUSED"}
 
 
 def _knob_params(knob_list):
@@ -166,6 +166,7 @@ _ES_STEP_KNOBS = [
     {"DNE_FC_SUB": "2", "DNE_FC_SUB_MIN": "2"},                         # the sub-slice fc (k_fc_sub: one wave per 128 / 120-row chain, folded by k_out<.., SUB>) for pairs, two windows
     {"DNE_FC_SUB": "2", "DNE_FC_SUB_MIN": "2", "DNE_FC_SUB_NSUB": "1", "DNE_FC_SUB_SPW": "2"},   # ... one window, two chains per wave
     {"DNE_FC_SUB": "2", "DNE_FC_SUB_MIN": "2", "DNE_FC_SUB_SPW": "8"},   # ... a whole quarter per wave
+    {"DNE_FC_SUB": "2", "DNE_FC_SUB_MIN": "2", "DNE_SUB_RENDER_FUSED": "1"},   # ... head + emulator + renderer in one launch behind it (three launches per window and lock-step; round 6, measured slower: not the default)
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_DUO_FAT": "1"},   # ... the form that the hardware places once per CU (register footprint past 256), two units per wave
     {"DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_FAT": "1", "DNE_NSUB": "2"},   # ... one unit per wave, two windows
     {"DNE_FC_RING": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_RING_MIN": "0"},   # k_fc_ring (round 5) through its DEFAULT gate (dense enough, enough pairs): the workgroup's noise rows through an LDS ring (LDS-DMA), base rows from the column-permuted copy; one unit per wave, eight per workgroup
