@@ -770,6 +770,13 @@ __global__ __launch_bounds__(256, 2) void k_conv12(FwdArgs A, const int *__restr
     const Item it = decode_item(A, blockIdx.x, list, gsize, 1, 0, stacks, nullptr, A.done);
     if (it.skip) return;
     DNE_WG_BEGIN;
+    // profiling build: thread 0 of workgroups 1024 .. 1151 of the launch (the steady state, not the launch's first wave) stamps its phases (tools/conv12_phase_clock.py)
+#ifdef DNE_PHASE_CLOCK
+#define CONV12_MARK(I) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x - 1024u < 128u) dne::g_phase[4][blockIdx.x - 1024u][I] = (long long)wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CONV12_MARK(I) do { } while (0)
+#endif
+    CONV12_MARK(0);
     constexpr int PS = C2_PS, RW = C2_RW;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, lp = lane & 15, ci = lane >> 4;
     const float *base = item_base<false>(A, it);     // more than 128 members per launch: the tail table is never in use here
@@ -818,6 +825,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12(FwdArgs A, const int *__restr
         if (e < 7056) S.img[(e / 84 + 2) * 88 + e % 84 + 2] = px[j];
     }
     __syncthreads();
+    CONV12_MARK(1);
     // ---- conv1: 28 position tiles, 7 per wave (three pairs + one single), exactly k_conv1's schedule
     float *out1 = y1 ? y1 + (size_t)it.row * 7056 : nullptr;
     auto run1 = [&](int j, auto has_b) {
@@ -861,6 +869,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12(FwdArgs A, const int *__restr
     run1(2, std::true_type{});
     run1(4, std::true_type{});
     run1(6, std::false_type{});
+    CONV12_MARK(2);
     // ---- conv2: its perturbed weights (fetching them before conv1 costs 69 spilled registers and was slower), then four
     //      position tiles per wave over the image conv1 just wrote
     float b2[64];
@@ -874,6 +883,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12(FwdArgs A, const int *__restr
         }
     }
     __syncthreads();
+    CONV12_MARK(3);
     int off[4];
     f32x4 acc[4];
 #pragma unroll
@@ -897,6 +907,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12(FwdArgs A, const int *__restr
             }
         }
     }
+    CONV12_MARK(4);
     float *o = y2 + (size_t)it.row * 3872;
     // k_fc_ring takes its activations as scalars and wants them finished: relu(fl(fl(y * scale) + shift)), the consumer's own operations
     const bool act = HAS_BN && act2 != 0;
@@ -914,7 +925,9 @@ __global__ __launch_bounds__(256, 2) void k_conv12(FwdArgs A, const int *__restr
             }
             if (pos < 121) o[pos * 32 + nt * 16 + lp] = y;
         }
+    CONV12_MARK(5);
     DNE_WG_END(0);
+#undef CONV12_MARK
 }
 
 // conv1 -> conv2 in one launch for the tail of a generation (a few dozen members left: a lock-step is a chain of launches on a
