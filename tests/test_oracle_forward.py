@@ -149,3 +149,81 @@ def test_large_model_forward_vs_torch(oracle):
         assert np.allclose(ol, lg[i].numpy(), atol=2e-3, rtol=1e-4)
         a, lg2 = O.act(L, th, None, obs[i])
         assert a == int(np.argmax(ol)) and np.array_equal(lg2, ol)
+
+
+def _conv64(x, w, b, stride, pad_lo, pad_hi):
+    """float64 SAME-style convolution, NHWC x HWIO, of ONE image: returns (sum, sum of |terms|) per output element"""
+    H, W, C = x.shape
+    kh, kw, _, CO = w.shape
+    xp = np.zeros((H + pad_lo + pad_hi, W + pad_lo + pad_hi, C), np.float64)
+    xp[pad_lo:pad_lo + H, pad_lo:pad_lo + W] = x
+    oh = (xp.shape[0] - kh) // stride + 1
+    ow = (xp.shape[1] - kw) // stride + 1
+    cols = np.empty((oh, ow, kh, kw, C), np.float64)
+    for i in range(kh):
+        for j in range(kw):
+            cols[:, :, i, j, :] = xp[i:i + stride * oh:stride, j:j + stride * ow:stride, :]
+    cols = cols.reshape(oh * ow, kh * kw * C)
+    wm = w.reshape(kh * kw * C, CO).astype(np.float64)
+    return cols @ wm + b, np.abs(cols) @ np.abs(wm) + np.abs(b)
+
+
+@pytest.mark.parametrize("kind,nact", [(0, 18), (1, 18)])
+def test_every_layer_is_a_valid_fp32_evaluation_of_the_float64_layer(oracle, kind, nact):
+    """TensorFlow 0.12's fp32 summation order is unknowable here (TF is absent: SURVEY 8c), so no test can pin the forward pass bit for bit.
+    What CAN be pinned: every layer of the oracle, fed the oracle's own fp32 input of that layer, lies within the worst-case rounding
+    bound of ANY fp32 summation order around the float64 value of the TF-defined layer (SAME padding 2/2 and 1/2, HWIO weights, NHWC
+    flatten, bias, `y * scale + shift` batch norm, relu):  |fl(sum) - sum| <= gamma_n * sum |x_k w_k|,  gamma_n = n u / (1 - n u), u = 2^-24,
+    n = terms + bias (Higham, Accuracy and Stability of Numerical Algorithms, 2nd ed., section 4.2).  An indexing, padding or layout error moves an
+    output by a whole term, orders of magnitude beyond the bound."""
+    O = oracle
+    L = O.layout(kind, nact)
+    rs = np.random.RandomState(11 + kind)
+    if kind == 0:
+        th = O.es_init_theta(L, 0)
+        th += (0.02 * rs.randn(L.P)).astype(np.float32)
+    else:
+        th = O.ga_normc(L, rs.randn(L.P).astype(np.float32))
+        th += (0.005 * rs.randn(L.P)).astype(np.float32)
+    ref = O.get_ref_batch(seed=0, batch_size=16, nact=nact)
+    bn = O.es_ref_pass(L, th, ref) if kind == 0 else None
+    u = 2.0 ** -24
+
+    def gamma(n):
+        return n * u / (1.0 - n * u)
+
+    def t(off, shape):
+        return th[off:off + int(np.prod(shape))].reshape(shape)
+
+    def act(y, o, C):   # the consumer's own fp32 operations: relu(fl(fl(y * scale) + shift)) / relu(y)
+        if bn is None:
+            return np.maximum(y, np.float32(0))
+        s = bn[o:o + C].astype(np.float32); h = bn[o + C:o + 2 * C].astype(np.float32)
+        v = (y.astype(np.float32) * s).astype(np.float32)
+        v = (v + h).astype(np.float32)
+        return np.maximum(v, np.float32(0))
+
+    w1 = t(L.c1w, (8, 8, 4, 16)); b1 = t(L.c1b, (16,)).astype(np.float64)
+    w2 = t(L.c2w, (4, 4, 16, 32)); b2 = t(L.c2b, (32,)).astype(np.float64)
+    wf = t(L.fcw, (3872, 256)).astype(np.float64); bf = t(L.fcb, (256,)).astype(np.float64)
+    wo = t(L.ow, (256, nact)).astype(np.float64); bo = t(L.ob, (nact,)).astype(np.float64)
+    obs = rs.randint(0, 256, (3, 84, 84, 4)).astype(np.uint8)
+    obs[1] = ref[5]
+    for i in range(obs.shape[0]):
+        o1, o2, o3, ol = O.forward_debug(L, th, bn, obs[i])
+        x = (obs[i].astype(np.float32) / np.float32(255.0)).astype(np.float32)
+        y1, m1 = _conv64(x.astype(np.float64), w1, b1, 4, 2, 2)
+        assert y1.shape == (441, 16)
+        assert (np.abs(o1.reshape(441, 16) - y1) <= gamma(256 + 1) * m1 + 1e-30).all()
+        a1 = act(o1.reshape(441, 16), 0, 16).reshape(21, 21, 16)
+        y2, m2 = _conv64(a1.astype(np.float64), w2, b2, 2, 1, 2)
+        assert y2.shape == (121, 32)
+        assert (np.abs(o2.reshape(121, 32) - y2) <= gamma(256 + 1) * m2 + 1e-30).all()
+        a2 = act(o2.reshape(121, 32), 32, 32).reshape(3872).astype(np.float64)   # NHWC flatten: position-major, channel-minor
+        y3 = a2 @ wf + bf; m3 = np.abs(a2) @ np.abs(wf) + np.abs(bf)
+        assert (np.abs(o3 - y3) <= gamma(3872 + 4) * m3 + 1e-30).all()            # + the three adds that combine the four k-slices
+        a3 = act(o3, 96, 256).astype(np.float64)
+        yl = a3 @ wo + bo; ml = np.abs(a3) @ np.abs(wo) + np.abs(bo)
+        assert (np.abs(ol - yl) <= gamma(256 + 4) * ml + 1e-30).all()
+        # and the bound is tight enough to mean something: a single dropped or misplaced term would break it
+        assert gamma(3872 + 4) * m3.max() < 0.05 * np.abs(a2).max() * np.abs(wf).max() + 1e-3
