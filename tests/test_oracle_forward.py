@@ -227,3 +227,39 @@ def test_every_layer_is_a_valid_fp32_evaluation_of_the_float64_layer(oracle, kin
         assert (np.abs(ol - yl) <= gamma(256 + 4) * ml + 1e-30).all()
         # and the bound is tight enough to mean something: a single dropped or misplaced term would break it
         assert gamma(3872 + 4) * m3.max() < 0.05 * np.abs(a2).max() * np.abs(wf).max() + 1e-3
+
+
+def test_large_model_layers_within_the_fp32_bound_of_float64(oracle):
+    """the same pin for the GPU tree's LargeModel (dqn.py:39-47): every layer inside the any-order fp32 rounding band around float64"""
+    O = oracle
+    L = O.layout(O.KIND_GA_LARGE, 18)
+    rs = np.random.RandomState(5)
+    th = (rs.randn(L.P) * 0.03).astype(np.float32)
+    u = 2.0 ** -24
+
+    def gamma(n):
+        return n * u / (1.0 - n * u)
+
+    def t(off, shape):
+        return th[off:off + int(np.prod(shape))].reshape(shape)
+    w1 = t(L.c1w, (8, 8, 4, 32)); b1 = t(L.c1b, (32,)).astype(np.float64)
+    w2 = t(L.c2w, (4, 4, 32, 64)); b2 = t(L.c2b, (64,)).astype(np.float64)
+    w3 = t(L.c3w, (3, 3, 64, 64)); b3 = t(L.c3b, (64,)).astype(np.float64)
+    wf = t(L.fcw, (7744, 512)).astype(np.float64); bf = t(L.fcb, (512,)).astype(np.float64)
+    wo = t(L.ow, (512, 18)).astype(np.float64); bo = t(L.ob, (18,)).astype(np.float64)
+    relu = lambda y: np.maximum(y.astype(np.float32), np.float32(0)).astype(np.float64)
+    for obs in rs.randint(0, 256, (2, 84, 84, 4)).astype(np.uint8):
+        o1, o2, o3, o4, ol = O.forward_large_debug(L, th, obs)
+        x = (obs.astype(np.float32) / np.float32(255.0)).astype(np.float64)
+        y, m = _conv64(x, w1, b1, 4, 2, 2)
+        assert (np.abs(o1.reshape(441, 32) - y) <= gamma(256 + 1) * m + 1e-30).all()
+        y, m = _conv64(relu(o1).reshape(21, 21, 32), w2, b2, 2, 1, 2)
+        assert (np.abs(o2.reshape(121, 64) - y) <= gamma(512 + 1) * m + 1e-30).all()
+        y, m = _conv64(relu(o2).reshape(11, 11, 64), w3, b3, 1, 1, 1)
+        assert (np.abs(o3.reshape(121, 64) - y) <= gamma(576 + 1) * m + 1e-30).all()
+        a = relu(o3).reshape(7744)
+        y = a @ wf + bf; m = np.abs(a) @ np.abs(wf) + np.abs(bf)
+        assert (np.abs(o4 - y) <= gamma(7744 + 8) * m + 1e-30).all()
+        a = relu(o4)
+        y = a @ wo + bo; m = np.abs(a) @ np.abs(wo) + np.abs(bo)
+        assert (np.abs(ol - y) <= gamma(512 + 8) * m + 1e-30).all()
