@@ -3,7 +3,7 @@
 # in its own rocprofv3 --pmc pass (kernel trace only), over a workload whose every lock-step has the same width (tools/kbench.py:
 # nobody dies within 6 steps).  Counter collection serialises the dispatches: a launch is measured with the chip to itself.
 #   regime               pairs  windows   units per launch (member-steps)
-#   full_1window          2500     1       5000    two units per wave (table-ordered duos)
+#   full_1window          2500     1       5000    k_fc_ring (since round 5): one unit per wave, eight per workgroup
 #   full_3windows         2500     3       1667    round 2's shape of the first lock-steps
 #   full_4windows         2500     4       1250    the bench's first lock-steps (>= 1900 active pairs) since the sweep
 #   half_4windows         1250     4        625    one unit per wave (below 1500 active pairs)

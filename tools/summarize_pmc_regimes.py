@@ -46,7 +46,7 @@ for name, pairs, nsub in REGIMES:
     lo = [int(pairs * s / nsub) for s in range(nsub + 1)]
     uniq = float(np.mean([unique_row_bytes(idx[lo[s]:lo[s + 1]]) for s in range(nsub)]))
     out["regimes"].append({
-        "regime": "%s: %d active pairs in %d window(s), %s" % (name, pairs, nsub, "two units per wave" if pairs >= 1500 else "one unit per wave"),
+        "regime": "%s: %d active pairs in %d window(s), %s" % (name, pairs, nsub, "k_fc_ring: one unit per wave, eight per workgroup" if pairs >= 1500 else "k_fc_duo: one unit per wave"),
         "kernel": kf['kernel'], "grid_size": int(kf['grid_size']), "dispatches": int(kf['dispatches']), "units_per_launch": units,
         "FETCH_SIZE_KB_avg": float(kf['avg_counter_KB']), "WRITE_SIZE_KB_avg": float(kw['avg_counter_KB']),
         "hbm_bytes_per_launch": fetch + write, "hbm_bytes_per_unit": (fetch + write) / units,
