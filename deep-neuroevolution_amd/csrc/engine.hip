@@ -594,10 +594,10 @@ struct dne_handle {
     int duo_fat = 1;                 // DNE_DUO_FAT: k_fc_duo with a register footprint past 256 per lane = at most one of its workgroups per CU (it streams as fast from one), so the other windows' kernels always find room beside it
     int fc_sub = 1;                  // DNE_FC_SUB (ES 2, GA 1): the sub-slice fc (k_fc_sub: one wave per 128 / 120-row chain) in the mid range -- 0 off, 1 GA children (materialised), 2 also ES pairs
     int fc_sub_min = 97, fc_sub_max = 320;   // DNE_FC_SUB_MIN / _MAX: active groups (all windows) between which it runs (max: 450 for ES pairs, 320 for GA children)
-    int fc_sub_nsub = 2;             // DNE_FC_SUB_NSUB: windows of that regime (ES 3, GA 2)
+    int fc_sub_nsub = 2;             // DNE_FC_SUB_NSUB: windows of that regime (ES 3, GA 4 since round 6)
     int fc_sub_spw = 0;              // DNE_FC_SUB_SPW: sub-slices per wave (1, 2, 4, 8; 0 = by width)
     int fc_sub_grid = 512;           // DNE_FC_SUB_GRID: workgroups of k_fc_sub at most, 4 waves each (GA 512 = two waves per SIMD; ES: the whole launch resident)
-    int fc_sub_prio = 0;             // DNE_FC_SUB_PRIO: s_setprio of k_fc_sub's waves (ES 0: the regime is bound by a window's chain of small kernels, they must not starve; GA 3 on its bounded grid)
+    int fc_sub_prio = 0;             // DNE_FC_SUB_PRIO: s_setprio of k_fc_sub's waves (ES 0: the regime is bound by a window's chain of small kernels, they must not starve; GA: 0 since round 6, 3 on its bounded grid before)
     int fc_sub_head = 1;             // DNE_FC_SUB_HEAD: policy head + emulator step in one launch (k_tail_step) behind k_fc_sub instead of k_out + k_env_logic
     bool sub_now = false;            // decided per burst by eval_core
     float *y3s = nullptr;            // [member][32][256]: the chain sums k_fc_sub leaves for k_out<.., SUB>
@@ -1021,7 +1021,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     // alive, two windows, a grid of 512 workgroups at wave priority 3; ES pairs 97 .. 450 alive, three windows, the whole launch
     // resident, no priority (its chain of small kernels must not starve); above those widths the streaming kernels win
     if (cfg->policy_kind == DNE_KIND_ES) { h->fc_sub = 2; h->fc_sub_max = 450; h->fc_sub_nsub = 3; h->fc_sub_grid = 1 << 20; h->fc_sub_prio = 0; }
-    else { h->fc_sub = 1; h->fc_sub_max = 320; h->fc_sub_nsub = 2; h->fc_sub_grid = 512; h->fc_sub_prio = 3; }
+    else { h->fc_sub = 1; h->fc_sub_max = 320; h->fc_sub_nsub = 4; h->fc_sub_grid = 512; h->fc_sub_prio = 0; }   // round 6: four windows at wave priority 0 (was two at 3): Deep GA 1.02-1.05 vs 0.98-1.00 M env-steps/s same-box; five / six windows 0.91-0.94
     env_int("DNE_FC_SUB", 0, 2, &h->fc_sub);
     env_int("DNE_FC_SUB_MIN", 1, 1 << 30, &h->fc_sub_min);
     env_int("DNE_FC_SUB_MAX", 1, 1 << 30, &h->fc_sub_max);
