@@ -209,3 +209,97 @@ def test_snapshots_with_the_old_schedule_classes_still_load():
     # constructing by the old names still works too (experiment files name them)
     assert ga_gpu.LinearSchedule(schedule=10, field='iteration', final_p=1.0, initial_p=0.0).value(iteration=5) == pytest.approx(0.5)
     assert ga_gpu.ConstantSchedule(0.5).value() == 0.5
+
+
+def _es_gpu_exp(**over):
+    exp = {"game": "frostbite", "model": "ModelVirtualBN", "num_validation_episodes": 2, "num_test_episodes": 3, "population_size": 6,
+           "timesteps": 10 ** 9, "episode_cutoff_mode": "adaptive:6,0.3,2,20", "return_proc_mode": "centered_rank", "l2coeff": 0.005,
+           "mutation_power": {"type": "LinearSchedule", "schedule": 4, "initial_p": 0.02, "final_p": 0.01, "field": "iteration"},
+           "optimizer": {"args": {"stepsize": 0.01}, "type": "adam"}}
+    exp.update(over)
+    return exp
+
+
+def test_gpu_tree_es_adaptive_cutoff_resume_and_update(oracle, tmp_path):
+    """gpu_implementation/es.py on the engine surface: antithetic offspring at the scheduled power, the update of es.py:227-246, the
+    adaptive cutoff of es.py:273-276, snapshot.pkl resume (theta AND optimizer state) -- two iterations in one go equal one iteration + a
+    resumed one, bit for bit; the first update equals the reference formulas applied to the recorded returns."""
+    import pickle
+    from oracle_engine import OracleEngine
+    from dne_hip import es, es_gpu, policies
+    noise = es.SharedNoiseTable(count=2_500_000)
+    exp = _es_gpu_exp()
+
+    def run(log_dir, iters, eng=None):
+        eng = eng or OracleEngine(0, ref_count=8)
+        return es_gpu.main(str(log_dir), engine=eng, noise=noise, seed=4, max_iters=iters, **exp), eng
+
+    st1, e1 = run(tmp_path / "one", 1)
+    assert st1.it == 1 and st1.optimizer[2] == 1 and st1.timesteps_so_far > 0 and st1.num_frames == 4 * st1.timesteps_so_far
+    # the cutoff grew: every pair's two episodes together reach the 6-step limit (es.py:274 sums a pair's lengths), 100 % > 30 %
+    assert st1.tslimit == 12 and st1.adaptive_tslimit and st1.tslimit_max == 20
+    # what was evaluated and how it was turned into a step: the engine calls in order (initial test episodes, offspring, update, test episodes)
+    kinds = [c[0] for c in e1.calls]
+    assert kinds == ["es_eval", "es_eval", "es_update", "es_eval"] and e1.calls[1][1] == 3 and e1.calls[2][1] == 3
+    th0 = policies.xavier_flat(18, 4)
+    st2, e2 = run(tmp_path / "two", 2)
+    assert st2.it == 2 and st2.optimizer[2] == 2
+    st1b, _ = run(tmp_path / "one", 1)                       # resumes from snapshot.pkl of the one-iteration run
+    assert st1b.it == 2 and st1b.tslimit == st2.tslimit == 20
+    assert np.array_equal(st1b.theta, st2.theta) and not np.array_equal(st2.theta, th0)
+    for a, b in zip(st1b.optimizer[:2], st2.optimizer[:2]):
+        assert np.array_equal(a, b)
+    assert st1b.timesteps_so_far == st2.timesteps_so_far
+    snap = pickle.load(open(tmp_path / "two" / "snapshot.pkl", "rb"))
+    assert snap.it == 2 and np.array_equal(snap.theta, st2.theta) and snap.mutation_power.value(iteration=2) == pytest.approx(0.015)
+    log = open(tmp_path / "two" / "log.txt").read()
+    for key in ("MutationPower", "TimestepLimitPerEpisode", "PopulationEpRewMedian", "TestRewMean", "InitialRewMax", "TimestepsPerSecondThisIter", "TimestepsComputed"):
+        assert key in log
+    assert "Increased threshold to 12" in log and "Increased threshold to 20" in log
+
+
+def test_gpu_tree_es_first_update_is_the_reference_formula(oracle, tmp_path):
+    """One iteration of es_gpu.main against the formulas written out with numpy: compute_centered_ranks (es.py:112-121), the weighted sum
+    over noise rows divided by 2N (es.py:236-244), Adam on -g + l2coeff * theta (es.py:246, neuroevolution/optimizers.py:55-72)."""
+    from oracle_engine import OracleEngine
+    from dne_hip import es, es_gpu, policies
+    noise = es.SharedNoiseTable(count=2_500_000)
+    exp = _es_gpu_exp(episode_cutoff_mode=8, mutation_power=0.02)
+    eng = OracleEngine(0, ref_count=8)
+    seen = {}
+    inner = eng.es_update
+
+    def spy(idx, rets, sg, *a, **k):
+        seen["idx"], seen["rets"] = np.array(idx), np.array(rets, np.float32).reshape(-1, 2)
+        return inner(idx, rets, sg, *a, **k)
+    eng.es_update = spy
+    st = es_gpu.main(str(tmp_path), engine=eng, noise=noise, seed=9, max_iters=1, **exp)
+    th0 = policies.xavier_flat(18, 9)
+    r = seen["rets"]
+    ranks = np.empty(r.size, dtype=int); ranks[r.ravel().argsort(kind="stable")] = np.arange(r.size)
+    proc = (ranks.reshape(r.shape).astype(np.float32) / (r.size - 1)) - .5
+    w = proc[:, 0] - proc[:, 1]
+    g = np.dot(w.astype(np.float32), np.stack([noise.noise[i:i + th0.size] for i in seen["idx"]])) / r.size
+    grad = -g + 0.005 * th0
+    m = 0.1 * grad; v = 0.001 * grad * grad
+    a = 0.01 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    want = th0 + (-a * m / (np.sqrt(v) + 1e-8))
+    # Adam's first step is -stepsize * grad / (|grad| + eps'): where |grad| is itself of rounding size the step's sign is not defined,
+    # everywhere else the two agree to float32 rounding
+    far = np.abs(st.theta - want) > 1e-6
+    assert far.mean() < 1e-3 and np.abs(grad[far]).max(initial=0.0) < 1e-5 and np.abs(st.theta - th0).max() > 1e-3
+    assert st.tslimit == 8 and not st.adaptive_tslimit
+
+
+def test_gpu_tree_es_sgd_is_the_engine_sgd_at_a_rescaled_stepsize():
+    from dne_hip import es_gpu
+    assert es_gpu.engine_optimizer({"type": "sgd", "args": {"stepsize": 0.01, "momentum": 0.9}})[:3] == ("sgd", pytest.approx(0.1), 0.9)
+    assert es_gpu.engine_optimizer({"type": "adam", "args": {"stepsize": 0.01}}) == ("adam", 0.01, 0.9, 0.999, 1e-08)
+    # v' = mu v + g, step = -lr v'  ==  u' = mu u + (1 - mu) g, step = -(lr / (1 - mu)) u'   with u = (1 - mu) v
+    mu, lr, v, u, th_a, th_b = 0.9, 0.01, 0.0, 0.0, 1.0, 1.0
+    for g in (0.3, -0.2, 0.5, 0.1):
+        v = mu * v + g; th_a -= lr * v
+        u = mu * u + (1 - mu) * g; th_b -= lr / (1 - mu) * u
+    assert abs(th_a - th_b) < 1e-12
+    with pytest.raises(NotImplementedError):
+        es_gpu.main("/tmp/_dne_es_gpu_nolog", engine=object(), noise=object(), load_from="x", population_size=2)

@@ -674,3 +674,25 @@ def test_gpu_tree_genomes_bit_exact(ga_engine, oracle, small_noise):
     for i, c in enumerate(chains):
         r = O.rollout(L, O.ga_rebuild(L, small_noise, c, 0.002), None, seeds[i], 50)
         assert (ret[i], sg[i], ln[i]) == r[:3], i
+
+
+def test_gpu_tree_es_driver_equals_the_oracle_engine(hip, oracle, tmp_path):
+    """dne_hip/es_gpu.py (gpu_implementation/es.py: scheduled mutation power, adaptive cutoff, test episodes of the unperturbed theta as
+    pairs at power 0, snapshot.pkl) on the HIP engine against the same driver on the oracle behind the same method surface: two
+    iterations, theta and Adam's state bit for bit, every counter equal."""
+    from oracle_engine import OracleEngine
+    from dne_hip import es, es_gpu
+    noise = es.SharedNoiseTable(count=2_500_000)
+    exp = {"game": "frostbite", "model": "ModelVirtualBN", "num_test_episodes": 3, "population_size": 8, "timesteps": 10 ** 9,
+           "episode_cutoff_mode": "adaptive:10,0.3,2,40", "return_proc_mode": "centered_rank", "l2coeff": 0.005,
+           "mutation_power": {"type": "LinearSchedule", "schedule": 4, "initial_p": 0.02, "final_p": 0.01, "field": "iteration"},
+           "optimizer": {"args": {"stepsize": 0.01}, "type": "adam"}}
+    e = hip.Engine(hip.KIND_ES, NACT, max_members=8, ref_count=NREF)
+    try:
+        sg = es_gpu.main(str(tmp_path / "gpu"), engine=e, noise=noise, seed=2, max_iters=2, **exp)
+    finally:
+        e.close()
+    so = es_gpu.main(str(tmp_path / "cpu"), engine=OracleEngine(0, ref_count=NREF, max_members=8), noise=noise, seed=2, max_iters=2, **exp)
+    assert sg.it == so.it == 2 and sg.tslimit == so.tslimit and sg.timesteps_so_far == so.timesteps_so_far and sg.num_frames == so.num_frames
+    assert np.array_equal(sg.theta, so.theta)
+    assert sg.optimizer[2] == so.optimizer[2] == 2 and np.array_equal(sg.optimizer[0], so.optimizer[0]) and np.array_equal(sg.optimizer[1], so.optimizer[1])
