@@ -365,6 +365,7 @@ constexpr int ENV_MAX_ROWS = 80;   // 45 classes + at most 3 extra keys for each
 // non-negative x here: a padded tap is an exact no-op, so are the two / two always-zero taps rounds 1-5 carried at 5 / 7 per pixel and dropped in
 // round 6 -- same bits, 20 % / 29 % fewer f64 multiply-adds in the renderer, which is bound by its own VALU stream: profiles/r06_pmc_lockstep_kernels.json)
 constexpr int RS_KH = 4, RS_KV = 5;
+typedef float f32q __attribute__((ext_vector_type(4)));
 struct ResizeLds {
     double kh[84 * RS_KH];
     double kv[84 * RS_KV];
@@ -427,14 +428,25 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     const int yy0 = band * 84 / nbands, yy1 = (band + 1) * 84 / nbands;
     const int ylo = s.R.ymin[yy0], yhi = s.R.ymin[yy1 - 1] + RS_KV;
     const int out0 = yy0 * 84, nout = (yy1 - yy0) * 84;
-    constexpr int VP = 7;
-    uint32_t old[VP] = {};
-    const bool pre = !fill && nthr * VP >= nout;
+    // The vertical pass works on QUADS of output pixels (four neighbours of one output row: 21 quads per row): a quad shares its row's five
+    // coefficients and five source-row offsets, reads the four floats of a tap as ONE 16-byte LDS word and moves its four stack words as one
+    // 16-byte load and store -- 4 LDS and 21 vector instructions per pixel instead of 16 and 46 (rounds 1-6a: one pixel per thread-step; the
+    // pass was 6.5 of a full-width workgroup's 16.1 us, bound by its own instruction stream: tools/render_phase_clock.py).  Per pixel the
+    // same five products are added in the same order: same bits.
+    constexpr int QPR = 21, VI = 4;                 // quads per output row; quads in flight per thread
+    const int nitems = (yy1 - yy0) * QPR;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 oldq[VI];
+#pragma unroll
+    for (int j = 0; j < VI; j++) oldq[j] = u32x4{0u, 0u, 0u, 0u};
+    const u32x4 *stack_in4 = (const u32x4 *)(stack_in + out0);   // (out0 and every row are multiples of 84 = 4 * 21 words: 16-byte aligned)
+    u32x4 *stack4 = (u32x4 *)(stack + out0);
+    const bool pre = !fill && nthr * 2 >= nitems;   // the whole band's old words fit two quads per thread: asked for before the first barrier
     if (pre) {
 #pragma unroll
-        for (int j = 0; j < VP; j++) {
-            const int i = tid + j * nthr;
-            old[j] = i < nout ? stack_in[out0 + i] : 0u;
+        for (int j = 0; j < 2; j++) {
+            const int it = tid + j * nthr;
+            if (it < nitems) oldq[j] = stack_in4[it];
         }
     }
     if (tid < 192) s.slot_of_key[tid] = -1;
@@ -515,31 +527,36 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     }
     __syncthreads();
     DNE_PHASE(0, 3);
-    // vertical pass + u8 truncation + stack shift.  The old stack words are fetched VP at a time (all of them before
-    // the first barrier when the workgroup covers the stack in one go) so that the global-load latency is paid once
-    // per chunk, not once per pixel.  (A branch-free form -- threads past the end recompute the last pixel, only the store predicated, so that
-    // the VP outputs' LDS round trips overlap -- needs more than the 80 registers three workgroups per CU leave: it spills.  Not kept.)
-    for (int base = 0; base < nout; base += nthr * VP) {
+    // vertical pass + u8 truncation + stack shift, a quad at a time (above).  The old stack words of a thread's VI quads are asked for together
+    // (all of them before the first barrier when two per thread cover the band) so that the global-load latency is paid once per chunk.
+    for (int base = 0; base < nitems; base += nthr * VI) {
         if (!pre && !fill) {
 #pragma unroll
-            for (int j = 0; j < VP; j++) {
-                const int i = base + tid + j * nthr;
-                old[j] = i < nout ? stack_in[out0 + i] : 0u;
+            for (int j = 0; j < VI; j++) {
+                const int it = base + tid + j * nthr;
+                if (it < nitems) oldq[j] = stack_in4[it];
             }
         }
 #pragma unroll
-        for (int j = 0; j < VP; j++) {
-            const int i = base + tid + j * nthr;
-            if (i < nout) {
-                const int yy = yy0 + i / 84, xx = i % 84;
+        for (int j = 0; j < VI; j++) {
+            const int it = base + tid + j * nthr;
+            if (it < nitems) {
+                const int r = it / QPR, q = it - r * QPR, yy = yy0 + r;
                 const uint16_t *sl = s.off_of_y + s.R.ymin[yy];
                 const double *k = s.R.kv + yy * RS_KV;
-                const char *col = (const char *)(s.tmp + xx);
-                double acc = 0.0;
+                const char *col = (const char *)s.tmp + q * 16;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-                for (int t = 0; t < RS_KV; t++) acc = acc + (double)*(const float *)(col + sl[t]) * k[t];
-                const uint32_t pix = (uint32_t)(uint8_t)(float)acc;
-                stack[out0 + i] = fill ? pix * 0x01010101u : ((old[j] >> 8) | (pix << 24));
+                for (int t = 0; t < RS_KV; t++) {
+                    const f32q v = *(const f32q *)(col + sl[t]);
+                    const double kt = k[t];
+                    a0 = a0 + (double)v[0] * kt;
+                    a1 = a1 + (double)v[1] * kt;
+                    a2 = a2 + (double)v[2] * kt;
+                    a3 = a3 + (double)v[3] * kt;
+                }
+                const u32x4 pix = {(uint32_t)(uint8_t)(float)a0, (uint32_t)(uint8_t)(float)a1, (uint32_t)(uint8_t)(float)a2, (uint32_t)(uint8_t)(float)a3};
+                stack4[it] = fill ? pix * 0x01010101u : ((oldq[j] >> 8) | (pix << 24));
             }
         }
     }
