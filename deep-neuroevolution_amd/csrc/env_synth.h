@@ -339,18 +339,49 @@ __device__ __forceinline__ void synth_row_desc(const PixState &p, int y, int &bg
     r_col = hud ? 11 : sky ? 13 : 9;
 }
 
-__device__ __forceinline__ int synth_row_pixel(int x, int bg, int p_off, int p_len, int p_period, int p_recip, int p_width,
-                                               int p_col, uint32_t p_mask, int r_lo, int r_len, int r_col, int s_on, int s_px) {
+// the three layers of a row, each for one pixel x: the caller skips a layer the row does not have (wave-uniform tests on the description)
+__device__ __forceinline__ int synth_row_pattern(int x, int c, int p_off, int p_len, int p_period, int p_recip, int p_width, int p_col, uint32_t p_mask) {
     int rel = x - p_off;
     rel += rel < 0 ? 160 : 0;
     const int cell = (rel * p_recip) >> 16;              // rel / p_period for 0 <= rel < 160 and the periods 8, 10, 40
     const int rem = rel - cell * p_period;
     const bool hit = (rel < p_len) & (rem < p_width) & (((p_mask >> cell) & 1u) != 0u);
-    int c = hit ? p_col : bg;
-    c = (unsigned)(x - r_lo) < (unsigned)r_len ? r_col : c;
+    return hit ? p_col : c;
+}
+__device__ __forceinline__ int synth_row_span(int x, int c, int r_lo, int r_len, int r_col) { return (unsigned)(x - r_lo) < (unsigned)r_len ? r_col : c; }
+__device__ __forceinline__ int synth_row_sprite(int x, int c, int s_px) {
     int sx = x - s_px;
     sx += sx < 0 ? 160 : 0;
-    return ((s_on != 0) & (sx < 8)) ? 8 : c;
+    return sx < 8 ? 8 : c;
+}
+
+__device__ __forceinline__ int synth_row_pixel(int x, int bg, int p_off, int p_len, int p_period, int p_recip, int p_width,
+                                               int p_col, uint32_t p_mask, int r_lo, int r_len, int r_col, int s_on, int s_px) {
+    int c = synth_row_pattern(x, bg, p_off, p_len, p_period, p_recip, p_width, p_col, p_mask);
+    c = synth_row_span(x, c, r_lo, r_len, r_col);
+    return s_on != 0 ? synth_row_sprite(x, c, s_px) : c;
+}
+
+// pixels lane, lane + 64, lane + 128 of a row from its description (three int4 words, the same in every lane).  Most rows have no pattern
+// (shore, sky above the igloo, 20 of a water band's 32 rows), no span and no sprite: an empty pattern (p_len <= 0), an empty span (r_len <= 0)
+// and a sprite that is off change nothing, so those layers are skipped as a whole -- tested once per row on the scalar unit.
+__device__ __forceinline__ void synth_row_paint3(int lane, const int4 &q0, const int4 &q1, const int4 &q2, int &c0, int &c1, int &c2) {
+    c0 = c1 = c2 = q0.x;
+    if (__builtin_amdgcn_readfirstlane(q0.z) > 0) {
+        c0 = synth_row_pattern(lane, c0, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, (uint32_t)q1.w);
+        c1 = synth_row_pattern(lane + 64, c1, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, (uint32_t)q1.w);
+        c2 = synth_row_pattern(lane + 128, c2, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, (uint32_t)q1.w);
+    }
+    if (__builtin_amdgcn_readfirstlane(q2.y) > 0) {
+        c0 = synth_row_span(lane, c0, q2.x, q2.y, q2.z);
+        c1 = synth_row_span(lane + 64, c1, q2.x, q2.y, q2.z);
+        c2 = synth_row_span(lane + 128, c2, q2.x, q2.y, q2.z);
+    }
+    if (__builtin_amdgcn_readfirstlane(q2.w) & 1) {
+        c0 = synth_row_sprite(lane, c0, q2.w >> 1);
+        c1 = synth_row_sprite(lane + 64, c1, q2.w >> 1);
+        c2 = synth_row_sprite(lane + 128, c2, q2.w >> 1);
+    }
 }
 
 // Screen rows fall into 45 static classes (HUD bands, sky, igloo block rows, shore, 4-row strips of the
@@ -472,16 +503,15 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     // waves describe all <= 80 rows of both frames at once (rounds 2-5: one WAVE per row on the scalar unit, 170 scalar instructions per row,
     // 7.5 of a full-width workgroup's 19.3 us -- tools/render_phase_clock.py).  The 13 fields of a description lie in the part of LDS the
     // horizontal pass will fill later (tmp: a barrier lies between), 12 ints per (row, frame): sprite flag and position share one.
-    const PixState pp = synth_pix_uniform(synth_pix_state(s.ram_prev)), pc = synth_pix_uniform(synth_pix_state(s.ram_cur));
     int *desc = (int *)s.tmp;
     static_assert(ENV_MAX_ROWS * 2 * 12 <= ENV_MAX_ROWS * 84, "the row descriptions fit the region they borrow");
-    {
+    if (tid < 256) {                                    // (the four waves that describe rows unpack the RAM snapshots; the others go straight to the barrier)
         const int f = tid >> 7, u = tid & 127;          // threads 0..127: the previous frame's rows, 128..255: the current frame's
-        if (tid < 256 && u < nu) {
+        const PixState pf = synth_pix_uniform(synth_pix_state(f == 0 ? s.ram_prev : s.ram_cur));   // (f is the same in every lane of a wave)
+        if (u < nu) {
             const int y = s.rep_y[u];
             DNE_ROW_FIELDS(d_);
-            if (f == 0) synth_row_desc(pp, y, DNE_ROW_ARGS(d_));
-            else synth_row_desc(pc, y, DNE_ROW_ARGS(d_));
+            synth_row_desc(pf, y, DNE_ROW_ARGS(d_));
             int4 *o = (int4 *)(desc + (u * 2 + f) * 12);
             o[0] = make_int4(d_bg, d_p_off, d_p_len, d_p_period);
             o[1] = make_int4(d_p_recip, d_p_width, d_p_col, (int)d_p_mask);
@@ -493,26 +523,23 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6, lane = tid & 63;
     for (int u = wave; u < nu; u += nwave) {
         const int4 *da = (const int4 *)(desc + u * 24);
-#define DNE_ROW_FROM(q0, q1, q2) q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, (uint32_t)q1.w, q2.x, q2.y, q2.z, q2.w & 1, q2.w >> 1
         int c0, c1, c2;
         {   // the previous frame's colours first, then the current frame's: one description live at a time (register footprint: three workgroups per CU)
             const int4 a0 = da[0], a1 = da[1], a2 = da[2];
-            c0 = synth_row_pixel(lane, DNE_ROW_FROM(a0, a1, a2)) << 4;
-            c1 = synth_row_pixel(lane + 64, DNE_ROW_FROM(a0, a1, a2)) << 4;
-            c2 = synth_row_pixel(lane + 128, DNE_ROW_FROM(a0, a1, a2)) << 4;
+            synth_row_paint3(lane, a0, a1, a2, c0, c1, c2);
+            c0 <<= 4; c1 <<= 4; c2 <<= 4;
         }
         __builtin_amdgcn_sched_barrier(0);
         {
             const int4 b0 = da[3], b1 = da[4], b2 = da[5];
-            c0 |= synth_row_pixel(lane, DNE_ROW_FROM(b0, b1, b2));
-            c1 |= synth_row_pixel(lane + 64, DNE_ROW_FROM(b0, b1, b2));
-            c2 |= synth_row_pixel(lane + 128, DNE_ROW_FROM(b0, b1, b2));
+            int d0, d1, d2;
+            synth_row_paint3(lane, b0, b1, b2, d0, d1, d2);
+            c0 |= d0; c1 |= d1; c2 |= d2;
         }
         uint8_t *row = s.img + u * 160;
         row[lane] = (uint8_t)c0;
         row[lane + 64] = (uint8_t)c1;
         if (lane < 32) row[lane + 128] = (uint8_t)c2;
-#undef DNE_ROW_FROM
     }
     __syncthreads();
     DNE_PHASE(0, 2);

@@ -5,7 +5,7 @@
 set -u
 TAG=${1:-r06q1}; R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 C=$R/deep-neuroevolution_amd/csrc
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edges.py -x -q -m gpu 2>&1 | tail -3 | tee $O/parity.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edges.py -x -q -m gpu 2>&1 | grep -v '^ROCm\|^Hostname\|^Librccl\|^RCCL\|^HIP version' | tail -3 | tee $O/parity.txt
 grep -q failed $O/parity.txt && exit 1
 DNE_LIB_PATH=$C/libdne_hip_clock.so timeout 200 python tools/render_phase_clock.py 2500 2>&1 | tail -1 | tee $O/render_phase.json
 for round in 1 2; do
