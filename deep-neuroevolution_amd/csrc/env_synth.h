@@ -543,14 +543,26 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     }
     __syncthreads();
     DNE_PHASE(0, 2);
-    for (int i = tid; i < nu * 84; i += nthr) {   // horizontal pass over the unique rows
-        const int u = i / 84, xx = i % 84;
-        const uint8_t *px = s.img + u * 160 + s.R.xmin[xx];
-        const double *k = s.R.kh + xx * RS_KH;
-        double acc = 0.0;
-#pragma unroll
-        for (int t = 0; t < RS_KH; t++) acc = acc + (double)s.R.gray2[px[t]] * k[t];
-        s.tmp[i] = (float)acc;
+    {   // horizontal pass over the unique rows: a thread keeps ONE output column (its window start and four coefficients in registers) and walks
+        // down the unique rows, nthr / 84 rows apart -- no index arithmetic and no coefficient reads per output (rounds 1-6a: output i = tid + k * nthr,
+        // a division and four 8-byte LDS reads each).  The same four products added in the same order: same bits.
+        const int G = nthr / 84;
+        if (tid < G * 84) {
+            const int u0 = tid / 84, xx = tid - u0 * 84;
+            const int x0 = s.R.xmin[xx];
+            const double *k = s.R.kh + xx * RS_KH;
+            const double k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3];
+            static_assert(RS_KH == 4, "the horizontal pass is written out for four taps");
+            for (int u = u0; u < nu; u += G) {
+                const uint8_t *px = s.img + u * 160 + x0;
+                double acc = 0.0;
+                acc = acc + (double)s.R.gray2[px[0]] * k0;
+                acc = acc + (double)s.R.gray2[px[1]] * k1;
+                acc = acc + (double)s.R.gray2[px[2]] * k2;
+                acc = acc + (double)s.R.gray2[px[3]] * k3;
+                s.tmp[u * 84 + xx] = (float)acc;
+            }
+        }
     }
     __syncthreads();
     DNE_PHASE(0, 3);
