@@ -590,6 +590,14 @@ struct dne_handle {
     int ring_min = 1000;             // DNE_RING_MIN: k_fc_ring needs this many active pairs on the rank whatever their density (below, its workgroups -- eight units, one per CU --
                                      // no longer fill the chip: a 625-pair share measured 61.6 ms per generation on the ring against 57.8 on k_fc_duo, profiles/r06_shard_ab.jsonl)
     int ring_on = 1;                 // DNE_FC_RING (round 5): k_fc_ring instead of k_fc_duo -- the workgroup's noise rows through an LDS ring filled by LDS-DMA, the base rows from a column-permuted copy of the fc matrix; 1: from DNE_DUO_SOLO_BELOW active pairs (1500) upwards, 2: in the whole k_fc_duo range (measured slower in the sparse part: 239 vs 233 ms), 0: k_fc_duo everywhere
+    float *noise_pre = nullptr;      // the noise table scaled by the evaluation's sigma, fl(sigma * eps) entry by entry (k_scale_table): k_fc_ring<true>'s DMA source.  Built the first
+                                     // time an evaluation enters the ring's range at that sigma (ES runs keep one sigma: once per run, 0.4 ms), dropped with the table
+    size_t noise_pre_count = 0;      // entries of the table the copy was made from (0: none)
+    float noise_pre_sigma = 0.0f;    // the sigma it holds
+    int ring_pre = 1;                // DNE_RING_PRE: 0 = the ring multiplies every row by sigma itself (rounds 5-6a)
+    bool ring_pre_now = false;       // this evaluation's ring launches read noise_pre
+    bool pair_sigma_uniform = false; // every pair of the member set is (+s, -s) with ONE s (dne_set_members)
+    float pair_sigma = 0.0f;
     float *theta_perm = nullptr;     // [3872 + 16][256]: base slot 0's fc matrix, every row stored as columns l, l+64, l+128, l+192 per lane (k_theta_perm, once per evaluation)
     int duo_fat = 1;                 // DNE_DUO_FAT: k_fc_duo with a register footprint past 256 per lane = at most one of its workgroups per CU (it streams as fast from one), so the other windows' kernels always find room beside it
     int fc_sub = 1;                  // DNE_FC_SUB (ES 2, GA 1): the sub-slice fc (k_fc_sub: one wave per 128 / 120-row chain) in the mid range -- 0 off, 1 GA children (materialised), 2 also ES pairs
@@ -1013,7 +1021,7 @@ extern "C" int dne_create(const dne_config *cfg, dne_handle **out) {
     env_int("DNE_FC_PRIO", 0, 3, &h->fc_prio);
     env_int("DNE_DUO_SWEEP", 0, 2, &h->duo_sweep);
     env_int("DNE_DUO_SYNC", 1, 8, &h->duo_sync);
-    env_int("DNE_DUO_FAT", 0, 1, &h->duo_fat); env_int("DNE_FC_RING", 0, 2, &h->ring_on); env_int("DNE_RING_MIN", 0, 1 << 30, &h->ring_min); env_int("DNE_SUB_RENDER_FUSED", 0, 1, &h->sub_render_fused);
+    env_int("DNE_DUO_FAT", 0, 1, &h->duo_fat); env_int("DNE_FC_RING", 0, 2, &h->ring_on); env_int("DNE_RING_MIN", 0, 1 << 30, &h->ring_min); env_int("DNE_RING_PRE", 0, 1, &h->ring_pre); env_int("DNE_SUB_RENDER_FUSED", 0, 1, &h->sub_render_fused);
     env_int("DNE_BURST", 1, 256, &h->burst);
     env_int("DNE_BURST_TAIL", 1, 256, &h->burst_tail);
     env_int("DNE_DUO_GRID", 0, 1 << 16, &h->duo_grid);
@@ -1248,7 +1256,8 @@ extern "C" int dne_noise_alloc(dne_handle *h, size_t count) {
     DeviceGuard dg(h);
     if (count == 0) return h->fail("dne_noise_alloc: empty table");
     HCHECK(h, h->release(h->noise));
-    h->noise_count = 0;
+    HCHECK(h, h->release(h->noise_pre));
+    h->noise_count = 0; h->noise_pre_count = 0;
     // the streaming fc kernels (k_fc_duo, k_fc_sub) fetch one 8-row block past a unit's last row and never use it: for small action
     // counts that block ends behind the member's parameter slice, i.e. up to OVERFETCH_FLOATS behind the table's last legal slice
     HCHECK(h, h->alloc(&h->noise, count + OVERFETCH_FLOATS, "noise"));
@@ -1261,6 +1270,7 @@ extern "C" int dne_noise_alloc(dne_handle *h, size_t count) {
 extern "C" int dne_noise_write(dne_handle *h, size_t offset, const float *host, size_t count) {
     DeviceGuard dg(h);
     if (!h->noise || offset + count > h->noise_count) return h->fail("dne_noise_write: [%zu, %zu) outside the table of %zu", offset, offset + count, h->noise_count);
+    h->noise_pre_count = 0;   // the scaled copy is stale
     return copy_h2d(h, h->noise + offset, host, count * sizeof(float));
 }
 
@@ -1439,6 +1449,9 @@ extern "C" int dne_set_members(dne_handle *h, int n, const int32_t *slot, const 
     h->antithetic_slot0 = h->uniform_base && slot[0] == 0 && n % 2 == 0;
     for (int i = 0; i + 1 < n && h->antithetic_slot0; i += 2)
         h->antithetic_slot0 = off[i] == off[i + 1] && scale[i] == -scale[i + 1];
+    h->pair_sigma = n > 0 ? scale[0] : 0.0f;
+    h->pair_sigma_uniform = h->antithetic_slot0;
+    for (int i = 0; i < n && h->pair_sigma_uniform; i += 2) h->pair_sigma_uniform = scale[i] == scale[0];
     h->members_materialized = false;
     h->host_slot.assign(slot, slot + n); h->host_off.assign(off, off + n); h->host_scale.assign(scale, scale + n);
     return 0;
@@ -1683,8 +1696,8 @@ static void launch_fc(dne_handle *h, const int *list, int count, int gsize, floa
         const int flags = h->duo_lag | (solo ? 256 : 0) | (h->fc_prio << 9) | ((h->duo_sync - 1) << 11);
         if (h->ring_now) {   // one unit per wave, eight units per workgroup whatever the regime
             const int ring_blocks = std::min((n_units + 7) / 8, duo_grid);
-            if (h->duo_fat) hipLaunchKernelGGL((k_fc_ring<true, 8>), dim3(ring_blocks), dim3(576), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, (const float *)h->theta_perm, h->fc_prio << 9);
-            else hipLaunchKernelGGL((k_fc_ring<false, 8>), dim3(ring_blocks), dim3(576), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, (const float *)h->theta_perm, h->fc_prio << 9);
+            if (h->ring_pre_now) hipLaunchKernelGGL((k_fc_ring<true, 8>), dim3(ring_blocks), dim3(576), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, (const float *)h->theta_perm, h->fc_prio << 9, (const float *)h->noise_pre);
+            else hipLaunchKernelGGL((k_fc_ring<false, 8>), dim3(ring_blocks), dim3(576), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, (const float *)h->theta_perm, h->fc_prio << 9, (const float *)A.noise);
         }
         else if (sweep && h->duo_fat) hipLaunchKernelGGL((k_fc_duo<2, true, true, 8, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, flags);
         else if (sweep) hipLaunchKernelGGL((k_fc_duo<2, true, true>), dim3(blocks), dim3(256), 0, st, A, order, n_units, (const float *)h->y2, h->y3t, flags);
@@ -1849,6 +1862,25 @@ static int eval_core(dne_handle *h, int n, int gsize, int tslimit, const uint32_
     auto ring_dense = [&](int t) { return (double)t * h->dense_scale >= (double)h->duo_solo_below && t >= h->ring_min; };
     const bool ring_eval = duo_eval && h->L.kind == DNE_KIND_ES && gsize == 2 && h->theta_perm && h->antithetic_slot0 && h->duo_sweep &&
                            (h->ring_on > 1 || ring_dense(groups)) && (ring_dense(groups) || h->duo_sweep > 1);
+    // the ring's DMA source: the table scaled by this evaluation's sigma (k_fc_ring<true>), made once per (table, sigma)
+    h->ring_pre_now = false;
+    if (ring_eval && h->ring_pre && h->pair_sigma_uniform) {
+        if (!h->noise_pre && h->alloc(&h->noise_pre, h->noise_count + OVERFETCH_FLOATS, "noise_pre")) {
+            h->trace("no room for the scaled table: the ring scales its rows itself");
+            (void)hipGetLastError(); h->noise_pre = nullptr; h->ring_pre = 0;
+        }
+        if (h->noise_pre) {
+            if (h->noise_pre_count != h->noise_count || h->noise_pre_sigma != h->pair_sigma) {
+                static_assert(OVERFETCH_FLOATS % 4 == 0, "k_scale_table moves 16 bytes per step");
+                const size_t n4 = (h->noise_count + OVERFETCH_FLOATS) / 4;   // (a table whose count is not a multiple of four leaves its last 1-3 padding floats unscaled: zeros either way)
+                hipLaunchKernelGGL(k_scale_table, dim3(256 * 8), dim3(256), 0, h->stream, (const float *)h->noise, h->noise_pre, n4, h->pair_sigma);
+                HCHECK(h, hipStreamSynchronize(h->stream));   // the windows' streams start behind the host
+                h->noise_pre_count = h->noise_count; h->noise_pre_sigma = h->pair_sigma;
+                h->trace("noise table scaled by %g for the ring", (double)h->pair_sigma);
+            }
+            h->ring_pre_now = true;
+        }
+    }
     while (total > 0 && t < tslimit) {
         const int burst = std::min(total <= h->fc_tail_max ? h->burst_tail : h->burst, tslimit - t);   // lock-steps until the next compaction
         const int nsub = pick_nsub(total);

@@ -458,7 +458,7 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
     const int tid = threadIdx.x, nthr = blockDim.x;   // 256 threads normally, 1024 when few members remain
     const int yy0 = band * 84 / nbands, yy1 = (band + 1) * 84 / nbands;
     const int ylo = s.R.ymin[yy0], yhi = s.R.ymin[yy1 - 1] + RS_KV;
-    const int out0 = yy0 * 84, nout = (yy1 - yy0) * 84;
+    const int out0 = yy0 * 84;
     // The vertical pass works on QUADS of output pixels (four neighbours of one output row: 21 quads per row): a quad shares its row's five
     // coefficients and five source-row offsets, reads the four floats of a tap as ONE 16-byte LDS word and moves its four stack words as one
     // 16-byte load and store -- 4 LDS and 21 vector instructions per pixel instead of 16 and 46 (rounds 1-6a: one pixel per thread-step; the

@@ -1868,6 +1868,16 @@ __global__ __launch_bounds__(256) void k_theta_perm(const float *__restrict__ fc
     out[(size_t)r * 256 + t] = r < rows ? fcw[(size_t)r * 256 + (t >> 2) + 64 * (t & 3)] : 0.0f;
 }
 
+// out[i] = fl(sigma * table[i]) over the whole table (+ its over-fetch padding): k_fc_ring<true>'s source, once per sigma
+__global__ __launch_bounds__(256) void k_scale_table(const float *__restrict__ in, float *__restrict__ out, size_t n4, float sigma) {
+    const f32x4 *i4 = (const f32x4 *)in;
+    f32x4 *o4 = (f32x4 *)out;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = i4[i];
+        o4[i] = f32x4{sigma * v[0], sigma * v[1], sigma * v[2], sigma * v[3]};
+    }
+}
+
 // the same finishing touch for windows whose convolutions ran as other kernels (k_conv1 + k_conv2): y2 <- relu(bn2(y2)) in place
 __global__ __launch_bounds__(256) void k_y2_activate(FwdArgs A, const int *__restrict__ list, int gsize, float *__restrict__ y2) {
     const int g = list ? list[blockIdx.x / gsize] : blockIdx.x / gsize, member = g * gsize + blockIdx.x % gsize;
@@ -1914,9 +1924,12 @@ __device__ __forceinline__ void ring_x(f32x2 &x, unsigned vaddr) {   // (member 
 // 199-register k_conv12 wave still fits beside the three.  (A plain launch bound of (576, 1) makes the compiler pad to 129 registers,
 // three waves per SIMD: then nothing fits beside them.  An accumulation register named in an asm, k_fc_duo's way, splits the compiler's
 // budget 84 / 84 and it spills to AGPRs -- copying registers that loads are still writing.)
-template <bool FAT, int NW>
+// PRE (round 6): every pair of an ES evaluation is perturbed at the same sigma (es.py:412-419), so fl(sigma * eps) is a property of the TABLE: the ring's
+// DMAs then stream a copy of the table scaled once per sigma (k_scale_table; ring_noise = that copy) and a row's four v_pk_mul_f32 of twenty packed
+// instructions per step disappear -- the same single rounding, made earlier: same bits.  PRE = false: ring_noise = the table itself.
+template <bool PRE, int NW>
 __global__ __launch_bounds__((NW + 1) * 64) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_fc_ring(FwdArgs A, const int *__restrict__ order, int n_units, const float *__restrict__ y2,
-                                                     float *__restrict__ y3t, const float *__restrict__ theta_perm, int flags) {
+                                                     float *__restrict__ y3t, const float *__restrict__ theta_perm, int flags, const float *__restrict__ ring_noise) {
     constexpr int NV = 2, W = 8, NBLK = 968 / W, BPC = 64 / W, R = RING_SLOTS, PD = RING_PD;
     constexpr int ND = RING_SEG / 256;      // LDS-DMA instructions per segment (1 KB each), all issued by the loader wave
     static_assert(RING_SEG == W * 256, "one segment = one tick of the timeline");
@@ -1972,7 +1985,7 @@ __global__ __launch_bounds__((NW + 1) * 64) __attribute__((amdgpu_waves_per_eu(3
         if (kmax < 0) continue;                       // every unit of this item belongs to a finished pair (the same answer in every wave)
         K0 &= ~3ll;                                   // 16-byte-aligned DMA sources
         const int tmax = (int)((kmax - K0) >> 11) + NBLK;
-        const float *seg0 = A.noise + K0;             // segment 0
+        const float *seg0 = ring_noise + K0;          // segment 0
         int tau = 0, slot = 0;                        // the workgroup's time in ticks (= segments) and the ring slot of segment tau
         // segment j (clamped to the last one anybody reads) into slot sj: the loader wave's eight 1 KB pieces
         auto dma_seg = [&](int j, int sj) {
@@ -2107,7 +2120,8 @@ __global__ __launch_bounds__((NW + 1) * 64) __attribute__((amdgpu_waves_per_eu(3
                         const f32x2 sc = {scale0, scale0};
                         // fl(-sigma eps) = -fl(sigma eps): the second member's weight is base - p with the first member's p (es.py:415, 419)
                         const f32x2 tl0 = {t[I0][0], t[I0][1]}, th0 = {t[I0][2], t[I0][3]}, tl1 = {t[I1][0], t[I1][1]}, th1 = {t[I1][2], t[I1][3]};
-                        const f32x2 pl0 = sc * e[S0][0], ph0 = sc * e[S0][1], pl1 = sc * e[S1][0], ph1 = sc * e[S1][1];
+                        f32x2 pl0 = e[S0][0], ph0 = e[S0][1], pl1 = e[S1][0], ph1 = e[S1][1];
+                        if constexpr (!PRE) { pl0 = sc * pl0; ph0 = sc * ph0; pl1 = sc * pl1; ph1 = sc * ph1; }
                         const f32x2 a0 = tl0 + pl0, a1 = th0 + ph0, a2 = tl0 - pl0, a3 = th0 - ph0;
                         const f32x2 b0 = tl1 + pl1, b1 = th1 + ph1, b2 = tl1 - pl1, b3 = th1 - ph1;
                         const f32x2 xa0 = {xr[S0][0], xr[S0][0]}, xa1 = {xr[S0][1], xr[S0][1]}, xb0 = {xr[S1][0], xr[S1][0]}, xb1 = {xr[S1][1], xr[S1][1]};

@@ -174,6 +174,7 @@ _ES_STEP_KNOBS = [
     {"DNE_FC_RING": "2", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_CONV_FUSED_MIN": "1"},   # ... behind k_conv12, which leaves relu(bn2(y2)) itself
     {"DNE_FC_RING": "2", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_CONV_FUSED": "0", "DNE_CONV12T_MAX": "0"},   # ... behind k_conv1 + k_conv2
     {"DNE_FC_RING": "1", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_DUO_SOLO_BELOW": "0", "DNE_RING_MIN": "0", "DNE_NSUB": "2"},   # ... two windows, each with its own unit order
+    {"DNE_FC_RING": "2", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1", "DNE_RING_PRE": "0"},   # ... scaling its noise rows itself (k_fc_ring<false>: the path an engine takes when the table's scaled copy does not fit; the cases above stream the copy)
     {"DNE_BURST": "5", "DNE_BURST_TAIL": "40"},                         # compaction of the active list every 5 / 40 lock-steps instead of 16
     {"DNE_FC_DUO": "0", "DNE_FC2_MIN": "2", "DNE_FC_TAIL_MAX": "1"},    # the duo path switched off: k_fc2
     {"DNE_FC_PAIRS": "1", "DNE_FC_TAIL_MAX": "1"},                      # k_fc<2> streaming kernel
