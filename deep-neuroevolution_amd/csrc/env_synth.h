@@ -496,6 +496,7 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
         }
     }
     __syncthreads();
+    DNE_PHASE(0, 5);
     if (myrow) s.off_of_y[tid] = (uint16_t)(s.slot_of_key[key] * (84 * 4));
     const int nu = min(s.misc[2], ENV_MAX_ROWS);
     // Row descriptions (round 6): one LANE per (unique row, frame) -- every row of each frame reduced to a background colour + one periodic
@@ -519,6 +520,7 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
         }
     }
     __syncthreads();
+    DNE_PHASE(0, 6);
     // one wave per unique row: the description is the same in every lane (a broadcast read), the per-pixel work a short branch-free select chain
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwave = nthr >> 6, lane = tid & 63;
     for (int u = wave; u < nu; u += nwave) {

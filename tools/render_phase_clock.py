@@ -30,6 +30,8 @@ ms = ["start", "tables+ram", "unique rows", "horizontal", "end"]
 b = buf[0]
 ok = [w for w in range(128) if b[w, 0] > 0 and b[w, 4] >= b[w, 0]]
 d = np.diff(b[ok][:, :5], axis=1) * 0.01
-print(json.dumps({"pairs": pairs, "knobs": sys.argv[2:], "workgroups": len(ok), "phase_us_mean": {ms[i + 1]: round(float(d[:, i].mean()), 2) for i in range(4)},
+fine = {"keys claimed": round(float(((b[ok][:, 5] - b[ok][:, 1]) * 0.01).mean()), 2), "rows described": round(float(((b[ok][:, 6] - b[ok][:, 5]) * 0.01).mean()), 2),
+        "rows painted": round(float(((b[ok][:, 2] - b[ok][:, 6]) * 0.01).mean()), 2)} if (b[ok][:, 5] > 0).all() and (b[ok][:, 6] > 0).all() else None
+print(json.dumps({"pairs": pairs, "unique_rows_split_us": fine, "knobs": sys.argv[2:], "workgroups": len(ok), "phase_us_mean": {ms[i + 1]: round(float(d[:, i].mean()), 2) for i in range(4)},
                   "phase_us_p90": {ms[i + 1]: round(float(np.percentile(d[:, i], 90)), 2) for i in range(4)},
                   "total_us_mean": round(float(d.sum(1).mean()), 2), "span_first_start_to_last_end_us": round(float((b[ok][:, 4].max() - b[ok][:, 0].min()) * 0.01), 1)}))
