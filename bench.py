@@ -56,7 +56,8 @@ REF_FLOP_PER_FRAME = 2 * (441 * 256 * 16 + 121 * 256 * 32 + 3872 * 256)
 FC_KERNELS = {   # the kernel behind the profiled ("full") fc launches of one evaluation (dne_profile.fc_full_kind)
     5: "dne::k_fc_ring<true, 8> (table-ordered streaming fc, round 5: eight (pair, k-slice) units that follow each other in the noise table per "
        "workgroup, one per wave, walking ONE table timeline; the table window they share lives in an LDS ring that a ninth, loader wave fills "
-       "by LDS-DMA five ticks ahead -- every noise row passes the CU's vector-memory path once per workgroup instead of once per unit; base rows "
+       "by LDS-DMA five ticks ahead -- since round 6 from a copy of the table scaled once per sigma, fl(sigma * eps) entry by entry -- every noise row passes "
+       "the CU's vector-memory path once per workgroup instead of once per unit; base rows "
        "from a column-permuted copy of the fc matrix (16 bytes per lane and row), activations relu(bn2(y2)) left by k_conv12 and read back "
        "as LDS broadcasts; one workgroup per CU; every window of a lock-step with >= 1500 active pairs on the rank; bn3 + output layer + "
        "argmax follow in k_out, outside the timed bracket)",
