@@ -233,6 +233,41 @@ def test_every_step_kernel_variant_is_bit_exact(knobs, oracle, small_noise, monk
         e.close()
 
 
+def test_ring_scaled_table_follows_sigma_and_table_writes(oracle, small_noise, monkeypatch):
+    """k_fc_ring<true> streams a copy of the noise table scaled by the evaluation's sigma (DNE_RING_PRE): the copy is
+    made again when the next evaluation comes with another sigma (a scheduled mutation power: dne_hip/es_gpu.py), with sigma 0, and after
+    a part of the table is rewritten (dne_noise_write) -- every evaluation against the oracle."""
+    from dne_hip import _lib
+    for k, v in {"DNE_FC_RING": "2", "DNE_FC_DUO_MIN": "2", "DNE_FC_TAIL_MAX": "1"}.items():
+        monkeypatch.setenv(k, v)
+    e = _lib.Engine(_lib.KIND_ES, NACT, max_members=10, ref_count=NREF)
+    try:
+        noise = small_noise.copy()
+        e.noise_upload(noise)
+        ref = oracle.get_ref_batch(seed=0, batch_size=NREF, nact=NACT)
+        e.set_ref_batch(ref)
+        L = oracle.layout(0, NACT)
+        th = oracle.es_init_theta(L, 0)
+        e.set_theta(th)
+        idx = np.array([11, 222_222, 2_900_001, 1_234_567, 42], np.int64)
+        seeds = (np.arange(10, dtype=np.uint32) * 2654435761).astype(np.uint32)
+
+        def check(sigma, steps):
+            ret, sg, ln = e.es_eval(idx, sigma, steps, seeds)
+            oret, osg, oln = oracle.es_eval(L, th, noise, idx, sigma, steps, ref, seeds)
+            assert np.array_equal(ln, oln) and np.array_equal(ret, oret) and np.array_equal(sg, osg), sigma
+        check(0.02, 40)
+        check(0.05, 40)                    # another sigma on the same engine: the scaled copy is rebuilt
+        check(0.0, 25)                     # sigma 0: every member is theta itself
+        check(0.02, 40)
+        chunk = np.random.RandomState(7).randn(300_000).astype(np.float32)
+        noise[200_000:500_000] = chunk     # rows of the second pair's slice change under the copy
+        e.noise_write(200_000, chunk)
+        check(0.02, 40)
+    finally:
+        e.close()
+
+
 def _crafted_rams(rs, n):
     """valid SynthAtari RAM snapshots that visit every branch of the renderer: sprite on every row
     band and wrapping over the screen edge, blink on/off, temperature / lives / score HUD, igloo 0..16 with and without the
