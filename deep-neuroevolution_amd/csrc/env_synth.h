@@ -343,8 +343,9 @@ __device__ __forceinline__ void synth_row_desc(const PixState &p, int y, int &bg
 __device__ __forceinline__ int synth_row_pattern(int x, int c, int p_off, int p_len, int p_period, int p_recip, int p_width, int p_col, uint32_t p_mask) {
     int rel = x - p_off;
     rel += rel < 0 ? 160 : 0;
-    const int cell = (rel * p_recip) >> 16;              // rel / p_period for 0 <= rel < 160 and the periods 8, 10, 40
-    const int rem = rel - cell * p_period;
+    // (24-bit multiplies: rel < 160, p_recip <= 8192, cell <= 20, p_period <= 40 -- v_mul_lo_u32 runs at a quarter of v_mul_u32_u24's rate)
+    const int cell = (int)(__umul24((unsigned)rel, (unsigned)p_recip) >> 16);   // rel / p_period for 0 <= rel < 160 and the periods 8, 10, 40
+    const int rem = rel - (int)__umul24((unsigned)cell, (unsigned)p_period);
     const bool hit = (rel < p_len) & (rem < p_width) & (((p_mask >> cell) & 1u) != 0u);
     return hit ? p_col : c;
 }
@@ -582,9 +583,9 @@ __device__ inline void synth_observe(EnvLds &s, uint32_t *__restrict__ stack, bo
         for (int j = 0; j < VI; j++) {
             const int it = base + tid + j * nthr;
             if (it < nitems) {
-                const int r = it / QPR, q = it - r * QPR, yy = yy0 + r;
+                const int r = (int)(__umul24((unsigned)it, 3121u) >> 16), q = it - r * QPR, yy = yy0 + r;   // it / 21, exact below 4096 (it < 1764), on the full-rate multiplier
                 const uint16_t *sl = s.off_of_y + s.R.ymin[yy];
-                const double *k = s.R.kv + yy * RS_KV;
+                const double *k = s.R.kv + __umul24((unsigned)yy, (unsigned)RS_KV);
                 const char *col = (const char *)s.tmp + q * 16;
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
