@@ -1108,15 +1108,19 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_get(float v) {
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
 }
+// The tree's value in LANE 63.  The two top levels (rows of 16 -> the wave) cross the rows by DPP broadcasts (row_bcast:15 into rows 1 and 3,
+// row_bcast:31 into rows 2 and 3) instead of two ds_bpermute round trips through the LDS pipe: row 3 ends with (R3 + R2) + (R1 + R0), bit for bit
+// the butterfly's (R0 + R1) + (R2 + R3) -- fp addition is commutative at every level.  The other rows hold partial sums: only lane 63 is read.
 __device__ __forceinline__ float wave_tree_sum(float v) {
     v = v + dpp_get<0xB1>(v);      // quad_perm [1,0,3,2]: lane ^ 1
     v = v + dpp_get<0x4E>(v);      // quad_perm [2,3,0,1]: lane ^ 2
     v = v + dpp_get<0x141>(v);     // row_half_mirror: the other quad of the 8 (every lane of a quad holds the quad's sum by now)
     v = v + dpp_get<0x140>(v);     // row_mirror: the other half of the row of 16
-    v = v + __shfl_xor(v, 16);
-    v = v + __shfl_xor(v, 32);
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3 (+ 0.0f elsewhere)
+    v = v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
     return v;
 }
+constexpr int WAVE_TREE_LANE = 63;
 
 constexpr int OUT_NA = 32;         // the action loops are unrolled over the largest action set the engine accepts
 
@@ -1150,7 +1154,7 @@ __device__ __forceinline__ void out_wave_sums(float (&p)[NS][OUT_NA], int nact, 
 #pragma unroll
             for (int s2 = 0; s2 < NS; s2++) p[s2][a] = wave_tree_sum(p[s2][a]);
         }
-    if (lane == 0) {
+    if (lane == WAVE_TREE_LANE) {
 #pragma unroll
         for (int a = 0; a < OUT_NA; a++)
             if (a < nact) {
